@@ -1,0 +1,281 @@
+#!/usr/bin/env python3
+"""bench.py -- prefill tokens/s of the MixQ W8A8O16 linear path, Llama-2-7B, on N x MI355X.
+
+One "step" = one prefill pass of `--tokens` synthetic tokens (default 512 x 2048 = 1,048,576, BASELINE.json's quoted
+config) through every MixQ'd linear of Llama-2-7B (attention.qkv 12288x4096, mlp.gate 11008x4096, mlp.proj 4096x11008;
+32 layers = 96 operator calls per token chunk), executed in M-chunks of `--chunk` tokens (tokens/s is chunk-invariant,
+SURVEY.md §8).  Every call goes through the drop-in C ABI (`mixq_enqueue_profiled` == `mixq_enqueue` + two event
+records around the GEMM launch).  Inputs (activations, packed weights) are resident in HBM before the timed region.
+
+  python bench.py --gpus N --steps K --warmup W           (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Multi-GPU: the path partitions over tokens with no data-path collective (each rank owns a full copy of the 4.6 GB of
+packed weights and its own token stream) -> default "dp", weak scaling.  `--tp T` runs the north-star TP layout
+instead (rows of W sharded T-ways, one RCCL all-gather of each fp16 output), strong scaling.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+LLAMA2_7B = dict(name="Llama-2-7B", layers=32, linears=[("attention.qkv", 12288, 4096), ("mlp.gate", 11008, 4096),
+                                                       ("mlp.proj", 4096, 11008)])
+NUM_OUTLIERS = 128
+INT8_MFMA_PEAK_TOPS = 5033.0  # dense int8 MFMA: 256 CU x 4 SIMD x 2048 op/clk x 2.4 GHz = 2x the 2.5 PF bf16 dense peak
+                              # (MI355X_MICROARCH.md: "I8 ~2x bf16 rate"; microbenchmark ceiling 4404 TOPS for 32x32x32)
+
+
+class Hip:
+    """hipEvent_* straight from libamdhip64 (events are recorded inside the C ABI on torch's current stream)."""
+
+    def __init__(self):
+        self.lib = ctypes.CDLL("libamdhip64.so")
+        self.lib.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+        self.lib.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
+        self.lib.hipEventDestroy.argtypes = [ctypes.c_void_p]
+
+    def event(self):
+        e = ctypes.c_void_p()
+        assert self.lib.hipEventCreate(ctypes.byref(e)) == 0
+        return e
+
+    def elapsed_ms(self, a, b):
+        ms = ctypes.c_float()
+        rc = self.lib.hipEventElapsedTime(ctypes.byref(ms), a, b)
+        assert rc == 0, f"hipEventElapsedTime rc={rc}"
+        return ms.value
+
+
+def synth_layer(N, K, dev, gen, n0=0, n1=None):
+    """Random-init packed tensors of one MixQ linear, generated on device in the operator's own contract:
+    int8 W ~ round(N(0, 32^2)) clipped (a gaussian weight row quantised with max|w|/127), outlier columns zero."""
+    n1 = N if n1 is None else n1
+    rows = n1 - n0
+    W = torch.randn((rows, K), device=dev, generator=gen).mul_(32.0).round_().clamp_(-127, 127).to(torch.int8)
+    ind = torch.randperm(K, device=dev, generator=gen)[:NUM_OUTLIERS].to(torch.int32)
+    W[:, ind.long()] = 0
+    sW = (torch.rand(rows, device=dev, generator=gen) * 4e-4 + 4e-4).to(torch.float16)
+    fpw = (torch.randn((rows, NUM_OUTLIERS), device=dev, generator=gen) * 0.02).to(torch.float16)
+    qweight = torch.zeros((K, rows), dtype=torch.uint8, device=dev)  # decode-path operand, untouched in prefill
+    return dict(weight=W.view(torch.float16), weights_scaling_factor=sW, fp_weight=fpw,
+                fp_ind=ind.view(torch.float16), qweight=qweight.view(torch.float16), ind_i32=ind)
+
+
+def synth_activation(M, K, ind, dev, gen):
+    A = torch.randn((M, K), device=dev, generator=gen)
+    A[:, ind.long()] *= 20.0  # activation outliers in the fp_ind columns
+    return A.to(torch.float16)
+
+
+def cpu_baseline(seconds_target=15.0):
+    """The oracle (CPU restatement of the reference arithmetic, OpenMP) on a bounded sample: ONE Llama-2-7B layer
+    (its three MixQ linears), M tokens chosen so the run takes ~seconds_target; tokens/s for the full model = M /
+    (32 x t_layer), i.e. extrapolated linearly over the 32 identical layers."""
+    import oracle
+    oracle.build()
+    rng = np.random.default_rng(0)
+    shapes = [(n, k) for _, n, k in LLAMA2_7B["linears"]]
+    layers = []
+    for n, k in shapes:
+        W = rng.integers(-127, 128, size=(n, k), dtype=np.int8)
+        ind = rng.permutation(k)[:NUM_OUTLIERS].astype(np.int32)
+        W[:, ind] = 0
+        layers.append(dict(W=W, sW=(rng.random(n) * 4e-4 + 4e-4).astype(np.float16),
+                           fpW=(rng.standard_normal((n, NUM_OUTLIERS)) * 0.02).astype(np.float16), ind=ind, k=k))
+
+    def run(M):
+        t0 = time.perf_counter()
+        for L in layers:
+            A = rng.standard_normal((M, L["k"])).astype(np.float16)
+            oracle.linear_prefill(A, L["W"], L["sW"], L["fpW"], L["ind"])
+        return time.perf_counter() - t0
+
+    probe_m = 16
+    t = run(probe_m)
+    M = int(max(16, min(4096, probe_m * seconds_target / max(t, 1e-3))))
+    M -= M % 16
+    t = run(M)
+    tok_s = M / (t * LLAMA2_7B["layers"])
+    return {"value": tok_s, "unit": "tokens/s", "cores": oracle.num_threads(), "kind": "port",
+            "sample": f"oracle.linear_prefill on 1 of 32 Llama-2-7B layers (qkv+gate+proj), M={M} tokens, "
+                      f"{t:.1f} s on {oracle.num_threads()} OpenMP threads; scaled x32 layers"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--tokens", type=int, default=512 * 2048, help="tokens per step per DP replica")
+    ap.add_argument("--chunk", type=int, default=8192, help="M of each operator call")
+    ap.add_argument("--tp", type=int, default=1, help="rows-of-W sharding degree (1 = pure DP, no collective)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the MixQ operator has no CPU path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    tp = args.tp
+    assert world % tp == 0
+    dp = world // tp
+    tp_group = None
+    if tp > 1:
+        for g in range(dp):
+            grp = dist.new_group(list(range(g * tp, (g + 1) * tp)))
+            if rank // tp == g:
+                tp_group = grp
+    tp_rank = rank % tp
+
+    from mixq_tensorrt_llm_amd import _lib, parallel
+    from mixq_tensorrt_llm_amd._lib import TensorDesc
+    lib = _lib.load()
+    assert lib.initOpenAiTritonPlugins(None, b"tensorrt_llm")
+    hip = Hip()
+
+    chunk = min(args.chunk, args.tokens)
+    assert args.tokens % chunk == 0
+    n_chunks = args.tokens // chunk
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+
+    # ---- resident state: packed weights of all 96 linears, activations, outputs, workspace -----------------
+    calls = []  # one entry per (layer, linear): prepared ctypes argument blocks
+    keep = []
+    acts, outs, gathered = {}, {}, {}
+    max_ws = 0
+    for layer in range(LLAMA2_7B["layers"]):
+        for name, N, K in LLAMA2_7B["linears"]:
+            n0, n1 = parallel.shard_bounds(N, tp, tp_rank) if tp > 1 else (0, N)
+            t = synth_layer(N, K, dev, gen, n0, n1)
+            if K not in acts:
+                acts[K] = [synth_activation(chunk, K, t["ind_i32"], dev, gen) for _ in range(2)]
+            if (n1 - n0) not in outs:
+                outs[n1 - n0] = torch.empty((chunk, n1 - n0), dtype=torch.float16, device=dev)
+            A = acts[K][layer % 2]
+            out = outs[n1 - n0]
+            ins = [A, t["weight"], t["weights_scaling_factor"], t["fp_weight"], t["fp_ind"], t["qweight"],
+                   t["weights_scaling_factor"]]
+            in_desc = (TensorDesc * 7)(*[TensorDesc.make(x.shape) for x in ins])
+            out_desc = TensorDesc.make(out.shape)
+            in_ptrs = (ctypes.c_void_p * 7)(*[x.data_ptr() for x in ins])
+            out_ptrs = (ctypes.c_void_p * 1)(out.data_ptr())
+            h = lib.mixq_create(chunk, n1 - n0, K)
+            max_ws = max(max_ws, lib.mixq_workspace_size(h, chunk, n1 - n0, K))
+            calls.append((ctypes.c_void_p(h), in_desc, out_desc, in_ptrs, out_ptrs, n1 - n0, K, out))
+            keep.append((t, ins))
+    workspace = torch.empty(max_ws, dtype=torch.uint8, device=dev)
+    ws_ptr = ctypes.c_void_p(workspace.data_ptr())
+    stream = torch.cuda.current_stream(dev)
+    st_ptr = ctypes.c_void_p(stream.cuda_stream)
+    comm_stream = torch.cuda.Stream(dev) if tp > 1 else None
+
+    def one_step(events=None):
+        ei = 0
+        for _ in range(n_chunks):
+            for (h, in_desc, out_desc, in_ptrs, out_ptrs, n_loc, K, out) in calls:
+                e0 = e1 = None
+                if events is not None:
+                    e0, e1 = events[ei]
+                    ei += 1
+                rc = lib.mixq_enqueue_profiled(h, in_desc, ctypes.byref(out_desc), in_ptrs, out_ptrs, ws_ptr, st_ptr,
+                                               e0, e1)
+                if rc != 0:
+                    raise _lib.MixQError(rc, "mixq_enqueue")
+                if tp > 1:
+                    # the ONE collective of the path: all-gather the fp16 output columns (RCCL), overlapped with the
+                    # next call's compute on a side stream; the operator's output buffer is consumed before reuse.
+                    comm_stream.wait_stream(stream)
+                    with torch.cuda.stream(comm_stream):
+                        gathered[n_loc] = parallel.all_gather_columns(out, tp_group, tp)
+                    stream.wait_stream(comm_stream)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        one_step()
+    launches_per_step = n_chunks * len(calls)
+    events = [[(hip.event(), hip.event()) for _ in range(launches_per_step)] for _ in range(args.steps)]
+
+    sync_all()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        one_step(events[s])
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- roofline of the dominant kernel (fused int8 GEMM), from the events recorded inside the timed region ----
+    gemm_ms = 0.0
+    for s in range(args.steps):
+        for (e0, e1) in events[s]:
+            gemm_ms += hip.elapsed_ms(e0, e1)
+    n_launch = args.steps * launches_per_step
+    avg_launch_s = gemm_ms / 1e3 / n_launch
+    ops_per_launch = 0.0
+    for (_, _, _, _, _, n_loc, K, _) in calls:
+        ops_per_launch += 2.0 * chunk * n_loc * K + 2.0 * chunk * n_loc * NUM_OUTLIERS
+    ops_per_launch /= len(calls)
+    achieved_tops = ops_per_launch / avg_launch_s / 1e12
+
+    tokens_total = args.tokens * dp * args.steps
+    value = tokens_total / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
+    int8_gop_per_token = sum(2.0 * n * k for _, n, k in LLAMA2_7B["linears"]) * LLAMA2_7B["layers"] / 1e9
+
+    if rank == 0:
+        res = {
+            "metric": "prefill_tokens_per_sec", "value": value, "unit": "tokens/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak" if tp == 1 else "strong", "vs_baseline": None, "dtype": "int8",
+            "data": "synthetic",
+            "config": {"workload": "Llama-2-7B W8A8O16 (int8_mix) prefill, bs=512 seq=2048: all 96 MixQ linears "
+                                   "(qkv 12288x4096, gate 11008x4096, proj 4096x11008; 32 layers), 128 outlier cols",
+                       "tokens_per_step_per_replica": args.tokens, "m_chunk": chunk,
+                       "parallelism": f"dp{dp}" + (f"xtp{tp}" if tp > 1 else ""),
+                       "int8_gop_per_token": int8_gop_per_token},
+            "gemm_tops_end_to_end": value * int8_gop_per_token / 1e3 / world,
+            "roofline": {"bound": "mfma", "achieved": achieved_tops, "peak": INT8_MFMA_PEAK_TOPS, "unit": "TOP/s",
+                         "frac": achieved_tops / INT8_MFMA_PEAK_TOPS, "traffic": None,
+                         "kernel": "gemm_w8a8o16_kernel<256,256,2,4,EPI_DEQUANT>",
+                         "avg_launch_ms": avg_launch_s * 1e3, "launches": n_launch,
+                         "ops_per_launch": ops_per_launch,
+                         "gemm_share_of_wall": gemm_ms / 1e3 / elapsed},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline()
+            except Exception as e:  # the checker failing must not hide the measurement
+                res["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port",
+                                       "sample": f"failed: {e}"}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,178 @@
+/*
+ * mixq.h -- C ABI of libmixq_mi355x.so, the MI355X (gfx950) MixQ W8A8O16 linear operator.
+ *
+ * Drop-in boundary for the hot path of Qcompiler/MixQ_Tensorrt_LLM.  Each entry point names the
+ * reference interface it replaces (paths relative to the reference tree).  Plain pointers and sizes only:
+ * no C++ types, no torch types.  All device pointers are HIP device pointers; every launch is asynchronous
+ * on `stream` (a hipStream_t passed as void*); nothing here allocates or synchronises.
+ *
+ * Return convention: 0 = success, non-zero = MIXQ_E_* (the reference always returns 0 and ignores
+ * CUTLASS/cuBLAS status -- TsinghuaMixQPlugin.cpp:402,752, kernel/i8gemm.cu:190-192).
+ * No function throws across this boundary.
+ */
+#ifndef MIXQ_H_
+#define MIXQ_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#else
+#include <stdbool.h>
+#endif
+
+#define MIXQ_API __attribute__((visibility("default")))
+
+/* ---- error codes ------------------------------------------------------------------------------ */
+enum {
+    MIXQ_OK = 0,
+    MIXQ_E_BADARG = 1,    /* null pointer, negative size, nbDims out of range */
+    MIXQ_E_SHAPE = 2,     /* K/N not a multiple of 16 (the reference's CUTLASS 16-B alignment), O > 256 ... */
+    MIXQ_E_ALIGN = 3,     /* a device pointer is not 16-byte aligned */
+    MIXQ_E_HIP = 4,       /* a HIP launch failed; hipGetLastError() has the detail */
+    MIXQ_E_WORKSPACE = 5, /* workspace pointer is null where one is needed */
+};
+
+/* ---- tensor descriptor ------------------------------------------------------------------------ */
+/* POD mirror of nvinfer1::PluginTensorDesc as TensorRT 10 lays it out (Dims64 {int32 nbDims; int64 d[8]},
+ * DataType, TensorFormat, float scale) -- the type behind the `inputDesc/outputDesc` arguments of
+ * MixQPlugin::enqueue (TsinghuaMixQPlugin.h:53-54).  Only dims are read (TsinghuaMixQPlugin.cpp:390-399). */
+#define MIXQ_MAX_DIMS 8
+typedef struct mixq_tensor_desc {
+    int32_t nbDims;
+    int64_t d[MIXQ_MAX_DIMS];
+    int32_t type;   /* MIXQ_TYPE_HALF for all 8 tensors (supportsFormatCombination, .cpp:263-320) */
+    int32_t format; /* MIXQ_FORMAT_LINEAR */
+    float scale;
+} mixq_tensor_desc;
+enum { MIXQ_TYPE_FLOAT = 0, MIXQ_TYPE_HALF = 1, MIXQ_TYPE_INT8 = 2, MIXQ_TYPE_INT32 = 3 }; /* nvinfer1::DataType values */
+enum { MIXQ_FORMAT_LINEAR = 0 };
+
+/* nvinfer1::PluginField mirror for the creator path (TsinghuaMixQPlugin.cpp:895-933 reads "m","n","k" INT32). */
+typedef struct mixq_plugin_field {
+    const char* name;
+    const void* data;
+    int32_t type; /* MIXQ_FIELD_INT32 */
+    int32_t length;
+} mixq_plugin_field;
+enum { MIXQ_FIELD_INT32 = 3 }; /* nvinfer1::PluginFieldType::kINT32 */
+
+typedef struct mixq_handle mixq_handle; /* opaque; immutable after creation => enqueue is re-entrant */
+
+/* ---- registry (MixQPlugins.cpp:33-132) -------------------------------------------------------- */
+/* Same symbol, signature and behaviour the reference's loaders call (plugin.py:34-43, summarize.py:45-56,
+ * run.py:41-52): registers creator ("MixQ","1",libNamespace) once per namespace, mutex-guarded, idempotent,
+ * returns true.  `logger` is ignored (there is no TensorRT on MI355X). */
+MIXQ_API bool initOpenAiTritonPlugins(void* logger, const char* libNamespace);
+/* trt.get_plugin_registry().get_plugin_creator(name, version, ns) (plugin.py:55-57): 1 if registered. */
+MIXQ_API int mixq_registry_has_creator(const char* name, const char* version, const char* libNamespace);
+MIXQ_API const char* mixq_plugin_type(void);    /* "MixQ"  getPluginType  .cpp:775-778 */
+MIXQ_API const char* mixq_plugin_version(void); /* "1"     getPluginVersion .cpp:780-783 */
+
+/* ---- plugin object lifecycle (TsinghuaMixQPlugin.h:34-89) ------------------------------------- */
+MIXQ_API mixq_handle* mixq_create(int32_t m, int32_t n, int32_t k);                       /* ctor .cpp:217-225 */
+MIXQ_API mixq_handle* mixq_create_from_fields(const mixq_plugin_field* fields, int32_t nbFields); /* createPlugin .cpp:895-933 */
+MIXQ_API mixq_handle* mixq_deserialize(const void* data, size_t length);                  /* .cpp:227-234, 935-951 */
+MIXQ_API size_t mixq_serialization_size(const mixq_handle* h);                            /* == 12, .cpp:808-811 */
+MIXQ_API void mixq_serialize(const mixq_handle* h, void* buffer);                         /* .cpp:813-820 */
+MIXQ_API mixq_handle* mixq_clone(const mixq_handle* h);                                   /* .cpp:237-242 */
+MIXQ_API void mixq_destroy(mixq_handle* h);                                               /* .cpp:851-855 */
+MIXQ_API int mixq_initialize(mixq_handle* h);                                             /* .cpp:792-799 (no cuBLAS handle to make) */
+MIXQ_API void mixq_terminate(mixq_handle* h);                                             /* .cpp:801-806 */
+MIXQ_API int mixq_get_mnk(const mixq_handle* h, int32_t* m, int32_t* n, int32_t* k);
+MIXQ_API int mixq_set_namespace(mixq_handle* h, const char* ns);                          /* .cpp:857-860 */
+MIXQ_API const char* mixq_get_namespace(const mixq_handle* h);                            /* .cpp:862-865 */
+
+/* ---- shape / format negotiation --------------------------------------------------------------- */
+MIXQ_API int mixq_get_nb_outputs(const mixq_handle* h); /* 1, .cpp:785-788 */
+/* getOutputDimensions (.cpp:244-261): out = in0.dims with last dim replaced by in1.d[0]. */
+MIXQ_API int mixq_get_output_dimensions(const mixq_handle* h, int outputIndex, const mixq_tensor_desc* inputs,
+                                        int nbInputs, mixq_tensor_desc* out);
+/* supportsFormatCombination (.cpp:263-320): pos 0..7 must be HALF + LINEAR. 1 = supported. */
+MIXQ_API int mixq_supports_format_combination(const mixq_handle* h, int pos, const mixq_tensor_desc* inOut,
+                                              int nbInputs, int nbOutputs);
+MIXQ_API int mixq_get_output_data_type(const mixq_handle* h, int index); /* MIXQ_TYPE_HALF, .cpp:768-773 */
+
+/* ---- workspace -------------------------------------------------------------------------------- */
+/* configurePlugin + getWorkspaceSize (.cpp:325-378).  Bytes this implementation needs for M <= maxM:
+ *   qA int8 [maxM*K] | sA fp16 [maxM] | fpA fp16 [maxM*128], each carved at 128-B alignment like
+ *   nextWorkspacePtr (.cpp:206-215).  size_t-clean (the reference overflows int). */
+MIXQ_API size_t mixq_workspace_size(const mixq_handle* h, int64_t maxM, int64_t N, int64_t K);
+/* The reference's own (larger) formula, for callers that size buffers by it:
+ *   max(maxM*K + 2*maxM + 2*K*N, 16*maxM*N), 32 MiB if that is 0. */
+MIXQ_API size_t mixq_reference_workspace_size(int64_t maxM, int64_t N, int64_t K);
+
+/* ---- enqueue: THE hot path (MixQPlugin::enqueue, TsinghuaMixQPlugin.h:53-54, .cpp:384-765) ------
+ * inputs[0] A fp16 [...,K] | [1] weight = int8 [N,K] (declared fp16 [N,K/2]) | [2] weights_scaling_factor fp16 [N]
+ * | [3] fp_weight fp16 [N,128] | [4] fp_ind = int32 [128] (declared fp16 [256]) | [5] qweight = uint8 [K,N]
+ * EETQ-interleaved (declared fp16 [K,N/2]) | [6] scaling_factors fp16 [N] ; outputs[0] fp16 [...,N].
+ * M = prod(in0.d[:-1]), K = in0.d[-1], N = in1.d[0].   M > 4: prefill path; M <= 4: W8A16 decode path.
+ * Asynchronous on `stream`. */
+MIXQ_API int mixq_enqueue(const mixq_handle* h, const mixq_tensor_desc* inputDesc, const mixq_tensor_desc* outputDesc,
+                          const void* const* inputs, void* const* outputs, void* workspace, void* stream);
+
+/* Same work, same launches; additionally records two caller-owned hipEvent_t (may be NULL) on `stream` immediately
+ * before and after the fused-GEMM launch of the prefill path, so a harness can time the dominant kernel inside its
+ * timed region without changing the path (bench.py "roofline"). */
+MIXQ_API int mixq_enqueue_profiled(const mixq_handle* h, const mixq_tensor_desc* inputDesc,
+                                   const mixq_tensor_desc* outputDesc, const void* const* inputs, void* const* outputs,
+                                   void* workspace, void* stream, void* ev_gemm_start, void* ev_gemm_stop);
+
+/* ---- launcher level (kernel/int8FusedDequantizeCUDA.h:3-27, weightonlykernel/fpA_intB_gemm_wrapper.h:8-11) ----- */
+/* int8quant (kernel/i8gemm.cu:139-150): per-row fp16 amax/127 scale + int8 quantisation. */
+MIXQ_API int mixq_int8quant(int rows, int cols, const void* src_f16, int8_t* output, void* scale_f16, void* stream);
+/* ExtractOutliersAndSetToZeros (kernel/i8gemm.cu:226-244): fp_A[m,j] = A[m,ind[j]]; A is NOT modified (T-flavour). */
+MIXQ_API int mixq_extract_outliers(int M, int K, const void* A_f16, void* fpA_f16, const int32_t* ind, int len,
+                                   void* stream);
+/* mixlib twin (quantkernel/mix_cuda/cult.cu:1406-1465): same gather, then writes 0 into A (P-flavour). */
+MIXQ_API int mixq_extract_outliers_set_zero(int M, int K, void* A_f16, void* fpA_f16, const int32_t* ind, int len,
+                                            void* stream);
+/* The fused producer this implementation actually runs in enqueue: one pass over A producing qA, sA and fpA.
+ * zero_outliers = 0: T-flavour (amax includes outlier columns, A untouched; == mixq_extract_outliers + mixq_int8quant).
+ * zero_outliers = 1: mixlib FindRowScaleFusedExtracOutliers (cult.cu:2616-2709): outlier columns count as 0 for amax
+ * and q, and A is written back with zeros in those columns. */
+MIXQ_API int mixq_quant_extract(int M, int K, void* A_f16, int8_t* qA, void* sA_f16, void* fpA_f16, const int32_t* ind,
+                                int len, int zero_outliers, void* stream);
+/* mixlib Int8quantize (quantkernel/mix_cuda/cult.cu:1732-1771): output = (int8) half2int_rn(hdiv(src, scale[row])) with a
+ * caller-supplied per-row fp16 scale. */
+MIXQ_API int mixq_int8_quantize_with_scale(int rows, int cols, const void* src_f16, const void* scale_f16,
+                                           int8_t* output, void* stream);
+/* int8FusedDequantizeCUDA (kernel/i8gemm.cu:151-194): D = fp16(float(A.B^T) * (scale_col[n]*scale_row[m]) + y).
+ * A int8 [M,K], B int8 [N,K], scale_row fp16 [M], scale_col fp16 [N], y/D fp16 [M,N] (y may alias D, may be NULL = 0).
+ * `workspace` is unused (kept for signature parity). */
+MIXQ_API int mixq_int8_fused_dequantize(const int8_t* A, const int8_t* B, const void* scale_row, const void* scale_col,
+                                        const void* y, void* D, int M, int N, int K, char* workspace, void* stream);
+/* Same with the SiLU epilogue (mixlib int8FusedDequantizeSilu, linear_combination_dequant.h:176-270). */
+MIXQ_API int mixq_int8_fused_dequantize_silu(const int8_t* A, const int8_t* B, const void* scale_row,
+                                             const void* scale_col, const void* y, void* D, int M, int N, int K,
+                                             char* workspace, void* stream);
+/* The single fused GEMM this implementation runs in enqueue: int8 main loop + fp16 outlier side-GEMM (O columns,
+ * fp32 accumulate, rounded to fp16 like the reference's separate cuBLAS call) + dequant epilogue, Out written once. */
+MIXQ_API int mixq_gemm_mixed(const int8_t* qA, const int8_t* W, const void* sA, const void* sW, const void* fpA,
+                             const void* fpW, void* Out, int M, int N, int K, int O, void* stream);
+/* gemm (TsinghuaMixQPlugin.cpp:36-77, cuBLAS s8 x s8 -> s32): raw int32 accumulators, for bit-exact checks. */
+MIXQ_API int mixq_gemm_s8s8s32(const int8_t* A, const int8_t* B, int32_t* C, int M, int N, int K, void* stream);
+/* gemmfp16 (TsinghuaMixQPlugin.cpp:122-161): Out = fpA . fpW^T, fp32 accumulate, fp16 out. */
+MIXQ_API int mixq_gemm_fp16(const void* fpA, const void* fpW, void* Out, int M, int N, int O, void* stream);
+/* dequantizationCUDA (kernel/i8gemm.cu:258-300): out = hadd(fp16((float(x)*sRow[m])*sCol[n]), out). */
+MIXQ_API int mixq_dequantization(void* out_f16, const int32_t* x, const void* scaleRow, const void* scaleCol, int M,
+                                 int N, void* stream);
+/* w8_a16_gemm_forward_cuda (weightonlykernel/fpA_intB_gemm_wrapper.cu:29-70): Out = A . dequant(qweight).
+ * weight = EETQ-interleaved uint8 [K,N], scale fp16 [N]. */
+MIXQ_API int mixq_w8a16_gemm_forward(const void* input_f16, const uint8_t* weight, const void* scale_f16,
+                                     void* output_f16, int m, int n, int k, void* stream);
+
+/* ---- host helpers ----------------------------------------------------------------------------- */
+/* preprocess_weights (weightonlykernel/cutlass_kernels/cutlass_preprocessors.cc:536-545), int8, arch 80-90:
+ * row-major int8 [rows=K, cols=N] -> interleaved uint8.  Host memory.  And its inverse. */
+MIXQ_API int mixq_preprocess_weights_int8(uint8_t* preprocessed, const int8_t* row_major, size_t rows, size_t cols);
+MIXQ_API int mixq_unprocess_weights_int8(int8_t* row_major, const uint8_t* preprocessed, size_t rows, size_t cols);
+
+MIXQ_API const char* mixq_version(void);
+MIXQ_API const char* mixq_error_string(int code);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIXQ_H_ */

@@ -1,0 +1,128 @@
+"""ctypes binding of libmixq_mi355x.so (the C ABI declared in include/mixq.h).
+
+The library is built in-tree by ``mixq_tensorrt_llm_amd/csrc/build.sh`` (``__graft_entry__.build()``).  There is no
+CPU or PyTorch fallback: if the shared object is missing, every entry point raises ``MixQLibraryError``.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmixq_mi355x.so")
+
+MIXQ_MAX_DIMS = 8
+MIXQ_TYPE_HALF = 1
+MIXQ_FORMAT_LINEAR = 0
+MIXQ_FIELD_INT32 = 3
+
+ERRORS = {0: "ok", 1: "bad argument", 2: "unsupported shape", 3: "pointer not 16-byte aligned", 4: "HIP error",
+          5: "workspace missing"}
+
+
+class MixQLibraryError(RuntimeError):
+    pass
+
+
+class MixQError(RuntimeError):
+    def __init__(self, code, where=""):
+        self.code = int(code)
+        super().__init__(f"{where}: mixq error {self.code} ({ERRORS.get(self.code, 'unknown')})")
+
+
+class TensorDesc(ctypes.Structure):
+    """POD mirror of nvinfer1::PluginTensorDesc (include/mixq.h: mixq_tensor_desc)."""
+    _fields_ = [("nbDims", ctypes.c_int32), ("d", ctypes.c_int64 * MIXQ_MAX_DIMS), ("type", ctypes.c_int32),
+                ("format", ctypes.c_int32), ("scale", ctypes.c_float)]
+
+    @classmethod
+    def make(cls, shape, dtype=MIXQ_TYPE_HALF):
+        t = cls()
+        t.nbDims = len(shape)
+        for i, s in enumerate(shape):
+            t.d[i] = int(s)
+        t.type, t.format, t.scale = dtype, MIXQ_FORMAT_LINEAR, 1.0
+        return t
+
+
+class PluginField(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char_p), ("data", ctypes.c_void_p), ("type", ctypes.c_int32),
+                ("length", ctypes.c_int32)]
+
+
+_vp, _i, _i64, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
+
+# name -> (restype, argtypes).  Must list every symbol of include/mixq.h (tests/test_abi.py cross-checks).
+SIGNATURES = {
+    "initOpenAiTritonPlugins": (ctypes.c_bool, [_vp, ctypes.c_char_p]),
+    "mixq_registry_has_creator": (_i, [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]),
+    "mixq_plugin_type": (ctypes.c_char_p, []),
+    "mixq_plugin_version": (ctypes.c_char_p, []),
+    "mixq_create": (_vp, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
+    "mixq_create_from_fields": (_vp, [ctypes.POINTER(PluginField), ctypes.c_int32]),
+    "mixq_deserialize": (_vp, [_vp, _sz]),
+    "mixq_serialization_size": (_sz, [_vp]),
+    "mixq_serialize": (None, [_vp, _vp]),
+    "mixq_clone": (_vp, [_vp]),
+    "mixq_destroy": (None, [_vp]),
+    "mixq_initialize": (_i, [_vp]),
+    "mixq_terminate": (None, [_vp]),
+    "mixq_get_mnk": (_i, [_vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32),
+                          ctypes.POINTER(ctypes.c_int32)]),
+    "mixq_set_namespace": (_i, [_vp, ctypes.c_char_p]),
+    "mixq_get_namespace": (ctypes.c_char_p, [_vp]),
+    "mixq_get_nb_outputs": (_i, [_vp]),
+    "mixq_get_output_dimensions": (_i, [_vp, _i, ctypes.POINTER(TensorDesc), _i, ctypes.POINTER(TensorDesc)]),
+    "mixq_supports_format_combination": (_i, [_vp, _i, ctypes.POINTER(TensorDesc), _i, _i]),
+    "mixq_get_output_data_type": (_i, [_vp, _i]),
+    "mixq_workspace_size": (_sz, [_vp, _i64, _i64, _i64]),
+    "mixq_reference_workspace_size": (_sz, [_i64, _i64, _i64]),
+    "mixq_enqueue": (_i, [_vp, ctypes.POINTER(TensorDesc), ctypes.POINTER(TensorDesc), ctypes.POINTER(_vp),
+                          ctypes.POINTER(_vp), _vp, _vp]),
+    "mixq_enqueue_profiled": (_i, [_vp, ctypes.POINTER(TensorDesc), ctypes.POINTER(TensorDesc), ctypes.POINTER(_vp),
+                                   ctypes.POINTER(_vp), _vp, _vp, _vp, _vp]),
+    "mixq_int8quant": (_i, [_i, _i, _vp, _vp, _vp, _vp]),
+    "mixq_extract_outliers": (_i, [_i, _i, _vp, _vp, _vp, _i, _vp]),
+    "mixq_extract_outliers_set_zero": (_i, [_i, _i, _vp, _vp, _vp, _i, _vp]),
+    "mixq_quant_extract": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "mixq_int8_quantize_with_scale": (_i, [_i, _i, _vp, _vp, _vp, _vp]),
+    "mixq_int8_fused_dequantize": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "mixq_int8_fused_dequantize_silu": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "mixq_gemm_mixed": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mixq_gemm_s8s8s32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "mixq_gemm_fp16": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "mixq_dequantization": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "mixq_w8a16_gemm_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "mixq_preprocess_weights_int8": (_i, [_vp, _vp, _sz, _sz]),
+    "mixq_unprocess_weights_int8": (_i, [_vp, _vp, _sz, _sz]),
+    "mixq_version": (ctypes.c_char_p, []),
+    "mixq_error_string": (ctypes.c_char_p, [_i]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree library (RTLD_GLOBAL like the reference loader, plugin.py:34-43) and type every symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MixQLibraryError(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or mixq_tensorrt_llm_amd/csrc/build.sh).  There is no CPU fallback for the MixQ operator.")
+    try:
+        lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    except OSError as e:  # e.g. libamdhip64 not found
+        raise MixQLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise MixQLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc, where):
+    if rc != 0:
+        raise MixQError(rc, where)

@@ -1,0 +1,377 @@
+// Fused W8A8O16 GEMM for gfx950 (MI355X):  Out = fp16( float(qA.W^T) * (sW[n]*sA[m]) + fp16(fpA.fpW^T) )
+//
+// Replaces (reference, CUDA):
+//   kernel/i8gemm.cu:151-194 int8FusedDequantizeCUDA -> CUTLASS symmetric::GemmDequant
+//       (kernel/symmetric/gemm/kernel/gemm_dequant.h:225-380 main loop,
+//        kernel/symmetric/epilogue/thread/linear_combination_dequant.h:120-160 epilogue functor)
+//   TsinghuaMixQPlugin.cpp:122-161 gemmfp16 (cuBLAS fp16 side GEMM over the 128 outlier columns)
+//   TsinghuaMixQPlugin.cpp:36-77   gemm (cuBLAS s8 x s8 -> s32, the unfused route)
+// in ONE launch: Out is written once and never re-read (the reference writes it, re-reads it as C and writes it again).
+//
+// CDNA4 mapping
+//   * v_mfma_i32_32x32x32_i8, operands swapped: MFMA "A" = W rows (n), MFMA "B" = qA rows (m).  The 32x32 C/D layout
+//     then gives every lane 4 consecutive n for one m per accumulator quad -> 8-byte fp16 stores, and the int32
+//     accumulators are bit-exact by construction (integer adds commute).
+//   * K is consumed in 128-byte slices per row.  Both operand tiles are staged global -> LDS with 16-byte
+//     global_load_lds (no VGPR round trip).  The LDS image is lane-linear (hardware rule), so the bank-conflict
+//     swizzle is applied to the per-lane SOURCE address and mirrored on the ds_read_b128 side:
+//         16-B slot of row r = chunk ^ ((r >> 1) & 7)       (128-B rows: conflict-free for ds_read_b128's 16-lane groups)
+//   * double-buffered LDS, one barrier per K slice: loads of slice t+1 are in flight while slice t is multiplied.
+//   * The fp16 outlier side GEMM (O <= 128 columns) runs after the int8 main loop on v_mfma_f32_32x32x16_f16, tile by
+//     tile, re-using the main loop's LDS; its fp32 sum is rounded to fp16 first (the reference materialises it in fp16
+//     through a separate cuBLAS call) and enters the dequant FMA as the addend.
+//   * 1-D grid, XCD-aware remap (block b runs on XCD b % 8): each XCD owns a contiguous run of tiles, walked in groups
+//     of GROUP_M row-tiles so that co-resident workgroups share W / qA panels in that XCD's private L2.
+#include "mixq_device.h"
+#include "mixq_launch.h"
+
+namespace mixq {
+
+constexpr int KSLICE = 128;  // bytes of K per LDS row (int8 elements)
+constexpr int OSLICE = 256;  // bytes per LDS row in the outlier phase (128 fp16)
+constexpr int GROUP_M = 4;
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_w8a8o16_kernel(const GemmParams p)
+{
+    constexpr int NWAVES = WAVES_M * WAVES_N;
+    constexpr int T = NWAVES * 64;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int X_BYTES = BN * KSLICE, Y_BYTES = BM * KSLICE;
+    constexpr int STAGE_BYTES = X_BYTES + Y_BYTES;
+    constexpr int XL = BN * 8 / T, YL = BM * 8 / T;       // 16-B loads per thread per K slice
+    static_assert(BN * 8 % T == 0 && BM * 8 % T == 0, "tile rows must split evenly over the block");
+    static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA");
+    static_assert((BM + BN) * OSLICE <= 2 * STAGE_BYTES, "outlier tiles must fit the main-loop LDS");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    // ---- block -> tile mapping (XCD-aware, grouped) ------------------------------------------------
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int nwg = tiles_m * tiles_n;
+    int t_lin;
+    {
+        const int bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        t_lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3); // bijective for any nwg
+    }
+    int tile_m, tile_n;
+    {
+        const int per_group = GROUP_M * tiles_n;
+        const int g = t_lin / per_group, first_m = g * GROUP_M;
+        const int gsz = min(tiles_m - first_m, GROUP_M);
+        const int within = t_lin - g * per_group;
+        tile_m = first_m + within % gsz;
+        tile_n = within / gsz;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---- per-thread global source offsets for the staging loads ------------------------------------
+    // chunk index c = i*T + tid : LDS row = c/8, LDS slot = c%8 (linear image), source chunk = slot ^ ((row>>1)&7)
+    const int64_t K = p.K;
+    const char* xsrc[XL];
+    const char* ysrc[YL];
+    int xkoff, ykoff; // byte offset of this thread's source chunk inside the 128-B slice (same for every i)
+    {
+        const int slot = tid & 7;
+#pragma unroll
+        for (int i = 0; i < XL; ++i) {
+            const int row = (i * T + tid) >> 3;
+            const int grow = min(n0 + row, p.N - 1); // clamp: rows past N are loaded but never stored
+            xsrc[i] = reinterpret_cast<const char*>(p.B) + (int64_t)grow * K + ((slot ^ ((row >> 1) & 7)) << 4);
+        }
+        xkoff = (slot ^ (((tid >> 3) >> 1) & 7)) << 4; // (row>>1)&7 does not depend on i (T/8 is a multiple of 16)
+#pragma unroll
+        for (int i = 0; i < YL; ++i) {
+            const int row = (i * T + tid) >> 3;
+            const int grow = min(m0 + row, p.M - 1);
+            ysrc[i] = reinterpret_cast<const char*>(p.A) + (int64_t)grow * K + ((slot ^ ((row >> 1) & 7)) << 4);
+        }
+        ykoff = xkoff;
+    }
+    static_assert((T / 8) % 16 == 0, "row swizzle term must be i-invariant");
+
+    const int nk = (p.K + KSLICE - 1) / KSLICE;
+    const bool ktail = (p.K % KSLICE) != 0;
+
+    auto stage = [&](int buf, int kt) {
+        char* xb = smem + buf * STAGE_BYTES;
+        char* yb = xb + X_BYTES;
+        const int64_t kbyte = (int64_t)kt * KSLICE;
+        const bool last_partial = ktail && (kt == nk - 1);
+#pragma unroll
+        for (int i = 0; i < XL; ++i) {
+            const char* s = xsrc[i] + kbyte;
+            if (last_partial && (kbyte + xkoff >= K)) s = static_cast<const char*>(p.zeros);
+            glds16(s, xb + (i * T + wave * 64) * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < YL; ++i) {
+            const char* s = ysrc[i] + kbyte;
+            if (last_partial && (kbyte + ykoff >= K)) s = static_cast<const char*>(p.zeros);
+            glds16(s, yb + (i * T + wave * 64) * 16);
+        }
+    };
+
+    // ---- LDS read offsets for the MFMA fragments -----------------------------------------------------
+    // lane l supplies row (l & 31) and the 16 K-bytes [(l >> 5) * 16, +16) of each 32-byte MFMA k-step.
+    const int lr = lane & 31, lh = lane >> 5;
+    const int sw = (lr >> 1) & 7;
+    int koff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) koff[ks] = ((ks * 2 + lh) ^ sw) << 4;
+    const int xrow_off = (wn * WN + lr) * KSLICE;
+    const int yrow_off = X_BYTES + (wm * WM + lr) * KSLICE;
+
+    v16i acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
+
+    // ---- main loop -------------------------------------------------------------------------------------
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads(); // slice kt has landed for every wave; everyone is done reading the other buffer
+        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        const char* base = smem + (kt & 1) * STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            v4i xf[TN], yf[TM];
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+                xf[i] = *reinterpret_cast<const v4i*>(base + xrow_off + i * 32 * KSLICE + koff[ks]);
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+                yf[j] = *reinterpret_cast<const v4i*>(base + yrow_off + j * 32 * KSLICE + koff[ks]);
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xf[i], yf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- outlier side GEMM: stage fpW / fpA tiles (256-B rows, slot = chunk ^ (row & 15)) ------------
+    const bool has_outliers = (EPI != EPI_INT32) && p.O > 0;
+    if (has_outliers) {
+        __syncthreads(); // main-loop LDS is dead
+        constexpr int OXL = BN * 16 / T, OYL = BM * 16 / T;
+        const int obytes = p.O * 2; // valid bytes per row (O % 8 == 0)
+        const int slot = tid & 15;
+#pragma unroll
+        for (int i = 0; i < OXL; ++i) {
+            const int row = (i * T + tid) >> 4;
+            const int c = (slot ^ (row & 15)) << 4;
+            const int grow = min(n0 + row, p.N - 1);
+            const char* s = reinterpret_cast<const char*>(p.fpW) + (int64_t)grow * obytes + c;
+            if (c >= obytes) s = static_cast<const char*>(p.zeros);
+            glds16(s, smem + (i * T + wave * 64) * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < OYL; ++i) {
+            const int row = (i * T + tid) >> 4;
+            const int c = (slot ^ (row & 15)) << 4;
+            const int grow = min(m0 + row, p.M - 1);
+            const char* s = reinterpret_cast<const char*>(p.fpA) + (int64_t)grow * obytes + c;
+            if (c >= obytes) s = static_cast<const char*>(p.zeros);
+            glds16(s, smem + BN * OSLICE + (i * T + wave * 64) * 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue, one 32x32 tile at a time -----------------------------------------------------------
+    const int osteps = has_outliers ? (p.O + 15) / 16 : 0;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int m = m0 + wm * WM + j * 32 + lr;
+            const int nb0 = n0 + wn * WN + i * 32 + 4 * lh;
+            if (EPI == EPI_INT32) {
+                if (m < p.M) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int nb = nb0 + 8 * g;
+                        if (nb < p.N) {
+                            v4i o = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                            *reinterpret_cast<v4i*>(static_cast<int32_t*>(p.D) + (int64_t)m * p.N + nb) = o;
+                        }
+                    }
+                }
+                continue;
+            }
+            v16f P;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) P[e] = 0.f;
+            if (has_outliers) {
+                const char* xo = smem + (wn * WN + i * 32 + lr) * OSLICE;
+                const char* yo = smem + BN * OSLICE + (wm * WM + j * 32 + lr) * OSLICE;
+                const int sw16 = lr & 15;
+                for (int ks = 0; ks < osteps; ++ks) {
+                    const int off = ((ks * 2 + lh) ^ sw16) << 4;
+                    v8h xf = *reinterpret_cast<const v8h*>(xo + off);
+                    v8h yf = *reinterpret_cast<const v8h*>(yo + off);
+                    P = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf, yf, P, 0, 0, 0);
+                }
+            }
+            if (m < p.M) {
+                const float sa = h2f(p.sA[m]);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int nb = nb0 + 8 * g;
+                    if (nb < p.N) {
+                        const uint2 swb = *reinterpret_cast<const uint2*>(p.sW + nb);
+                        const uint16_t swh[4] = {(uint16_t)(swb.x & 0xffffu), (uint16_t)(swb.x >> 16),
+                                                 (uint16_t)(swb.y & 0xffffu), (uint16_t)(swb.y >> 16)};
+                        uint16_t yh[4] = {0, 0, 0, 0};
+                        if (p.Y != nullptr) {
+                            const uint2 yb = *reinterpret_cast<const uint2*>(p.Y + (int64_t)m * p.N + nb);
+                            yh[0] = (uint16_t)(yb.x & 0xffffu), yh[1] = (uint16_t)(yb.x >> 16);
+                            yh[2] = (uint16_t)(yb.y & 0xffffu), yh[3] = (uint16_t)(yb.y >> 16);
+                        }
+                        uint16_t oh[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            // addend: the fp16-rounded outlier product (cuBLAS writes fp16) or the caller's y
+                            const float c = has_outliers ? h2f(f2h_bits(P[4 * g + e])) : h2f(yh[e]);
+                            float v = __builtin_fmaf((float)acc[i][j][4 * g + e], h2f(swh[e]) * sa, c);
+                            if (EPI == EPI_DEQUANT_SILU) v = v / (1.f + __expf(-v));
+                            oh[e] = f2h_bits(v);
+                        }
+                        uint2 o;
+                        o.x = (unsigned)oh[0] | ((unsigned)oh[1] << 16);
+                        o.y = (unsigned)oh[2] | ((unsigned)oh[3] << 16);
+                        *reinterpret_cast<uint2*>(static_cast<uint16_t*>(p.D) + (int64_t)m * p.N + nb) = o;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+static hipError_t launch_cfg(const GemmParams& p, hipStream_t st)
+{
+    constexpr int T = WAVES_M * WAVES_N * 64;
+    constexpr size_t lds = 2 * (size_t)(BM + BN) * KSLICE;
+    auto kern = gemm_w8a8o16_kernel<BM, BN, WAVES_M, WAVES_N, EPI>;
+    static bool attr_done = false; // benign race: idempotent
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(T), lds, st, p);
+    return hipGetLastError();
+}
+
+template <int EPI>
+static hipError_t launch_epi(const GemmParams& p, hipStream_t st)
+{
+    if (p.M <= 64) return launch_cfg<32, 128, 1, 4, EPI>(p, st);
+    if (p.M <= 128 || (int64_t)p.M * p.N <= (int64_t)256 * 256 * 128) return launch_cfg<128, 128, 2, 2, EPI>(p, st);
+    return launch_cfg<256, 256, 2, 4, EPI>(p, st);
+}
+
+hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st)
+{
+    if (p.M <= 0 || p.N <= 0) return hipSuccess;
+    switch (epi) {
+    case EPI_DEQUANT: return launch_epi<EPI_DEQUANT>(p, st);
+    case EPI_DEQUANT_SILU: return launch_epi<EPI_DEQUANT_SILU>(p, st);
+    default: return launch_epi<EPI_INT32>(p, st);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Stand-alone pieces of the reference API surface that enqueue() no longer needs (kept for drop-in parity).
+
+// gemmfp16 (TsinghuaMixQPlugin.cpp:122-161): Out[M,N] = fp16(fpA[M,O] . fpW[N,O]^T), fp32 accumulate.
+// One wave per 32x32 output tile; operands straight from global (O is tiny, both panels stay in L2).
+__global__ __launch_bounds__(256) void gemm_fp16_kernel(const uint16_t* __restrict__ fpA,
+                                                         const uint16_t* __restrict__ fpW, uint16_t* __restrict__ Out,
+                                                         int M, int N, int O)
+{
+    const int lane = threadIdx.x & 63, lr = lane & 31, lh = lane >> 5;
+    const int tiles_n = (N + 31) / 32;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int tm = (int)(tile / tiles_n), tn = (int)(tile % tiles_n);
+    if ((int64_t)tm * 32 >= M) return;
+    const int mrow = min(tm * 32 + lr, M - 1), nrow = min(tn * 32 + lr, N - 1);
+    v16f P;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) P[e] = 0.f;
+    for (int k0 = 0; k0 < O; k0 += 16) {
+        const int k = k0 + lh * 8;
+        v8h xf, yf;
+        if (k + 8 <= O) {
+            xf = *reinterpret_cast<const v8h*>(fpW + (int64_t)nrow * O + k);
+            yf = *reinterpret_cast<const v8h*>(fpA + (int64_t)mrow * O + k);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xf[e] = (_Float16)0.f, yf[e] = (_Float16)0.f;
+        }
+        P = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf, yf, P, 0, 0, 0);
+    }
+    const int m = tm * 32 + lr;
+    if (m >= M) return;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int nb = tn * 32 + 8 * g + 4 * lh;
+        if (nb < N) {
+            uint2 o;
+            o.x = (unsigned)f2h_bits(P[4 * g]) | ((unsigned)f2h_bits(P[4 * g + 1]) << 16);
+            o.y = (unsigned)f2h_bits(P[4 * g + 2]) | ((unsigned)f2h_bits(P[4 * g + 3]) << 16);
+            *reinterpret_cast<uint2*>(Out + (int64_t)m * N + nb) = o;
+        }
+    }
+}
+
+hipError_t launch_gemm_fp16(const void* fpA, const void* fpW, void* Out, int M, int N, int O, hipStream_t st)
+{
+    if (M <= 0 || N <= 0) return hipSuccess;
+    const int64_t tiles = (int64_t)((M + 31) / 32) * ((N + 31) / 32);
+    hipLaunchKernelGGL(gemm_fp16_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st,
+                       static_cast<const uint16_t*>(fpA), static_cast<const uint16_t*>(fpW),
+                       static_cast<uint16_t*>(Out), M, N, O);
+    return hipGetLastError();
+}
+
+// dequantizationKernel (kernel/i8gemm.cu:258-279): out = hadd( fp16((float(x)*sRow[m])*sCol[n]), out ).
+__global__ __launch_bounds__(256) void dequantization_kernel(uint16_t* __restrict__ out, const int32_t* __restrict__ x,
+                                                              const uint16_t* __restrict__ sRow,
+                                                              const uint16_t* __restrict__ sCol, int M, int N)
+{
+    const int64_t total = (int64_t)M * N;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int m = (int)(i / N), n = (int)(i % N);
+        const float t = ((float)x[i] * h2f(sRow[m])) * h2f(sCol[n]);
+        out[i] = f2h_bits(h2f(f2h_bits(t)) + h2f(out[i]));
+    }
+}
+
+hipError_t launch_dequantization(void* out, const int32_t* x, const void* sRow, const void* sCol, int M, int N,
+                                 hipStream_t st)
+{
+    if (M <= 0 || N <= 0) return hipSuccess;
+    const int64_t total = (int64_t)M * N;
+    const int64_t want = (total + 255) / 256;
+    const unsigned grid = (unsigned)(want < 2048 ? want : 2048);
+    hipLaunchKernelGGL(dequantization_kernel, dim3(grid), dim3(256), 0, st, static_cast<uint16_t*>(out), x,
+                       static_cast<const uint16_t*>(sRow), static_cast<const uint16_t*>(sCol), M, N);
+    return hipGetLastError();
+}
+
+} // namespace mixq

@@ -1,0 +1,486 @@
+// Host side of libmixq_mi355x.so: plugin object, creator registry, enqueue orchestration and the C ABI declared in
+// include/mixq.h.  Mirrors the host half of the reference (TsinghuaMixQPlugin.{h,cpp}, MixQPlugins.cpp) without
+// TensorRT: there is no nvinfer on MI355X, so the "plugin" is a plain C++ object behind an opaque C handle.
+#include "../../include/mixq.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <unordered_set>
+#include <vector>
+
+#include "mixq_launch.h"
+
+namespace mixq {
+// 256 bytes of device zeros: source of the K / O tail chunks of the staging loads (never written).
+__device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
+
+static const void* zero_page()
+{
+    static const void* ptr = [] {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_zero_page)) != hipSuccess) p = nullptr;
+        return static_cast<const void*>(p);
+    }();
+    return ptr;
+}
+} // namespace mixq
+
+namespace {
+
+constexpr int kNumOutliers = 128;      // TsinghuaMixQPlugin.cpp:518, plugin.py:102-105
+constexpr int kSmallMFastPath = 4;     // TsinghuaMixQPlugin.cpp:472, fpA_intB_gemm_wrapper.h:4
+constexpr size_t kWorkspaceAlign = 128; // kCudaMemAlign, TsinghuaMixQPlugin.cpp:204
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline int hip_rc(hipError_t e) { return e == hipSuccess ? MIXQ_OK : MIXQ_E_HIP; }
+
+} // namespace
+
+struct mixq_handle {
+    int32_t mm, mn, mk; // serialized state: exactly the reference's three ints (TsinghuaMixQPlugin.cpp:813-820)
+    std::string ns;
+    bool initialized = false;
+};
+
+// ------------------------------------------------------------------------------------------- registry ---
+namespace {
+class CreatorRegistry { // TritonPluginCreatorRegistry, MixQPlugins.cpp:33-114
+public:
+    static CreatorRegistry& instance()
+    {
+        static CreatorRegistry r;
+        return r;
+    }
+    bool add(const char* ns)
+    {
+        std::lock_guard<std::mutex> lock(mu_);
+        keys_.insert(key("MixQ", "1", ns ? ns : ""));
+        return true;
+    }
+    bool has(const char* name, const char* version, const char* ns)
+    {
+        std::lock_guard<std::mutex> lock(mu_);
+        return keys_.count(key(name ? name : "", version ? version : "", ns ? ns : "")) != 0;
+    }
+
+private:
+    static std::string key(const char* name, const char* version, const char* ns)
+    {
+        return std::string(ns) + "::" + name + " version " + version;
+    }
+    std::mutex mu_;
+    std::unordered_set<std::string> keys_;
+};
+} // namespace
+
+extern "C" {
+
+bool initOpenAiTritonPlugins(void* /*logger*/, const char* libNamespace)
+{
+    try {
+        return CreatorRegistry::instance().add(libNamespace);
+    } catch (...) {
+        return false;
+    }
+}
+
+int mixq_registry_has_creator(const char* name, const char* version, const char* libNamespace)
+{
+    try {
+        return CreatorRegistry::instance().has(name, version, libNamespace) ? 1 : 0;
+    } catch (...) {
+        return 0;
+    }
+}
+
+const char* mixq_plugin_type(void) { return "MixQ"; }
+const char* mixq_plugin_version(void) { return "1"; }
+const char* mixq_version(void) { return "mixq-mi355x 0.1 (gfx950)"; }
+
+const char* mixq_error_string(int code)
+{
+    switch (code) {
+    case MIXQ_OK: return "ok";
+    case MIXQ_E_BADARG: return "bad argument";
+    case MIXQ_E_SHAPE: return "unsupported shape";
+    case MIXQ_E_ALIGN: return "pointer not 16-byte aligned";
+    case MIXQ_E_HIP: return "HIP error";
+    case MIXQ_E_WORKSPACE: return "workspace missing";
+    default: return "unknown";
+    }
+}
+
+// ------------------------------------------------------------------------------------------ lifecycle ---
+mixq_handle* mixq_create(int32_t m, int32_t n, int32_t k)
+{
+    mixq_handle* h = new (std::nothrow) mixq_handle;
+    if (!h) return nullptr;
+    h->mm = m, h->mn = n, h->mk = k;
+    return h;
+}
+
+mixq_handle* mixq_create_from_fields(const mixq_plugin_field* fields, int32_t nbFields)
+{
+    // createPlugin parses "m","n","k" (TsinghuaMixQPlugin.cpp:906-919) although the creator advertises
+    // "mm","mn","mk" (:873-875); unknown names are ignored and missing ones stay 0, as in the reference.
+    int32_t m = 0, n = 0, k = 0;
+    if (nbFields > 0 && !fields) return nullptr;
+    for (int i = 0; i < nbFields; ++i) {
+        const mixq_plugin_field& f = fields[i];
+        if (!f.name || !f.data) continue;
+        int32_t v;
+        std::memcpy(&v, f.data, sizeof(v));
+        if (!std::strcmp(f.name, "m")) m = v;
+        else if (!std::strcmp(f.name, "n")) n = v;
+        else if (!std::strcmp(f.name, "k")) k = v;
+    }
+    return mixq_create(m, n, k);
+}
+
+mixq_handle* mixq_deserialize(const void* data, size_t length)
+{
+    if (!data || length < 3 * sizeof(int32_t)) return nullptr;
+    int32_t v[3];
+    std::memcpy(v, data, sizeof(v));
+    return mixq_create(v[0], v[1], v[2]);
+}
+
+size_t mixq_serialization_size(const mixq_handle*) { return 3 * sizeof(int32_t); }
+
+void mixq_serialize(const mixq_handle* h, void* buffer)
+{
+    if (!h || !buffer) return;
+    const int32_t v[3] = {h->mm, h->mn, h->mk};
+    std::memcpy(buffer, v, sizeof(v));
+}
+
+mixq_handle* mixq_clone(const mixq_handle* h)
+{
+    if (!h) return nullptr;
+    mixq_handle* c = new (std::nothrow) mixq_handle(*h);
+    return c;
+}
+
+void mixq_destroy(mixq_handle* h) { delete h; }
+
+int mixq_initialize(mixq_handle* h)
+{
+    if (!h) return MIXQ_E_BADARG;
+    h->initialized = true; // the reference creates a cuBLAS handle here; nothing to create on this path
+    return MIXQ_OK;
+}
+
+void mixq_terminate(mixq_handle* h)
+{
+    if (h) h->initialized = false;
+}
+
+int mixq_get_mnk(const mixq_handle* h, int32_t* m, int32_t* n, int32_t* k)
+{
+    if (!h) return MIXQ_E_BADARG;
+    if (m) *m = h->mm;
+    if (n) *n = h->mn;
+    if (k) *k = h->mk;
+    return MIXQ_OK;
+}
+
+int mixq_set_namespace(mixq_handle* h, const char* ns)
+{
+    if (!h) return MIXQ_E_BADARG;
+    try {
+        h->ns = ns ? ns : "";
+    } catch (...) {
+        return MIXQ_E_BADARG;
+    }
+    return MIXQ_OK;
+}
+
+const char* mixq_get_namespace(const mixq_handle* h) { return h ? h->ns.c_str() : ""; }
+
+// --------------------------------------------------------------------------------- shape negotiation ---
+int mixq_get_nb_outputs(const mixq_handle*) { return 1; }
+
+int mixq_get_output_dimensions(const mixq_handle*, int outputIndex, const mixq_tensor_desc* inputs, int nbInputs,
+                               mixq_tensor_desc* out)
+{
+    if (outputIndex != 0 || !inputs || !out || nbInputs < 2) return MIXQ_E_BADARG;
+    const int nb = inputs[0].nbDims;
+    if (nb < 1 || nb > MIXQ_MAX_DIMS || inputs[1].nbDims < 1) return MIXQ_E_BADARG;
+    *out = inputs[0];
+    out->d[nb - 1] = inputs[1].d[0];
+    return MIXQ_OK;
+}
+
+int mixq_supports_format_combination(const mixq_handle*, int pos, const mixq_tensor_desc* inOut, int nbInputs,
+                                     int nbOutputs)
+{
+    if (!inOut || pos < 0 || pos >= nbInputs + nbOutputs || pos > 7) return 0;
+    return (inOut[pos].type == MIXQ_TYPE_HALF && inOut[pos].format == MIXQ_FORMAT_LINEAR) ? 1 : 0;
+}
+
+int mixq_get_output_data_type(const mixq_handle*, int) { return MIXQ_TYPE_HALF; }
+
+// ------------------------------------------------------------------------------------------ workspace ---
+size_t mixq_workspace_size(const mixq_handle*, int64_t maxM, int64_t /*N*/, int64_t K)
+{
+    if (maxM <= 0 || K <= 0) return kWorkspaceAlign;
+    size_t s = kWorkspaceAlign; // slack for aligning the base like nextWorkspacePtr(ptr, 0)
+    s += align_up((size_t)maxM * (size_t)K, kWorkspaceAlign);                                 // qA
+    s += align_up((size_t)maxM * sizeof(uint16_t), kWorkspaceAlign);                          // sA
+    s += align_up((size_t)maxM * (size_t)kNumOutliers * sizeof(uint16_t), kWorkspaceAlign);   // fpA
+    return s;
+}
+
+size_t mixq_reference_workspace_size(int64_t maxM, int64_t N, int64_t K)
+{
+    if (maxM < 0 || N < 0 || K < 0) return 0;
+    const size_t a = (size_t)maxM * (size_t)K + (size_t)maxM * 2 + (size_t)K * (size_t)N * 2;
+    const size_t b = (size_t)maxM * (size_t)N * 2 * 8;
+    const size_t w = a > b ? a : b;
+    return w ? w : (size_t)33554432; // CUBLAS_WORKSPACE_SIZE fallback, TsinghuaMixQPlugin.cpp:23,372-376
+}
+
+// ---------------------------------------------------------------------------------------- launchers ----
+int mixq_int8quant(int rows, int cols, const void* src, int8_t* output, void* scale, void* stream)
+{
+    if (rows < 0 || cols <= 0 || (rows > 0 && (!src || !output || !scale))) return MIXQ_E_BADARG;
+    if (cols % 8) return MIXQ_E_SHAPE;
+    if (!aligned16(src) || (reinterpret_cast<uintptr_t>(output) & 7u)) return MIXQ_E_ALIGN;
+    return hip_rc(mixq::launch_quant_extract(const_cast<void*>(src), output, scale, nullptr, nullptr, rows, cols, 0,
+                                             false, static_cast<hipStream_t>(stream)));
+}
+
+int mixq_extract_outliers(int M, int K, const void* A, void* fpA, const int32_t* ind, int len, void* stream)
+{
+    if (M < 0 || K <= 0 || len < 0 || (M > 0 && len > 0 && (!A || !fpA || !ind))) return MIXQ_E_BADARG;
+    return hip_rc(mixq::launch_extract(const_cast<void*>(A), fpA, ind, M, K, len, false,
+                                       static_cast<hipStream_t>(stream)));
+}
+
+int mixq_extract_outliers_set_zero(int M, int K, void* A, void* fpA, const int32_t* ind, int len, void* stream)
+{
+    if (M < 0 || K <= 0 || len < 0 || (M > 0 && len > 0 && (!A || !fpA || !ind))) return MIXQ_E_BADARG;
+    return hip_rc(mixq::launch_extract(A, fpA, ind, M, K, len, true, static_cast<hipStream_t>(stream)));
+}
+
+int mixq_quant_extract(int M, int K, void* A, int8_t* qA, void* sA, void* fpA, const int32_t* ind, int len,
+                       int zero_outliers, void* stream)
+{
+    if (M < 0 || K <= 0 || len < 0 || (M > 0 && (!A || !qA || !sA))) return MIXQ_E_BADARG;
+    if (len > 0 && (!fpA || !ind)) return MIXQ_E_BADARG;
+    if (K % 8) return MIXQ_E_SHAPE;
+    if (!aligned16(A) || (reinterpret_cast<uintptr_t>(qA) & 7u)) return MIXQ_E_ALIGN;
+    return hip_rc(mixq::launch_quant_extract(A, qA, sA, len > 0 ? fpA : nullptr, ind, M, K, len, zero_outliers != 0,
+                                             static_cast<hipStream_t>(stream)));
+}
+
+int mixq_int8_quantize_with_scale(int rows, int cols, const void* src, const void* scale, int8_t* output, void* stream)
+{
+    if (rows < 0 || cols <= 0 || (rows > 0 && (!src || !scale || !output))) return MIXQ_E_BADARG;
+    if (cols % 8) return MIXQ_E_SHAPE;
+    if (!aligned16(src) || (reinterpret_cast<uintptr_t>(output) & 7u)) return MIXQ_E_ALIGN;
+    return hip_rc(mixq::launch_quant_with_scale(src, scale, output, rows, cols, static_cast<hipStream_t>(stream)));
+}
+
+static int fused_dequant_impl(const int8_t* A, const int8_t* B, const void* scale_row, const void* scale_col,
+                              const void* y, void* D, int M, int N, int K, int epi, void* stream)
+{
+    if (M < 0 || N < 0 || K <= 0) return MIXQ_E_BADARG;
+    if (M == 0 || N == 0) return MIXQ_OK;
+    if (!A || !B || !scale_row || !scale_col || !D) return MIXQ_E_BADARG;
+    if (K % 16 || N % 16) return MIXQ_E_SHAPE; // CUTLASS 16-B alignment of the reference
+    if (!aligned16(A) || !aligned16(B) || !aligned16(D) || !aligned16(scale_col) || (y && !aligned16(y)))
+        return MIXQ_E_ALIGN;
+    mixq::GemmParams p{};
+    p.A = A, p.B = B;
+    p.sA = static_cast<const uint16_t*>(scale_row), p.sW = static_cast<const uint16_t*>(scale_col);
+    p.Y = static_cast<const uint16_t*>(y), p.D = D;
+    p.zeros = mixq::zero_page();
+    p.M = M, p.N = N, p.K = K, p.O = 0;
+    if (!p.zeros) return MIXQ_E_HIP;
+    return hip_rc(mixq::launch_gemm(p, epi, static_cast<hipStream_t>(stream)));
+}
+
+int mixq_int8_fused_dequantize(const int8_t* A, const int8_t* B, const void* scale_row, const void* scale_col,
+                               const void* y, void* D, int M, int N, int K, char* /*workspace*/, void* stream)
+{
+    return fused_dequant_impl(A, B, scale_row, scale_col, y, D, M, N, K, mixq::EPI_DEQUANT, stream);
+}
+
+int mixq_int8_fused_dequantize_silu(const int8_t* A, const int8_t* B, const void* scale_row, const void* scale_col,
+                                    const void* y, void* D, int M, int N, int K, char* /*workspace*/, void* stream)
+{
+    return fused_dequant_impl(A, B, scale_row, scale_col, y, D, M, N, K, mixq::EPI_DEQUANT_SILU, stream);
+}
+
+int mixq_gemm_mixed(const int8_t* qA, const int8_t* W, const void* sA, const void* sW, const void* fpA,
+                    const void* fpW, void* Out, int M, int N, int K, int O, void* stream)
+{
+    if (M < 0 || N < 0 || K <= 0 || O < 0) return MIXQ_E_BADARG;
+    if (M == 0 || N == 0) return MIXQ_OK;
+    if (!qA || !W || !sA || !sW || !Out || (O > 0 && (!fpA || !fpW))) return MIXQ_E_BADARG;
+    if (K % 16 || N % 16 || O % 8) return MIXQ_E_SHAPE;
+    if (!aligned16(qA) || !aligned16(W) || !aligned16(Out) || !aligned16(sW) || (O > 0 && (!aligned16(fpA) || !aligned16(fpW))))
+        return MIXQ_E_ALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    mixq::GemmParams p{};
+    p.A = qA, p.B = W;
+    p.sA = static_cast<const uint16_t*>(sA), p.sW = static_cast<const uint16_t*>(sW);
+    p.D = Out;
+    p.zeros = mixq::zero_page();
+    if (!p.zeros) return MIXQ_E_HIP;
+    p.M = M, p.N = N, p.K = K;
+    if (O <= kNumOutliers) {
+        p.fpA = static_cast<const uint16_t*>(fpA), p.fpW = static_cast<const uint16_t*>(fpW), p.O = O;
+        return hip_rc(mixq::launch_gemm(p, mixq::EPI_DEQUANT, st));
+    }
+    // more outlier columns than one LDS pass holds: the reference's own two-step order (side GEMM into Out, then C = D = Out)
+    hipError_t e = mixq::launch_gemm_fp16(fpA, fpW, Out, M, N, O, st);
+    if (e != hipSuccess) return MIXQ_E_HIP;
+    p.Y = static_cast<const uint16_t*>(Out), p.O = 0;
+    return hip_rc(mixq::launch_gemm(p, mixq::EPI_DEQUANT, st));
+}
+
+int mixq_gemm_s8s8s32(const int8_t* A, const int8_t* B, int32_t* C, int M, int N, int K, void* stream)
+{
+    if (M < 0 || N < 0 || K <= 0) return MIXQ_E_BADARG;
+    if (M == 0 || N == 0) return MIXQ_OK;
+    if (!A || !B || !C) return MIXQ_E_BADARG;
+    if (K % 16 || N % 16) return MIXQ_E_SHAPE;
+    if (!aligned16(A) || !aligned16(B) || !aligned16(C)) return MIXQ_E_ALIGN;
+    mixq::GemmParams p{};
+    p.A = A, p.B = B, p.D = C;
+    p.zeros = mixq::zero_page();
+    if (!p.zeros) return MIXQ_E_HIP;
+    p.M = M, p.N = N, p.K = K, p.O = 0;
+    return hip_rc(mixq::launch_gemm(p, mixq::EPI_INT32, static_cast<hipStream_t>(stream)));
+}
+
+int mixq_gemm_fp16(const void* fpA, const void* fpW, void* Out, int M, int N, int O, void* stream)
+{
+    if (M < 0 || N < 0 || O < 0) return MIXQ_E_BADARG;
+    if (M == 0 || N == 0) return MIXQ_OK;
+    if (!fpA || !fpW || !Out) return MIXQ_E_BADARG;
+    if (O % 8 || N % 4) return MIXQ_E_SHAPE;
+    if (!aligned16(fpA) || !aligned16(fpW) || !aligned16(Out)) return MIXQ_E_ALIGN;
+    return hip_rc(mixq::launch_gemm_fp16(fpA, fpW, Out, M, N, O, static_cast<hipStream_t>(stream)));
+}
+
+int mixq_dequantization(void* out, const int32_t* x, const void* scaleRow, const void* scaleCol, int M, int N,
+                        void* stream)
+{
+    if (M < 0 || N < 0) return MIXQ_E_BADARG;
+    if (M == 0 || N == 0) return MIXQ_OK;
+    if (!out || !x || !scaleRow || !scaleCol) return MIXQ_E_BADARG;
+    return hip_rc(mixq::launch_dequantization(out, x, scaleRow, scaleCol, M, N, static_cast<hipStream_t>(stream)));
+}
+
+int mixq_w8a16_gemm_forward(const void* input, const uint8_t* weight, const void* scale, void* output, int m, int n,
+                            int k, void* stream)
+{
+    if (m < 0 || n < 0 || k <= 0) return MIXQ_E_BADARG;
+    if (m == 0 || n == 0) return MIXQ_OK;
+    if (!input || !weight || !scale || !output) return MIXQ_E_BADARG;
+    if (k % 64 || n % 2) return MIXQ_E_SHAPE; // the interleaved layout needs 64-row tiles and column pairs
+    if (!aligned16(input) || !aligned16(weight)) return MIXQ_E_ALIGN;
+    return hip_rc(mixq::launch_w8a16(input, weight, scale, output, m, n, k, static_cast<hipStream_t>(stream)));
+}
+
+// ------------------------------------------------------------------------------------------- enqueue ----
+static int enqueue_impl(const mixq_handle* h, const mixq_tensor_desc* inputDesc, const void* const* inputs,
+                        void* const* outputs, void* workspace, void* stream, void* ev_gemm_start, void* ev_gemm_stop)
+{
+    if (!h || !inputDesc || !inputs || !outputs) return MIXQ_E_BADARG;
+    const mixq_tensor_desc& a = inputDesc[0];
+    if (a.nbDims < 1 || a.nbDims > MIXQ_MAX_DIMS || inputDesc[1].nbDims < 1) return MIXQ_E_BADARG;
+    int64_t M = 1;
+    for (int i = 0; i < a.nbDims - 1; ++i) M *= a.d[i];      // TsinghuaMixQPlugin.cpp:390-394
+    const int64_t K = a.d[a.nbDims - 1];                     // :396
+    const int64_t N = inputDesc[1].d[0];                     // :399
+    if (M < 0 || K <= 0 || N <= 0 || M > INT32_MAX || K > INT32_MAX || N > INT32_MAX) return MIXQ_E_BADARG;
+    if (M == 0) return MIXQ_OK;
+    for (int i = 0; i < 7; ++i)
+        if (!inputs[i]) return MIXQ_E_BADARG;
+    if (!outputs[0]) return MIXQ_E_BADARG;
+
+    void* Out = outputs[0];
+    const void* A = inputs[0];
+    const int8_t* W = static_cast<const int8_t*>(inputs[1]);
+    const void* scale_b = inputs[2];
+    const void* fp_weight = inputs[3];
+    const int32_t* ind = static_cast<const int32_t*>(inputs[4]);
+    const uint8_t* q_weight = static_cast<const uint8_t*>(inputs[5]);
+    const void* scaling_factors = inputs[6];
+
+    if (M > kSmallMFastPath) {
+        if (!workspace) return MIXQ_E_WORKSPACE;
+        // workspace carve, same order and 128-B alignment as TsinghuaMixQPlugin.cpp:404-421
+        uintptr_t base = align_up(reinterpret_cast<uintptr_t>(workspace), kWorkspaceAlign);
+        int8_t* qA = reinterpret_cast<int8_t*>(base);
+        base = align_up(base + (size_t)M * (size_t)K, kWorkspaceAlign);
+        void* sA = reinterpret_cast<void*>(base);
+        base = align_up(base + (size_t)M * sizeof(uint16_t), kWorkspaceAlign);
+        void* fpA = reinterpret_cast<void*>(base);
+
+        int rc = mixq_quant_extract((int)M, (int)K, const_cast<void*>(A), qA, sA, fpA, ind, kNumOutliers, 0, stream);
+        if (rc != MIXQ_OK) return rc;
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        if (ev_gemm_start && hipEventRecord(static_cast<hipEvent_t>(ev_gemm_start), st) != hipSuccess) return MIXQ_E_HIP;
+        rc = mixq_gemm_mixed(qA, W, sA, scale_b, fpA, fp_weight, Out, (int)M, (int)N, (int)K, kNumOutliers, stream);
+        if (ev_gemm_stop && hipEventRecord(static_cast<hipEvent_t>(ev_gemm_stop), st) != hipSuccess) return MIXQ_E_HIP;
+        return rc;
+    }
+    return mixq_w8a16_gemm_forward(A, q_weight, scaling_factors, Out, (int)M, (int)N, (int)K, stream);
+}
+
+int mixq_enqueue(const mixq_handle* h, const mixq_tensor_desc* inputDesc, const mixq_tensor_desc* /*outputDesc*/,
+                 const void* const* inputs, void* const* outputs, void* workspace, void* stream)
+{
+    return enqueue_impl(h, inputDesc, inputs, outputs, workspace, stream, nullptr, nullptr);
+}
+
+int mixq_enqueue_profiled(const mixq_handle* h, const mixq_tensor_desc* inputDesc,
+                          const mixq_tensor_desc* /*outputDesc*/, const void* const* inputs, void* const* outputs,
+                          void* workspace, void* stream, void* ev_gemm_start, void* ev_gemm_stop)
+{
+    return enqueue_impl(h, inputDesc, inputs, outputs, workspace, stream, ev_gemm_start, ev_gemm_stop);
+}
+
+// ------------------------------------------------------------------------------------- host helpers ----
+static inline size_t swap12(size_t x) { return (x & ~(size_t)3) | ((x & 1) << 1) | ((x & 2) >> 1); }
+
+// physical byte offset of logical element (k, n) in the interleaved image (see decode_kernels.hip header)
+static inline size_t eetq_offset(size_t k, size_t n, size_t K)
+{
+    static const int inv[16] = {0, 1, 4, 5, 8, 9, 12, 13, 2, 3, 6, 7, 10, 11, 14, 15}; // inverse of perm16
+    const size_t tb = k / 64, g = (k % 64) / 16, t = inv[k % 16];
+    const size_t xprime = g * 16 + t;
+    return (n / 2) * 2 * K + tb * 128 + (n % 2) * 64 + swap12(xprime);
+}
+
+int mixq_preprocess_weights_int8(uint8_t* preprocessed, const int8_t* row_major, size_t rows, size_t cols)
+{
+    if (!preprocessed || !row_major) return MIXQ_E_BADARG;
+    if (rows % 64 || cols % 2) return MIXQ_E_SHAPE;
+    for (size_t k = 0; k < rows; ++k)
+        for (size_t n = 0; n < cols; ++n)
+            preprocessed[eetq_offset(k, n, rows)] = (uint8_t)((int)row_major[k * cols + n] + 128);
+    return MIXQ_OK;
+}
+
+int mixq_unprocess_weights_int8(int8_t* row_major, const uint8_t* preprocessed, size_t rows, size_t cols)
+{
+    if (!preprocessed || !row_major) return MIXQ_E_BADARG;
+    if (rows % 64 || cols % 2) return MIXQ_E_SHAPE;
+    for (size_t k = 0; k < rows; ++k)
+        for (size_t n = 0; n < cols; ++n)
+            row_major[k * cols + n] = (int8_t)((int)preprocessed[eetq_offset(k, n, rows)] - 128);
+    return MIXQ_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,34 @@
+// Host-visible launch interface between mixq_api.hip (C ABI, orchestration) and the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mixq {
+
+enum { EPI_DEQUANT = 0, EPI_DEQUANT_SILU = 1, EPI_INT32 = 2 };
+
+struct GemmParams {
+    const int8_t* A;      // qA [M,K]
+    const int8_t* B;      // W  [N,K]
+    const uint16_t* sA;   // [M]
+    const uint16_t* sW;   // [N]
+    const uint16_t* fpA;  // [M,O] or null
+    const uint16_t* fpW;  // [N,O] or null
+    const uint16_t* Y;    // fp16 [M,N] addend or null (int8FusedDequantize API)
+    void* D;              // fp16 [M,N] (EPI_DEQUANT*) or int32 [M,N] (EPI_INT32)
+    const void* zeros;    // >= 16 B of device zeros (K / O tails)
+    int M, N, K, O;
+};
+
+hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st);
+hipError_t launch_gemm_fp16(const void* fpA, const void* fpW, void* Out, int M, int N, int O, hipStream_t st);
+hipError_t launch_dequantization(void* out, const int32_t* x, const void* sRow, const void* sCol, int M, int N,
+                                 hipStream_t st);
+hipError_t launch_quant_extract(void* A, int8_t* qA, void* sA, void* fpA, const int32_t* ind, int M, int K, int O,
+                                bool zero, hipStream_t st);
+hipError_t launch_quant_with_scale(const void* src, const void* scale, int8_t* dst, int M, int K, hipStream_t st);
+hipError_t launch_extract(void* A, void* fpA, const int32_t* ind, int M, int K, int O, bool zero, hipStream_t st);
+hipError_t launch_w8a16(const void* A, const uint8_t* Wq, const void* scale, void* Out, int M, int N, int K,
+                        hipStream_t st);
+
+} // namespace mixq

@@ -1,0 +1,166 @@
+"""``mixlib`` operator surface (reference: quantkernel/mix_cuda/pybind_mix.cpp:256-335) on MI355X.
+
+Same op names, argument order and return conventions as the reference's PyTorch extension, for the ops on the
+``int8_mix`` path.  Each function is a thin launch of libmixq_mi355x.so on the current HIP stream;
+tensors are only carriers of device pointers.  No op has a CPU implementation.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+__all__ = ["FindRowScale", "ExtractOutliersAndSetToZeros", "int8FusedDequantize", "int8FusedDequantizeSilu", "gemm",
+           "dequantizeInt8", "Int8quantize", "FindRowScaleFusedExtracOutliers", "int_to_half", "int_matrix_to_half",
+           "int8_matrix_to_half", "w8_a16_gemm", "preprocess_weights", "mixq_linear"]
+
+
+def _st(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _dev(*ts):
+    for t in ts:
+        if not t.is_cuda:
+            raise _lib.MixQLibraryError("mixlib ops run on the GPU only (no CPU path exists)")
+        assert t.is_contiguous(), "mixlib ops need contiguous tensors"
+
+
+def FindRowScale(x, scaleRow, rows, cols, bit=8):
+    """cult.cu:2569-2608.  Writes the per-row fp16 scale into ``scaleRow`` and returns the int8 rows."""
+    assert bit == 8, "only the 8-bit path is on the int8_mix hot path (int4 is SURVEY §8f 'next')"
+    _dev(x, scaleRow)
+    out = torch.empty((rows, cols), dtype=torch.int8, device=x.device)
+    _lib.check(_lib.load().mixq_int8quant(rows, cols, _p(x), _p(out), _p(scaleRow), _st(x)), "FindRowScale")
+    return out
+
+
+def ExtractOutliersAndSetToZeros(ind, input):
+    """cult.cu:1433-1465.  Returns input[:, ind] (fp16 [M, len]) and ZEROES those columns of ``input`` in place."""
+    _dev(ind, input)
+    assert ind.dtype == torch.int32 and input.dtype == torch.float16
+    m, k = input.shape
+    n = ind.shape[0]
+    out = torch.zeros((m, n), dtype=torch.float16, device=input.device)
+    _lib.check(_lib.load().mixq_extract_outliers_set_zero(m, k, _p(input), _p(out), _p(ind), n, _st(input)),
+               "ExtractOutliersAndSetToZeros")
+    return out
+
+
+def _fused(name, A, B, scale_row, scale_col, y, M, N, K):
+    _dev(A, B, scale_row, scale_col, y)
+    D = torch.empty((M, N), dtype=torch.float16, device=A.device)
+    fn = getattr(_lib.load(), name)
+    _lib.check(fn(_p(A), _p(B), _p(scale_row), _p(scale_col), _p(y), _p(D), M, N, K, None, _st(A)), name)
+    return D
+
+
+def int8FusedDequantize(A, B, scale_row, scale_col, y, M, N, K):
+    """cult.cu:1937-2000: D = fp16(float(A.B^T) * (scale_col[n]*scale_row[m]) + y), new tensor D."""
+    return _fused("mixq_int8_fused_dequantize", A, B, scale_row, scale_col, y, M, N, K)
+
+
+def int8FusedDequantizeSilu(A, B, scale_row, scale_col, y, M, N, K):
+    """cult.cu:2067-2117: same with SiLU applied before the fp16 rounding."""
+    return _fused("mixq_int8_fused_dequantize_silu", A, B, scale_row, scale_col, y, M, N, K)
+
+
+def gemm(mat1, mat2, m, n, k):
+    """cult.cu:180-220 (cuBLAS s8 x s8 -> s32): int32 [m,n] = mat1[m,k] . mat2[n,k]^T."""
+    _dev(mat1, mat2)
+    out = torch.empty((m, n), dtype=torch.int32, device=mat1.device)
+    _lib.check(_lib.load().mixq_gemm_s8s8s32(_p(mat1), _p(mat2), _p(out), m, n, k, _st(mat1)), "gemm")
+    return out
+
+
+def dequantizeInt8(x, scaleRow, scaleCol, y, bits, M, N):
+    """cult.cu:2258-2288: out = hadd(fp16((float(x)*scaleRow[m])*scaleCol[n]), y), new tensor."""
+    _dev(x, scaleRow, scaleCol, y)
+    out = y.clone()
+    _lib.check(_lib.load().mixq_dequantization(_p(out), _p(x), _p(scaleRow), _p(scaleCol), M, N, _st(x)),
+               "dequantizeInt8")
+    return out
+
+
+def Int8quantize(src, scale):
+    """cult.cu:1732-1771: dst = (int8) half2int_rn(hdiv(src, scale[row])) with a caller-supplied per-row scale."""
+    _dev(src, scale)
+    rows, cols = src.shape
+    dst = torch.empty((rows, cols), dtype=torch.int8, device=src.device)
+    _lib.check(_lib.load().mixq_int8_quantize_with_scale(rows, cols, _p(src), _p(scale), _p(dst), _st(src)),
+               "Int8quantize")
+    return dst
+
+
+def FindRowScaleFusedExtracOutliers(x, scaleRow, ind, len_ind, rows, cols):
+    """cult.cu:2671-2709: returns [int8 rows, outliers fp16 [rows,len_ind]]; zeroes the outlier columns of x."""
+    _dev(x, scaleRow)
+    q = torch.empty((rows, cols), dtype=torch.int8, device=x.device)
+    outl = torch.zeros((rows, len_ind), dtype=torch.float16, device=x.device)
+    _lib.check(_lib.load().mixq_quant_extract(rows, cols, _p(x), _p(q), _p(scaleRow), _p(outl),
+                                              _p(ind) if len_ind else None, len_ind, 1, _st(x)),
+               "FindRowScaleFusedExtracOutliers")
+    return [q, outl]
+
+
+def int_to_half(int_ind):
+    """cult.cu:3046-3056: bit reinterpretation int32 [n] -> fp16 [2n]."""
+    return int_ind.contiguous().view(torch.float16).clone()
+
+
+def int_matrix_to_half(int_ind):
+    """cult.cu:3058-3070: int32 [m,n] -> fp16 [m,2n], same bytes."""
+    return int_ind.contiguous().view(torch.float16).clone()
+
+
+def int8_matrix_to_half(int_ind):
+    """cult.cu:3072-3085: int8 [m,n] -> fp16 [m,n/2], same bytes."""
+    return int_ind.contiguous().view(torch.float16).clone()
+
+
+def w8_a16_gemm(input, weight, scale):
+    """EETQ/csrc/eetpy.cpp:7-19 w8_a16_gemm: fp16 [m,k] x interleaved uint8 [k,n] -> fp16 [m,n]."""
+    _dev(input, weight, scale)
+    m, k = input.shape
+    n = scale.numel()
+    out = torch.empty((m, n), dtype=torch.float16, device=input.device)
+    _lib.check(_lib.load().mixq_w8a16_gemm_forward(_p(input), _p(weight), _p(scale), _p(out), m, n, k, _st(input)),
+               "w8_a16_gemm")
+    return out
+
+
+def preprocess_weights(row_major_int8):
+    """EETQ preprocess_weights (cutlass_preprocessors.cc:536-545), int8: host tensor [K,N] -> interleaved uint8."""
+    w = row_major_int8.contiguous().cpu()
+    assert w.dtype == torch.int8
+    out = torch.empty_like(w, dtype=torch.uint8)
+    _lib.check(_lib.load().mixq_preprocess_weights_int8(ctypes.c_void_p(out.data_ptr()),
+                                                        ctypes.c_void_p(w.data_ptr()), w.shape[0], w.shape[1]),
+               "preprocess_weights")
+    return out
+
+
+def mixq_linear(A, W_int8, sW, fp_weight, ind, out=None, workspace=None):
+    """The fused two-launch prefill path used inside enqueue, on plain tensors:
+    A fp16 [M,K], W int8 [N,K], sW fp16 [N], fp_weight fp16 [N,O], ind int32 [O] -> fp16 [M,N]."""
+    _dev(A, W_int8, sW, fp_weight, ind)
+    M, K = A.shape
+    N, O = fp_weight.shape
+    lib = _lib.load()
+    dev = A.device
+    if workspace is None:
+        qA = torch.empty((M, K), dtype=torch.int8, device=dev)
+        sA = torch.empty((M,), dtype=torch.float16, device=dev)
+        fpA = torch.empty((M, O), dtype=torch.float16, device=dev)
+    else:
+        qA, sA, fpA = workspace
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float16, device=dev)
+    _lib.check(lib.mixq_quant_extract(M, K, _p(A), _p(qA), _p(sA), _p(fpA), _p(ind), O, 0, _st(A)), "quant_extract")
+    _lib.check(lib.mixq_gemm_mixed(_p(qA), _p(W_int8), _p(sA), _p(sW), _p(fpA), _p(fp_weight), _p(out), M, N, K, O,
+                                   _st(A)), "gemm_mixed")
+    return out

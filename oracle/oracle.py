@@ -1,0 +1,230 @@
+"""numpy front-end of oracle/mixq_oracle.c (ctypes).  TEST INFRASTRUCTURE ONLY -- see __init__.py.
+
+All fp16 tensors are numpy ``float16`` arrays (bit patterns are handed to C as uint16).  Function
+names follow the reference functions they restate; the C source cites file:line for each.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libmixq_oracle.so")
+
+__all__ = [
+    "build", "lib", "num_threads", "quant_rows", "extract_outliers", "gemm_s8s8s32", "gemm_fp16",
+    "dequant_epilogue", "dequantization", "linear_prefill", "weight_scales", "quantize_weight",
+    "select_outliers", "pack_linear_weights", "eetq_symmetric_quantize", "eetq_preprocess", "w8a16_gemv",
+    "int_to_half", "int8_matrix_to_half",
+]
+
+
+def build(force=False):
+    """Compile libmixq_oracle.so with gcc (oracle/Makefile).  Building the checker is not using it."""
+    src = os.path.join(_HERE, "mixq_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+        _lib.mixq_oracle_num_threads.restype = ctypes.c_int
+    return _lib
+
+
+def num_threads():
+    return int(lib().mixq_oracle_num_threads())
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _h(a):
+    a = np.ascontiguousarray(a)
+    assert a.dtype == np.float16, a.dtype
+    return a
+
+
+def _i64(v):
+    return ctypes.c_int64(int(v))
+
+
+def quant_rows(A, zero_cols=None):
+    """kernel/i8gemm.cu:66-107 -> (qA int8 [M,K], sA fp16 [M])."""
+    A = _h(A)
+    M, K = A.shape
+    qA = np.empty((M, K), np.int8)
+    sA = np.empty((M,), np.float16)
+    zc = None if zero_cols is None else np.ascontiguousarray(zero_cols, np.int32)
+    lib().mixq_oracle_quant_rows(_i64(M), _i64(K), _p(A), _p(qA), _p(sA), _p(zc),
+                                 ctypes.c_int(0 if zc is None else zc.size))
+    return qA, sA
+
+
+def extract_outliers(A, ind, set_zero=False):
+    """kernel/i8gemm.cu:198-244 (set_zero=False) / cult.cu:1406-1432 (set_zero=True, mutates A)."""
+    assert A.dtype == np.float16 and A.flags.c_contiguous
+    ind = np.ascontiguousarray(ind, np.int32)
+    M, K = A.shape
+    fpA = np.empty((M, ind.size), np.float16)
+    lib().mixq_oracle_extract_outliers(_i64(M), _i64(K), _p(A), _p(fpA), _p(ind), ctypes.c_int(ind.size),
+                                       ctypes.c_int(1 if set_zero else 0))
+    return fpA
+
+
+def gemm_s8s8s32(qA, W):
+    qA = np.ascontiguousarray(qA, np.int8)
+    W = np.ascontiguousarray(W, np.int8)
+    M, K = qA.shape
+    N = W.shape[0]
+    assert W.shape[1] == K
+    acc = np.empty((M, N), np.int32)
+    lib().mixq_oracle_gemm_s8s8s32(_i64(M), _i64(N), _i64(K), _p(qA), _p(W), _p(acc))
+    return acc
+
+
+def gemm_fp16(fpA, fpW):
+    fpA, fpW = _h(fpA), _h(fpW)
+    M, O = fpA.shape
+    N = fpW.shape[0]
+    P = np.empty((M, N), np.float16)
+    lib().mixq_oracle_gemm_fp16(_i64(M), _i64(N), ctypes.c_int(O), _p(fpA), _p(fpW), _p(P))
+    return P
+
+
+def dequant_epilogue(acc, sA, sW, C=None, silu=False):
+    acc = np.ascontiguousarray(acc, np.int32)
+    M, N = acc.shape
+    sA, sW = _h(sA).reshape(-1), _h(sW).reshape(-1)
+    assert sA.size == M and sW.size == N
+    C = None if C is None else _h(C)
+    D = np.empty((M, N), np.float16)
+    lib().mixq_oracle_dequant_epilogue(_i64(M), _i64(N), _p(acc), _p(sA), _p(sW), _p(C), _p(D),
+                                       ctypes.c_int(1 if silu else 0))
+    return D
+
+
+def dequantization(x, sA, sW, out):
+    """kernel/i8gemm.cu:258-279; returns a new array (out is the addend)."""
+    x = np.ascontiguousarray(x, np.int32)
+    M, N = x.shape
+    res = _h(out).copy()
+    lib().mixq_oracle_dequantization(_i64(M), _i64(N), _p(x), _p(_h(sA).reshape(-1)), _p(_h(sW).reshape(-1)), _p(res))
+    return res
+
+
+def linear_prefill(A, W, sW, fpW, ind, return_parts=False):
+    """TsinghuaMixQPlugin.cpp:518-532.  A fp16 [M,K], W int8 [N,K], sW fp16 [N], fpW fp16 [N,O], ind int32 [O]."""
+    A, sW, fpW = _h(A), _h(sW).reshape(-1), _h(fpW)
+    W = np.ascontiguousarray(W, np.int8)
+    ind = np.ascontiguousarray(ind, np.int32)
+    M, K = A.shape
+    N, O = fpW.shape
+    assert W.shape == (N, K) and sW.size == N and ind.size == O
+    Out = np.empty((M, N), np.float16)
+    qA = np.empty((M, K), np.int8)
+    sA = np.empty((M,), np.float16)
+    acc = np.empty((M, N), np.int32)
+    P = np.empty((M, N), np.float16)
+    lib().mixq_oracle_linear_prefill(_i64(M), _i64(N), _i64(K), ctypes.c_int(O), _p(A), _p(W), _p(sW), _p(fpW),
+                                     _p(ind), _p(Out), _p(qA), _p(sA), _p(acc), _p(P))
+    if return_parts:
+        return Out, dict(qA=qA, sA=sA, acc=acc, P=P)
+    return Out
+
+
+def weight_scales(W):
+    W = _h(W)
+    N, K = W.shape
+    sW = np.empty((N,), np.float16)
+    lib().mixq_oracle_weight_scales(_i64(N), _i64(K), _p(W), _p(sW))
+    return sW
+
+
+def quantize_weight(W, sW, zero_cols=()):
+    W, sW = _h(W), _h(sW).reshape(-1)
+    N, K = W.shape
+    zc = np.ascontiguousarray(zero_cols, np.int32)
+    Wq = np.empty((N, K), np.int8)
+    lib().mixq_oracle_quantize_weight(_i64(N), _i64(K), _p(W), _p(sW), _p(zc), ctypes.c_int(zc.size), _p(Wq))
+    return Wq
+
+
+def select_outliers(act_scale, num=128):
+    s = np.ascontiguousarray(act_scale, np.float32)
+    ind = np.empty((num,), np.int32)
+    lib().mixq_oracle_select_outliers(_i64(s.size), _p(s), ctypes.c_int(num), _p(ind))
+    return ind
+
+
+def int_to_half(ind_i32):
+    """mixlib.int_to_half (quantkernel/mix_cuda/cult.cu:3046-3085): bit reinterpretation int32[n] -> fp16[2n]."""
+    return np.ascontiguousarray(ind_i32, np.int32).view(np.float16)
+
+
+def int8_matrix_to_half(w_i8):
+    """mixlib.int8_matrix_to_half: int8 [R,C] -> fp16 [R,C/2], same bytes."""
+    w = np.ascontiguousarray(w_i8)
+    assert w.dtype in (np.int8, np.uint8)
+    return w.view(np.float16)
+
+
+def eetq_symmetric_quantize(Wt):
+    """cutlass_preprocessors.cc:573-660 on Wt fp16 [K,N] -> (unprocessed int8 [K,N], scales fp16 [N])."""
+    Wt = _h(Wt)
+    K, N = Wt.shape
+    q = np.empty((K, N), np.int8)
+    sc = np.empty((N,), np.float16)
+    lib().mixq_oracle_eetq_symmetric_quantize(_i64(K), _i64(N), _p(Wt), _p(q), _p(sc))
+    return q, sc
+
+
+def eetq_preprocess(q_rm):
+    """cutlass_preprocessors.cc:497-534 on row-major int8 [K,N] -> uint8 [K,N] (interleaved layout)."""
+    q = np.ascontiguousarray(q_rm, np.int8)
+    K, N = q.shape
+    assert K % 64 == 0 and N % 2 == 0
+    out = np.empty((K, N), np.uint8)
+    lib().mixq_oracle_eetq_preprocess(_i64(K), _i64(N), _p(q), _p(out))
+    return out
+
+
+def w8a16_gemv(A, Wq_rm, scale):
+    A, scale = _h(A), _h(scale).reshape(-1)
+    Wq = np.ascontiguousarray(Wq_rm, np.int8)
+    M, K = A.shape
+    N = Wq.shape[1]
+    Out = np.empty((M, N), np.float16)
+    lib().mixq_oracle_w8a16_gemv(_i64(M), _i64(N), _i64(K), _p(A), _p(Wq), _p(scale), _p(Out))
+    return Out
+
+
+def pack_linear_weights(W, act_scale, num_outliers=128):
+    """modelopt/torch/export/model_config_utils.py:429-466 for ONE linear layer.
+
+    W fp16 [N,K] (original weight), act_scale fp32 [K'] (K' may be < K: SURVEY A.3 #4).
+    Returns the 7-tensor contract of SURVEY A.1 as a dict (true dtypes + the fp16 carrier views).
+    """
+    W = _h(W)
+    sW = weight_scales(W)                                    # :429-430 (before zeroing)
+    q_un, eetq_scales = eetq_symmetric_quantize(W.T.copy())  # :437-438 (un-zeroed W^T)
+    qweight = eetq_preprocess(q_un)
+    ind = select_outliers(act_scale, num_outliers)           # :446-448
+    fp_weight = np.ascontiguousarray(W[:, ind])              # :452
+    Wq = quantize_weight(W, sW, ind)                         # :453, :460-466
+    return dict(
+        weight=Wq, weights_scaling_factor=sW, fp_weight=fp_weight, fp_ind=ind, qweight=qweight,
+        scales=eetq_scales,
+        weight_as_half=int8_matrix_to_half(Wq), fp_ind_as_half=int_to_half(ind),
+        qweight_as_half=int8_matrix_to_half(qweight),
+    )

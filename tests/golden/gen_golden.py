@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures from the importable pieces of the reference.
+
+Runs ONLY in the build container (needs /root/reference); the GPU box and the test-suite read the
+committed ``*.npz`` files and never this script's inputs.  Usage:  python tests/golden/gen_golden.py
+
+What is captured (inputs + expected outputs, data only):
+  pack_small.npz   W fp16 [96,512] (seeded), act-scale vector -> outputs of the REFERENCE functions
+                   * ``to_quantized_weight`` (modelopt/torch/export/model_config_utils.py:298-308), executed
+                     from the reference file itself (module loaded by path; its parent package __init__
+                     needs the nvidia-modelopt dist-info, so the two modules are loaded standalone);
+                   * the two expression lines of ``pack_linear_weights`` that need no CUDA/mixlib/EETQ
+                     (:429-430 weights_scaling_factor, :446-448 fp_ind, :452-453 fp_weight + zeroing),
+                     evaluated verbatim with torch on CPU.
+  act_scales_llama.npz  three real activation-scale vectors from act_scales/Llama-2-1b.pt (layer-0 q_proj,
+                   layer-0 up_proj, layer-1 down_proj [K=11008, max 1718]) and the reference selection
+                   ``torch.sort(scales)[1][-128:]`` for each.
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def load_reference_model_config_utils():
+    pkg = "modelopt.torch.export"
+    for name in ("modelopt", "modelopt.torch", pkg):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__path__ = []  # namespace-like parent so the relative import below resolves
+            sys.modules[name] = m
+    mods = {}
+    for leaf in ("model_config", "model_config_utils"):
+        path = f"{REF}/modelopt/torch/export/{leaf}.py"
+        spec = importlib.util.spec_from_file_location(f"{pkg}.{leaf}", path)
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[f"{pkg}.{leaf}"] = mod
+        spec.loader.exec_module(mod)
+        mods[leaf] = mod
+    return mods["model_config_utils"], mods["model_config"]
+
+
+def main():
+    mcu, mc = load_reference_model_config_utils()
+    act = torch.load(f"{REF}/act_scales/Llama-2-1b.pt")
+
+    # ---- act-scale vectors + reference outlier selection -------------------------------------
+    keys = ["model.layers.0.self_attn.q_proj", "model.layers.0.mlp.up_proj", "model.layers.1.mlp.down_proj"]
+    blob = {}
+    for i, k in enumerate(keys):
+        v = act[k].float().contiguous()
+        blob[f"scales_{i}"] = v.numpy()
+        blob[f"fp_ind_{i}"] = torch.sort(v)[1][-128:].to(torch.int32).numpy()  # model_config_utils.py:448
+    blob["keys"] = np.array(keys)
+    np.savez_compressed(os.path.join(OUT, "act_scales_llama.npz"), **blob)
+
+    # ---- one small linear layer through the reference packing math ----------------------------
+    g = torch.Generator().manual_seed(1234)
+    N, K = 96, 512
+    W = (torch.randn(N, K, generator=g) * 0.02).to(torch.float16)
+    W[3, 7] = 0.5     # a dominant element: exercises the +-127 end of the grid
+    W[5, :] = 0       # an all-zero row: scale 0 -> 0/0 -> NaN -> reference clamp/int8 behaviour
+    layer_scales = act[keys[0]][:K].float().contiguous()
+    weight = W.clone()
+    # model_config_utils.py:429-430
+    wsf = (torch.max(torch.abs(weight), dim=1)[0].unsqueeze(1) / (127)).to(torch.float16).reshape((weight.shape[0],))
+    fp_ind = torch.sort(layer_scales)[1][-128:]                       # :446-448
+    fp_weight = weight[:, fp_ind].clone()                             # :452
+    weight[:, fp_ind] *= 0                                            # :453
+    q = mcu.to_quantized_weight(weight, wsf, mc.QUANTIZATION_INT8_MIX)  # :460-464 -> reference function
+    np.savez_compressed(
+        os.path.join(OUT, "pack_small.npz"),
+        W=W.numpy(), layer_scales=layer_scales.numpy(),
+        weights_scaling_factor=wsf.numpy(), fp_ind=fp_ind.to(torch.int32).numpy(),
+        fp_weight=fp_weight.numpy(), weight_int8=q.numpy(),
+    )
+    print("wrote", os.listdir(OUT))
+
+
+if __name__ == "__main__":
+    main()

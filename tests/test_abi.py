@@ -1,0 +1,134 @@
+"""CPU: the C-ABI library loads, exports every symbol include/mixq.h declares, and its host-only entry points
+(registry, plugin lifecycle, shape negotiation, workspace sizing, qweight layout importer) behave like the reference's
+host code.  No compute launches here (no GPU in the build container)."""
+import ctypes
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+from mixq_tensorrt_llm_amd import _lib
+from mixq_tensorrt_llm_amd._lib import PluginField, TensorDesc
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return _lib.load()
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "mixq.h")).read()
+    return sorted(set(re.findall(r"MIXQ_API\s+[\w\s\*]+?\b(\w+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_typed(lib):
+    syms = header_symbols()
+    assert len(syms) >= 35
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/mixq.h but not exported"
+    assert sorted(_lib.SIGNATURES) == syms, "ctypes SIGNATURES out of sync with include/mixq.h"
+
+
+def test_registry_matches_reference_loader(lib):
+    # plugin.py:34-43: initOpenAiTritonPlugins(None, b"tensorrt_llm") must return true, idempotently
+    assert lib.mixq_registry_has_creator(b"MixQ", b"1", b"never_registered_ns") == 0
+    assert lib.initOpenAiTritonPlugins(None, b"tensorrt_llm") is True
+    assert lib.initOpenAiTritonPlugins(None, b"tensorrt_llm") is True
+    assert lib.mixq_registry_has_creator(b"MixQ", b"1", b"tensorrt_llm") == 1
+    assert lib.mixq_registry_has_creator(b"MixQ", b"2", b"tensorrt_llm") == 0
+    assert lib.mixq_plugin_type() == b"MixQ" and lib.mixq_plugin_version() == b"1"
+
+
+def test_lifecycle_serialize_clone(lib):
+    vals = [np.array([v], np.int32) for v in (8192, 12288, 4096)]
+    fields = (PluginField * 4)()
+    for f, name, v in zip(fields, (b"m", b"n", b"k"), vals):
+        f.name, f.data, f.type, f.length = name, v.ctypes.data, _lib.MIXQ_FIELD_INT32, 1
+    junk = np.array([7], np.int32)
+    fields[3].name, fields[3].data, fields[3].type, fields[3].length = b"mm", junk.ctypes.data, 3, 1  # ignored
+    h = lib.mixq_create_from_fields(fields, 4)
+    assert h
+    assert lib.mixq_serialization_size(h) == 12           # TsinghuaMixQPlugin.cpp:808-811
+    buf = ctypes.create_string_buffer(12)
+    lib.mixq_serialize(h, buf)
+    assert struct.unpack("<iii", buf.raw) == (8192, 12288, 4096)
+    h2 = lib.mixq_deserialize(buf, 12)
+    h3 = lib.mixq_clone(h2)
+    m, n, k = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    assert lib.mixq_get_mnk(h3, ctypes.byref(m), ctypes.byref(n), ctypes.byref(k)) == 0
+    assert (m.value, n.value, k.value) == (8192, 12288, 4096)
+    assert lib.mixq_deserialize(buf, 11) is None           # short blob
+    assert lib.mixq_set_namespace(h, b"tensorrt_llm") == 0 and lib.mixq_get_namespace(h) == b"tensorrt_llm"
+    assert lib.mixq_initialize(h) == 0
+    lib.mixq_terminate(h)
+    for x in (h, h2, h3):
+        lib.mixq_destroy(x)
+    lib.mixq_destroy(None)
+
+
+def test_shape_negotiation(lib):
+    h = lib.mixq_create(1, 2, 3)
+    descs = (TensorDesc * 8)(
+        TensorDesc.make((4, 2048, 4096)), TensorDesc.make((12288, 2048)), TensorDesc.make((12288,)),
+        TensorDesc.make((12288, 128)), TensorDesc.make((256,)), TensorDesc.make((4096, 6144)),
+        TensorDesc.make((12288,)), TensorDesc.make((4, 2048, 12288)))
+    out = TensorDesc()
+    assert lib.mixq_get_output_dimensions(h, 0, descs, 7, ctypes.byref(out)) == 0
+    assert [out.d[i] for i in range(out.nbDims)] == [4, 2048, 12288]     # .cpp:244-261
+    assert lib.mixq_get_output_dimensions(h, 1, descs, 7, ctypes.byref(out)) != 0
+    for pos in range(8):
+        assert lib.mixq_supports_format_combination(h, pos, descs, 7, 1) == 1
+    descs[3].type = 0  # float
+    assert lib.mixq_supports_format_combination(h, 3, descs, 7, 1) == 0
+    assert lib.mixq_get_nb_outputs(h) == 1 and lib.mixq_get_output_data_type(h, 0) == _lib.MIXQ_TYPE_HALF
+    lib.mixq_destroy(h)
+
+
+def test_workspace_sizes_are_size_t_clean(lib):
+    h = lib.mixq_create(0, 0, 0)
+    M, N, K = 8192, 12288, 4096
+    ws = lib.mixq_workspace_size(h, M, N, K)
+    need = M * K + 2 * M + 2 * 128 * M
+    assert need <= ws <= need + 4 * 128 + 128
+    # 1M tokens x 11008: the reference's int arithmetic overflows here
+    big = lib.mixq_workspace_size(h, 1 << 20, 4096, 11008)
+    assert big > (1 << 20) * 11008 > 2**31
+    assert lib.mixq_reference_workspace_size(M, N, K) == max(M * K + 2 * M + 2 * K * N, 16 * M * N)
+    assert lib.mixq_reference_workspace_size(0, 0, 0) == 33554432
+    lib.mixq_destroy(h)
+
+
+def test_enqueue_rejects_bad_arguments_without_touching_the_gpu(lib):
+    h = lib.mixq_create(0, 0, 0)
+    d = (TensorDesc * 7)(*[TensorDesc.make((8, 64))] * 7)
+    assert lib.mixq_enqueue(h, d, None, None, None, None, None) == 1
+    d[0].nbDims = 0
+    ins = (ctypes.c_void_p * 7)()
+    outs = (ctypes.c_void_p * 1)()
+    assert lib.mixq_enqueue(h, d, None, ins, outs, None, None) == 1
+    assert lib.mixq_error_string(2) == b"unsupported shape"
+    assert lib.mixq_gemm_s8s8s32(None, None, None, 0, 0, 16, None) == 0      # empty problem is a no-op
+    assert lib.mixq_gemm_s8s8s32(None, None, None, 8, 16, 16, None) == 1     # null pointers
+    assert lib.mixq_int8quant(4, 12, ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16), None) == 2
+    lib.mixq_destroy(h)
+
+
+def test_qweight_layout_importer_matches_oracle(lib, oracle):
+    rng = np.random.default_rng(0)
+    K, N = 192, 96
+    q = rng.integers(-128, 128, size=(K, N), dtype=np.int8)
+    want = oracle.eetq_preprocess(q)
+    got = np.empty((K, N), np.uint8)
+    assert lib.mixq_preprocess_weights_int8(got.ctypes.data, q.ctypes.data, K, N) == 0
+    assert np.array_equal(got, want)
+    back = np.empty((K, N), np.int8)
+    assert lib.mixq_unprocess_weights_int8(back.ctypes.data, got.ctypes.data, K, N) == 0
+    assert np.array_equal(back, q)
+    assert lib.mixq_preprocess_weights_int8(got.ctypes.data, q.ctypes.data, 100, N) == 2

@@ -1,0 +1,312 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the same seeded inputs.
+
+Bar (BASELINE.json north_star): int8 quantisation, per-token scales, outlier gather and int32 accumulators are
+BIT-EXACT; the dequant epilogue is bit-exact once its addend is given; the complete operator (whose fp16 side GEMM has
+an unspecified accumulation order in the reference too -- cuBLAS) is within 1e-3 relative.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import make_layer
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def dev():
+    assert torch.cuda.is_available(), "-m gpu tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def to_dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint16)
+
+
+REL_TOL = 1e-3  # north_star: fp16 output within 1e-3 relative (normalised by the output's max magnitude)
+
+
+def rel_err(got, want):
+    g, w = got.astype(np.float64), want.astype(np.float64)
+    return np.abs(g - w).max() / max(np.abs(w).max(), 1e-30)
+
+
+# ------------------------------------------------------------------------------- quant + extract -------
+@pytest.mark.parametrize("M,K", [(1, 256), (5, 512), (37, 1024), (64, 3584), (33, 4096), (17, 8192), (9, 11008),
+                                 (6, 18944), (5, 28672), (3, 40960)])
+def test_quant_rows_bit_exact(oracle, M, K):
+    from mixq_tensorrt_llm_amd import mixlib
+    rng = np.random.default_rng(K + M)
+    A = (rng.standard_normal((M, K)) * rng.uniform(0.01, 30)).astype(np.float16)
+    if M > 2:
+        A[1] = 0                       # zero row -> scale 0, q 0
+        A[2, K // 3] = np.float16(6.5e4)
+    if M > 4:
+        A[3, 5] = np.nan
+        A[4, :] = np.float16(6e-8)     # subnormal amax -> scale 0 -> +-inf quotient
+    x = to_dev(A)
+    s = torch.empty(M, dtype=torch.float16, device=dev())
+    q = mixlib.FindRowScale(x, s, M, K, 8)
+    qo, so = oracle.quant_rows(A)
+    assert np.array_equal(bits(s.cpu().numpy()), bits(so))
+    assert np.array_equal(q.cpu().numpy(), qo)
+    assert np.array_equal(bits(x.cpu().numpy()), bits(A)), "T-flavour quantiser must not modify A"
+    # Int8quantize with the same scales reproduces the rows (cult.cu:1732-1771)
+    q2 = mixlib.Int8quantize(x, s)
+    assert np.array_equal(q2.cpu().numpy(), qo)
+
+
+@pytest.mark.parametrize("M,K,O", [(7, 512, 128), (40, 4096, 128), (12, 11008, 128), (5, 28672, 128), (9, 1024, 8)])
+def test_fused_quant_extract_both_flavours(oracle, M, K, O):
+    from mixq_tensorrt_llm_amd import _lib, mixlib
+    rng = np.random.default_rng(M * K)
+    A = rng.standard_normal((M, K)).astype(np.float16)
+    ind = rng.permutation(K)[:O].astype(np.int32)
+    A[:, ind[: O // 2]] *= np.float16(20)
+    lib = _lib.load()
+    # T-flavour (enqueue): gather + quant, A untouched, amax includes the outliers
+    x = to_dev(A)
+    q = torch.empty((M, K), dtype=torch.int8, device=dev())
+    s = torch.empty(M, dtype=torch.float16, device=dev())
+    f = torch.empty((M, O), dtype=torch.float16, device=dev())
+    i_d = to_dev(ind)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.mixq_quant_extract(M, K, x.data_ptr(), q.data_ptr(), s.data_ptr(), f.data_ptr(), i_d.data_ptr(), O, 0,
+                                  st) == 0
+    qo, so = oracle.quant_rows(A)
+    assert np.array_equal(q.cpu().numpy(), qo) and np.array_equal(bits(s.cpu().numpy()), bits(so))
+    assert np.array_equal(bits(f.cpu().numpy()), bits(A[:, ind]))
+    assert np.array_equal(bits(x.cpu().numpy()), bits(A))
+    # stand-alone gather API (kernel/i8gemm.cu:226-244)
+    f2 = torch.empty_like(f)
+    assert lib.mixq_extract_outliers(M, K, x.data_ptr(), f2.data_ptr(), i_d.data_ptr(), O, st) == 0
+    assert torch.equal(f, f2)
+    # P-flavour (mixlib): outliers zeroed before amax/quant, A mutated
+    x2 = to_dev(A)
+    s2 = torch.empty(M, dtype=torch.float16, device=dev())
+    q2, out2 = mixlib.FindRowScaleFusedExtracOutliers(x2, s2, i_d, O, M, K)
+    Az = A.copy()
+    fo = oracle.extract_outliers(Az, ind, set_zero=True)
+    qz, sz = oracle.quant_rows(Az)
+    assert np.array_equal(bits(out2.cpu().numpy()), bits(fo))
+    assert np.array_equal(q2.cpu().numpy(), qz) and np.array_equal(bits(s2.cpu().numpy()), bits(sz))
+    assert np.array_equal(bits(x2.cpu().numpy()), bits(Az))
+    # unfused mixlib pair gives the same thing
+    x3 = to_dev(A)
+    out3 = mixlib.ExtractOutliersAndSetToZeros(i_d, x3)
+    s3 = torch.empty(M, dtype=torch.float16, device=dev())
+    q3 = mixlib.FindRowScale(x3, s3, M, K, 8)
+    assert torch.equal(out3, out2) and torch.equal(q3, q2) and torch.equal(s3, s2)
+
+
+# ----------------------------------------------------------------------------------- int8 GEMM ---------
+GEMM_SHAPES = [(5, 16, 16), (32, 128, 128), (33, 144, 272), (64, 256, 512), (100, 400, 1040), (129, 256, 384),
+               (256, 512, 1024), (300, 768, 640), (513, 1280, 896), (32, 4096, 4096)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_int32_accumulators_bit_exact(oracle, M, N, K):
+    from mixq_tensorrt_llm_amd import mixlib
+    rng = np.random.default_rng(M + N + K)
+    a = rng.integers(-128, 128, size=(M, K), dtype=np.int8)
+    b = rng.integers(-128, 128, size=(N, K), dtype=np.int8)
+    # asymmetric operands: a transposed or permuted output cannot pass
+    got = mixlib.gemm(to_dev(a), to_dev(b), M, N, K).cpu().numpy()
+    want = oracle.gemm_s8s8s32(a, b) if M * N * K < 3e8 else (a.astype(np.int32) @ b.astype(np.int32).T)
+    assert np.array_equal(got, want)
+
+
+def test_int32_extremes_do_not_saturate(oracle):
+    from mixq_tensorrt_llm_amd import mixlib
+    M, N, K = 32, 128, 28672
+    a = np.full((M, K), -128, np.int8)
+    b = np.full((N, K), -128, np.int8)
+    b[1::2] = 127
+    got = mixlib.gemm(to_dev(a), to_dev(b), M, N, K).cpu().numpy()
+    assert got[0, 0] == 128 * 128 * K and got[0, 1] == -128 * 127 * K
+
+
+@pytest.mark.parametrize("M,N,K", [(7, 16, 32), (37, 256, 512), (130, 272, 1040), (300, 512, 256)])
+@pytest.mark.parametrize("silu", [False, True])
+def test_fused_dequant_epilogue(oracle, M, N, K, silu):
+    """int8FusedDequantize(A,B,scale_row,scale_col,y): exact integer GEMM + fp32 FMA + one RNE -> bit-exact;
+    the SiLU variant goes through expf, whose device implementation may differ by an ulp -> 1e-3."""
+    from mixq_tensorrt_llm_amd import mixlib
+    rng = np.random.default_rng(K)
+    a = rng.integers(-127, 128, size=(M, K), dtype=np.int8)
+    b = rng.integers(-127, 128, size=(N, K), dtype=np.int8)
+    sa = (np.abs(rng.standard_normal(M)) * 0.05 + 1e-3).astype(np.float16)
+    sb = (np.abs(rng.standard_normal(N)) * 1e-3 + 1e-5).astype(np.float16)
+    y = rng.standard_normal((M, N)).astype(np.float16)
+    fn = mixlib.int8FusedDequantizeSilu if silu else mixlib.int8FusedDequantize
+    got = fn(to_dev(a), to_dev(b), to_dev(sa), to_dev(sb), to_dev(y), M, N, K).cpu().numpy()
+    want = oracle.dequant_epilogue(oracle.gemm_s8s8s32(a, b), sa, sb, y, silu=silu)
+    if silu:
+        assert rel_err(got, want) < REL_TOL
+    else:
+        assert np.array_equal(bits(got), bits(want))
+
+
+def test_unfused_pair_matches_reference_rounding(oracle):
+    """mixlib.gemm + dequantizeInt8 (P-flavour sm90 route, linear.py:231-238): two roundings, bit-exact."""
+    from mixq_tensorrt_llm_amd import mixlib
+    rng = np.random.default_rng(1)
+    M, N, K = 45, 96, 256
+    a = rng.integers(-127, 128, size=(M, K), dtype=np.int8)
+    b = rng.integers(-127, 128, size=(N, K), dtype=np.int8)
+    sa = (np.abs(rng.standard_normal(M)) * 0.05).astype(np.float16)
+    sb = (np.abs(rng.standard_normal(N)) * 1e-3).astype(np.float16)
+    y = rng.standard_normal((M, N)).astype(np.float16)
+    acc = mixlib.gemm(to_dev(a), to_dev(b), M, N, K)
+    got = mixlib.dequantizeInt8(acc, to_dev(sa), to_dev(sb), to_dev(y), 8, M, N).cpu().numpy()
+    want = oracle.dequantization(oracle.gemm_s8s8s32(a, b), sa, sb, y)
+    assert np.array_equal(bits(got), bits(want))
+
+
+def test_fp16_side_gemm(oracle):
+    from mixq_tensorrt_llm_amd import _lib
+    rng = np.random.default_rng(2)
+    M, N, O = 70, 208, 128
+    fa = (rng.standard_normal((M, O)) * 10).astype(np.float16)
+    fw = (rng.standard_normal((N, O)) * 0.02).astype(np.float16)
+    out = torch.empty((M, N), dtype=torch.float16, device=dev())
+    a_d, w_d = to_dev(fa), to_dev(fw)
+    rc = _lib.load().mixq_gemm_fp16(a_d.data_ptr(), w_d.data_ptr(), out.data_ptr(), M, N, O,
+                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    assert rel_err(out.cpu().numpy(), oracle.gemm_fp16(fa, fw)) < REL_TOL
+
+
+# --------------------------------------------------------------------------- the whole operator --------
+LINEAR_SHAPES = [(5, 128, 256), (32, 256, 512), (37, 256, 512), (100, 512, 1024), (129, 400, 640), (256, 1024, 2048),
+                 (300, 768, 1280), (520, 512, 3584)]
+
+
+def run_enqueue(A, p, lead=None):
+    from mixq_tensorrt_llm_amd import plugin
+    M, K = A.shape
+    N = p["weight"].shape[0]
+    layer = plugin.MixQLinear(K, N, device=dev()).load(p)
+    x = to_dev(A)
+    if lead is not None:
+        x = x.reshape(*lead, K)
+    out = layer(x)
+    torch.cuda.synchronize()
+    return out.cpu().numpy().reshape(M, N)
+
+
+@pytest.mark.parametrize("M,N,K", LINEAR_SHAPES)
+def test_enqueue_prefill_matches_oracle(oracle, M, N, K):
+    A, W, act = make_layer(M, N, K, seed=M + N)
+    p = oracle.pack_linear_weights(W, act)
+    got = run_enqueue(A, p)
+    want, parts = oracle.linear_prefill(A, p["weight"], p["weights_scaling_factor"], p["fp_weight"], p["fp_ind"],
+                                        return_parts=True)
+    assert rel_err(got, want) < REL_TOL
+    # and the answer is the operator's, not just self-consistent: close to the unquantised product
+    ref = A.astype(np.float64) @ W.astype(np.float64).T
+    assert rel_err(got, ref.astype(np.float32)) < 0.05
+    mism = np.mean(bits(got) != bits(want))
+    assert mism < 0.02, f"{mism:.4f} of outputs differ from the oracle by >= 1 fp16 ulp"
+
+
+def test_enqueue_gemm_stage_is_bit_exact_given_oracle_side_product(oracle):
+    """Feeding the oracle's fp16 side product P as the addend removes the only order-dependent step: the remaining
+    pipeline (quant -> int8 GEMM -> dequant FMA) must then agree with the oracle bit for bit."""
+    from mixq_tensorrt_llm_amd import mixlib
+    M, N, K = 150, 384, 1024
+    A, W, act = make_layer(M, N, K, seed=77)
+    p = oracle.pack_linear_weights(W, act)
+    want, parts = oracle.linear_prefill(A, p["weight"], p["weights_scaling_factor"], p["fp_weight"], p["fp_ind"],
+                                        return_parts=True)
+    x = to_dev(A)
+    s = torch.empty(M, dtype=torch.float16, device=dev())
+    q = mixlib.FindRowScale(x, s, M, K, 8)
+    got = mixlib.int8FusedDequantize(q, to_dev(p["weight"]), s, to_dev(p["weights_scaling_factor"]),
+                                     to_dev(parts["P"]), M, N, K).cpu().numpy()
+    assert np.array_equal(bits(got), bits(want))
+
+
+def test_enqueue_leading_dims_and_registry_path(oracle):
+    from mixq_tensorrt_llm_amd import plugin
+    A, W, act = make_layer(48, 256, 512, seed=4)
+    p = oracle.pack_linear_weights(W, act)
+    got3d = run_enqueue(A, p, lead=(4, 12))
+    want = oracle.linear_prefill(A, p["weight"], p["weights_scaling_factor"], p["fp_weight"], p["fp_ind"])
+    assert rel_err(got3d, want) < REL_TOL
+    layer = plugin.MixQLinear(512, 256, device=dev()).load(p)
+    out = plugin.mixgemm(48, 256, 512, [to_dev(A), layer.weight, layer.weights_scaling_factor, layer.fp_weight,
+                                        layer.fp_ind, layer.qweight, layer.weights_scaling_factor])
+    assert rel_err(out.cpu().numpy(), want) < REL_TOL
+
+
+def test_enqueue_edge_rows(oracle):
+    """Zero rows, a NaN, an all-outlier row, M = 5 (smallest prefill), ragged M."""
+    A, W, act = make_layer(5, 128, 256, seed=8)
+    p = oracle.pack_linear_weights(W, act)
+    A[1] = 0
+    A[2, :] = 0
+    A[2, p["fp_ind"]] = np.float16(3.0)   # only outlier columns are non-zero
+    got = run_enqueue(A, p)
+    want = oracle.linear_prefill(A, p["weight"], p["weights_scaling_factor"], p["fp_weight"], p["fp_ind"])
+    with np.errstate(invalid="ignore"):
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        ok = ~np.isnan(want)
+        assert np.abs(got[ok].astype(np.float64) - want[ok].astype(np.float64)).max() <= \
+            REL_TOL * np.abs(want[ok].astype(np.float64)).max()
+
+
+@pytest.mark.parametrize("M", [1, 2, 3, 4])
+@pytest.mark.parametrize("N,K", [(128, 256), (512, 1024), (384, 4096)])
+def test_enqueue_decode_path(oracle, M, N, K):
+    """M <= 4 routes to the W8A16 path on the EETQ-interleaved qweight (TsinghuaMixQPlugin.cpp:641-647).
+    Tolerance 5e-3: the reference accumulates per-thread partial sums in fp16 (kernel.h:425-433), an artefact of its
+    launch shape; both the oracle and the HIP kernel keep fp32 sums of fp16-rounded weights."""
+    A, W, act = make_layer(M, N, K, seed=N + M, outlier_gain=1.0)
+    p = oracle.pack_linear_weights(W, act)
+    got = run_enqueue(A, p)
+    q_un = oracle.eetq_symmetric_quantize(W.T.copy())[0]
+    want = oracle.w8a16_gemv(A, q_un, p["weights_scaling_factor"])   # plugin reuses max/127 scales
+    assert rel_err(got, want) < 5e-3
+
+
+def test_tp_shards_compose(oracle):
+    """Row-sharded W on one GPU: concatenating the shards' outputs equals the unsharded operator bit for bit."""
+    from mixq_tensorrt_llm_amd import pack, parallel
+    A, W, act = make_layer(70, 512, 512, seed=21)
+    full = pack.pack_linear_weights(torch.from_numpy(W), torch.from_numpy(act))
+    whole = run_enqueue(A, full)
+    parts = [run_enqueue(A, parallel.shard_packed(full, 4, r)) for r in range(4)]
+    assert np.array_equal(bits(np.concatenate(parts, axis=1)), bits(whole))
+
+
+# --------------------------------------------------- full-size properties (no oracle at these sizes) ---
+def test_full_size_linearity_and_row_independence():
+    """Llama-2-7B qkv shape, M = 2048: (i) int32 GEMM is linear in W: acc(W1) + acc(W2) == acc(W1 + W2) when no int8
+    overflow; (ii) quantisation is per-row: permuting rows of A permutes rows of Out bit-exactly."""
+    from mixq_tensorrt_llm_amd import mixlib
+    g = torch.Generator(device="cpu").manual_seed(0)
+    M, N, K = 2048, 12288, 4096
+    a = torch.randint(-128, 128, (M, K), dtype=torch.int8, generator=g).to(dev())
+    w1 = torch.randint(-60, 60, (N, K), dtype=torch.int8, generator=g).to(dev())
+    w2 = torch.randint(-60, 60, (N, K), dtype=torch.int8, generator=g).to(dev())
+    acc = mixlib.gemm(a, w1, M, N, K) + mixlib.gemm(a, w2, M, N, K)
+    assert torch.equal(acc, mixlib.gemm(a, (w1 + w2), M, N, K))
+    # checksum against an independent formulation: column sums
+    colsum = (a.to(torch.float64).sum(dim=0, keepdim=True) @ w1.to(torch.float64).t()).to(torch.int64)
+    assert torch.equal(mixlib.gemm(a, w1, M, N, K).to(torch.int64).sum(dim=0, keepdim=True), colsum)
+    A = torch.randn((M, K), generator=g).to(torch.float16).to(dev())
+    sW = (torch.rand(N, generator=g) * 1e-3 + 1e-4).to(torch.float16).to(dev())
+    fpw = (torch.randn((N, 128), generator=g) * 0.02).to(torch.float16).to(dev())
+    ind = torch.randperm(K, generator=g)[:128].to(torch.int32).to(dev())
+    out = mixlib.mixq_linear(A, w1, sW, fpw, ind)
+    perm = torch.randperm(M, generator=g).to(dev())
+    out_p = mixlib.mixq_linear(A[perm].contiguous(), w1, sW, fpw, ind)
+    assert torch.equal(out[perm], out_p)
+    assert torch.isfinite(out).all()

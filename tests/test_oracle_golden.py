@@ -1,0 +1,132 @@
+"""CPU: the oracle against the committed golden vectors (generated from the importable reference pieces by
+tests/golden/gen_golden.py) and against independent restatements (numpy float16 for the fp16 primitives)."""
+import os
+
+import numpy as np
+
+from conftest import GOLDEN
+
+
+def test_fp16_conversions_exhaustive(oracle):
+    lib = oracle.lib()
+    import ctypes
+    lib.mixq_oracle_h2f.restype = ctypes.c_float
+    lib.mixq_oracle_h2f.argtypes = [ctypes.c_uint16]
+    lib.mixq_oracle_f2h.restype = ctypes.c_uint16
+    lib.mixq_oracle_f2h.argtypes = [ctypes.c_float]
+    bits = np.arange(65536, dtype=np.uint16)
+    ref = bits.view(np.float16).astype(np.float32)
+    got = np.array([lib.mixq_oracle_h2f(int(b)) for b in bits], dtype=np.float32)
+    assert np.array_equal(ref.view(np.uint32)[~np.isnan(ref)], got.view(np.uint32)[~np.isnan(ref)])
+    assert np.all(np.isnan(got[np.isnan(ref)]))
+    # float -> half RNE: every half value, every midpoint between neighbours, and random floats
+    rng = np.random.default_rng(0)
+    f = np.concatenate([
+        ref[~np.isnan(ref)],
+        ((ref[:-1].astype(np.float64) + ref[1:].astype(np.float64)) / 2).astype(np.float32)[~np.isnan(ref[:-1] + ref[1:])],
+        rng.standard_normal(20000).astype(np.float32) * 100,
+        (rng.standard_normal(20000) * 1e-6).astype(np.float32),
+        np.array([65504, 65519.99, 65520, 70000, 1e-8, 2.98e-8, 2.9802322e-8, 5.96e-8, -0.0, np.inf, -np.inf], np.float32),
+    ])
+    want = f.astype(np.float16).view(np.uint16)
+    got = np.array([lib.mixq_oracle_f2h(float(x)) for x in f], dtype=np.uint16)
+    assert np.array_equal(want, got)
+
+
+def test_weight_packing_matches_reference_golden(oracle):
+    g = np.load(os.path.join(GOLDEN, "pack_small.npz"))
+    W = g["W"]
+    sW = oracle.weight_scales(W)
+    assert np.array_equal(sW.view(np.uint16), g["weights_scaling_factor"].view(np.uint16))
+    # to_quantized_weight (reference function) on the reference's own fp_ind
+    Wq = oracle.quantize_weight(W, sW, g["fp_ind"])
+    assert np.array_equal(Wq, g["weight_int8"])
+    assert np.array_equal(W[:, g["fp_ind"]].view(np.uint16), g["fp_weight"].view(np.uint16))
+    assert np.all(Wq[:, g["fp_ind"]] == 0)
+
+
+def test_outlier_selection_matches_reference_up_to_ties(oracle):
+    """torch.sort (unstable) leaves the order inside groups of equal scales unspecified; everything else must agree:
+    the selected scale values position by position, and the index set wherever no tie straddles the cut."""
+    a = np.load(os.path.join(GOLDEN, "act_scales_llama.npz"))
+    for i in range(3):
+        s, ref = a[f"scales_{i}"], a[f"fp_ind_{i}"]
+        mine = oracle.select_outliers(s)
+        assert np.array_equal(s[mine], s[ref])
+        cut = s[ref[0]]
+        strict_ref = set(ref[s[ref] > cut].tolist())
+        strict_mine = set(mine[s[mine] > cut].tolist())
+        assert strict_ref == strict_mine
+        if np.sum(s == cut) == np.sum(s[ref] == cut):  # no tie across the cut -> identical sets
+            assert set(ref.tolist()) == set(mine.tolist())
+    g = np.load(os.path.join(GOLDEN, "pack_small.npz"))
+    mine = oracle.select_outliers(g["layer_scales"])
+    assert np.array_equal(g["layer_scales"][mine], g["layer_scales"][g["fp_ind"]])
+
+
+def test_quant_rows_against_numpy_float16(oracle):
+    """numpy's float16 division is correctly rounded (computed in fp32, rounded once) == the oracle's __hdiv."""
+    rng = np.random.default_rng(3)
+    A = (rng.standard_normal((9, 512)) * 3).astype(np.float16)
+    A[2] = 0                      # zero row: 0/0 -> NaN -> 0, scale 0
+    A[3, 5] = np.float16(60000)   # huge amax
+    A[4, 7] = np.nan              # NaN element is dropped by __hmax and quantises to 0
+    A[5, :] = np.float16(6e-8)    # subnormal amax: scale underflows to 0 -> x/0 = inf -> INT_MAX -> int8 -1
+    qA, sA = oracle.quant_rows(A)
+    with np.errstate(all="ignore"):
+        amax = np.nanmax(np.abs(A.astype(np.float32)), axis=1).astype(np.float16)
+        s = (amax / np.float16(127)).astype(np.float16)
+        assert np.array_equal(s.view(np.uint16), sA.view(np.uint16))
+        q = (A / s[:, None]).astype(np.float16).astype(np.float32)
+        want = np.where(np.isnan(q), 0, np.where(np.isinf(q), np.where(q > 0, 2**31 - 1, -2**31), np.rint(q)))
+        want = (want.astype(np.int64) & 0xff).astype(np.uint8).view(np.int8)
+    assert np.array_equal(qA, want)
+    assert np.all(qA[2] == 0) and sA[2] == 0
+    assert qA[4, 7] == 0
+    assert np.all(qA[5] == -1)
+    assert np.abs(qA[[0, 1, 3, 6, 7, 8]].astype(np.int32)).max() == 127
+
+
+def test_linear_prefill_against_float64(oracle):
+    from conftest import make_layer
+    A, W, act = make_layer(37, 256, 512, seed=5)
+    p = oracle.pack_linear_weights(W, act)
+    out, parts = oracle.linear_prefill(A, p["weight"], p["weights_scaling_factor"], p["fp_weight"], p["fp_ind"],
+                                       return_parts=True)
+    # int32 accumulators vs exact integer matmul
+    acc = parts["qA"].astype(np.int64) @ p["weight"].astype(np.int64).T
+    assert np.array_equal(acc, parts["acc"].astype(np.int64))
+    # the whole operator approximates A @ W^T (quantisation error only)
+    ref = A.astype(np.float64) @ W.astype(np.float64).T
+    err = np.abs(out.astype(np.float64) - ref)
+    assert err.max() < 0.05 * np.abs(ref).max()
+    # epilogue identity on the parts
+    o2 = oracle.dequant_epilogue(parts["acc"], parts["sA"], p["weights_scaling_factor"], parts["P"])
+    assert np.array_equal(o2.view(np.uint16), out.view(np.uint16))
+
+
+def test_eetq_layout_roundtrip_and_structure(oracle):
+    rng = np.random.default_rng(7)
+    K, N = 128, 64
+    q = rng.integers(-128, 128, size=(K, N), dtype=np.int8)
+    img = oracle.eetq_preprocess(q).reshape(-1)
+    # closed form of the layout (csrc/decode_kernels.hip header), derived independently of the loop restatement
+    P = [0, 1, 8, 9, 2, 3, 10, 11, 4, 5, 12, 13, 6, 7, 14, 15]
+    for n in range(N):
+        for tb in range(K // 64):
+            for x in range(64):
+                xs = (x & ~3) | ((x & 1) << 1) | ((x & 2) >> 1)
+                k = 64 * tb + 16 * (xs // 16) + P[xs % 16]
+                assert img[(n // 2) * 2 * K + tb * 128 + (n % 2) * 64 + x] == (int(q[k, n]) + 128)
+
+
+def test_w8a16_gemv_matches_float64(oracle):
+    rng = np.random.default_rng(11)
+    K, N, M = 256, 64, 3
+    Wt = (rng.standard_normal((K, N)) * 0.02).astype(np.float16)
+    q, sc = oracle.eetq_symmetric_quantize(Wt)
+    A = rng.standard_normal((M, K)).astype(np.float16)
+    out = oracle.w8a16_gemv(A, q, sc)
+    ref = A.astype(np.float64) @ (q.astype(np.float64) * sc.astype(np.float64)[None, :])
+    assert np.allclose(out.astype(np.float64), ref, rtol=2e-2, atol=2e-3)
+    assert np.abs(q).max() <= 128 and np.abs(q.astype(np.int32)).max() >= 126
