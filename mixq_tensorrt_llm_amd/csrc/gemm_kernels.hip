@@ -243,10 +243,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_w8a8o16_kernel(con
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             // addend: the fp16-rounded outlier product (cuBLAS writes fp16) or the caller's y
-                            const float c = has_outliers ? h2f(f2h_bits(P[4 * g + e])) : h2f(yh[e]);
+                            const float c = has_outliers ? h2f(f2h_bits_of_f32_result(P[4 * g + e])) : h2f(yh[e]);
                             float v = __builtin_fmaf((float)acc[i][j][4 * g + e], h2f(swh[e]) * sa, c);
                             if (EPI == EPI_DEQUANT_SILU) v = v / (1.f + __expf(-v));
-                            oh[e] = f2h_bits(v);
+                            oh[e] = f2h_bits_of_f32_result(v);
                         }
                         uint2 o;
                         o.x = (unsigned)oh[0] | ((unsigned)oh[1] << 16);
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void dequantization_kernel(uint16_t* __restric
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int m = (int)(i / N), n = (int)(i % N);
         const float t = ((float)x[i] * h2f(sRow[m])) * h2f(sCol[n]);
-        out[i] = f2h_bits(h2f(f2h_bits(t)) + h2f(out[i]));
+        out[i] = f2h_bits_of_f32_result(h2f(f2h_bits_of_f32_result(t)) + h2f(out[i]));
     }
 }
 

@@ -30,6 +30,15 @@ __device__ __forceinline__ uint16_t f2h_bits(float f)
     return b;
 }
 
+// fp32 -> fp16 with the fp32 value pinned in a VGPR first.  Without the (empty) asm hipcc folds
+// "fptrunc(fma(...))" into v_fma_mixlo/mixhi_f16, whose result is not the twice-rounded value
+// fp16(fp32(fma)) the reference computes (__float2half of an fp32 FMA) -- measured: rare 1-ulp differences.
+__device__ __forceinline__ uint16_t f2h_bits_of_f32_result(float f)
+{
+    asm("" : "+v"(f));
+    return f2h_bits(f);
+}
+
 // 16-byte async copy global -> LDS.  LDS destination = wave-uniform base + lane*16 (hardware rule); the
 // per-lane part lives entirely in the global source address.
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base)

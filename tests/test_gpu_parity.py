@@ -29,6 +29,16 @@ def bits(a):
     return np.ascontiguousarray(a).view(np.uint16)
 
 
+def assert_bits_equal(got, want, what=""):
+    g, w = bits(got), bits(want)
+    if not np.array_equal(g, w):
+        bad = np.argwhere(g != w)
+        i = tuple(bad[0])
+        raise AssertionError(f"{what}: {len(bad)} of {g.size} fp16 values differ; first at {i}: got {got[i]!r} "
+                             f"(0x{int(g[i]):04x}) want {want[i]!r} (0x{int(w[i]):04x}); max |diff| "
+                             f"{np.nanmax(np.abs(got.astype(np.float64) - want.astype(np.float64)))}")
+
+
 REL_TOL = 1e-3  # north_star: fp16 output within 1e-3 relative (normalised by the output's max magnitude)
 
 
@@ -150,7 +160,7 @@ def test_fused_dequant_epilogue(oracle, M, N, K, silu):
     if silu:
         assert rel_err(got, want) < REL_TOL
     else:
-        assert np.array_equal(bits(got), bits(want))
+        assert_bits_equal(got, want, "int8FusedDequantize")
 
 
 def test_unfused_pair_matches_reference_rounding(oracle):
@@ -166,7 +176,7 @@ def test_unfused_pair_matches_reference_rounding(oracle):
     acc = mixlib.gemm(to_dev(a), to_dev(b), M, N, K)
     got = mixlib.dequantizeInt8(acc, to_dev(sa), to_dev(sb), to_dev(y), 8, M, N).cpu().numpy()
     want = oracle.dequantization(oracle.gemm_s8s8s32(a, b), sa, sb, y)
-    assert np.array_equal(bits(got), bits(want))
+    assert_bits_equal(got, want, "gemm + dequantizeInt8")
 
 
 def test_fp16_side_gemm(oracle):
@@ -230,7 +240,7 @@ def test_enqueue_gemm_stage_is_bit_exact_given_oracle_side_product(oracle):
     q = mixlib.FindRowScale(x, s, M, K, 8)
     got = mixlib.int8FusedDequantize(q, to_dev(p["weight"]), s, to_dev(p["weights_scaling_factor"]),
                                      to_dev(parts["P"]), M, N, K).cpu().numpy()
-    assert np.array_equal(bits(got), bits(want))
+    assert_bits_equal(got, want, "quant -> int8 GEMM -> dequant FMA")
 
 
 def test_enqueue_leading_dims_and_registry_path(oracle):

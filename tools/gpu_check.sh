@@ -20,7 +20,7 @@ else
 fi
 echo "== rocprofv3 kernel trace"
 rm -rf "$OUT/prof" ; mkdir -p "$OUT/prof"
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof" -o mixq -- \
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/prof" -o mixq -- \
     python "$OLDPWD/bench.py" --tokens 65536 --steps 1 --warmup 1 --no-cpu-baseline ) > "$OUT/rocprof.log" 2>&1
 tail -3 "$OUT/rocprof.log"
 find "$OUT/prof" -name "*kernel_stats*" | head -3
