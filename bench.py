@@ -121,6 +121,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=8192, help="M of each operator call")
     ap.add_argument("--tp", type=int, default=1, help="rows-of-W sharding degree (1 = pure DP, no collective)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", type=int, default=0, help="GEMM schedule: 0 auto, 1 two-barrier, 2 ping-pong (A/B runs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -148,6 +149,7 @@ def main():
     from mixq_tensorrt_llm_amd._lib import TensorDesc
     lib = _lib.load()
     assert lib.initOpenAiTritonPlugins(None, b"tensorrt_llm")
+    lib.mixq_debug_set_gemm_variant(args.variant)
     hip = Hip()
 
     chunk = min(args.chunk, args.tokens)
@@ -260,7 +262,8 @@ def main():
             "gemm_tops_end_to_end": value * int8_gop_per_token / 1e3 / world,
             "roofline": {"bound": "mfma", "achieved": achieved_tops, "peak": INT8_MFMA_PEAK_TOPS, "unit": "TOP/s",
                          "frac": achieved_tops / INT8_MFMA_PEAK_TOPS, "traffic": None,
-                         "kernel": "gemm_w8a8o16_kernel<256,256,2,4,EPI_DEQUANT>",
+                         "kernel": "gemm_w8a8o16_kernel<256,256,2,4,0>" if args.variant == 1
+                         else "gemm_w8a8o16_pp_kernel<0>",
                          "avg_launch_ms": avg_launch_s * 1e3, "launches": n_launch,
                          "ops_per_launch": ops_per_launch,
                          "gemm_share_of_wall": gemm_ms / 1e3 / elapsed},

@@ -169,6 +169,9 @@ MIXQ_API int mixq_w8a16_gemm_forward(const void* input_f16, const uint8_t* weigh
 MIXQ_API int mixq_preprocess_weights_int8(uint8_t* preprocessed, const int8_t* row_major, size_t rows, size_t cols);
 MIXQ_API int mixq_unprocess_weights_int8(int8_t* row_major, const uint8_t* preprocessed, size_t rows, size_t cols);
 
+/* Test / measurement knob: main-loop schedule of the fused GEMM.  0 = auto (default), 1 = 2-barrier double-buffered
+ * kernel only, 2 = 256x256 ping-pong kernel for every M > 4.  Results are identical bit for bit in all modes. */
+MIXQ_API void mixq_debug_set_gemm_variant(int variant);
 MIXQ_API const char* mixq_version(void);
 MIXQ_API const char* mixq_error_string(int code);
 

@@ -93,6 +93,7 @@ SIGNATURES = {
     "mixq_w8a16_gemm_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "mixq_preprocess_weights_int8": (_i, [_vp, _vp, _sz, _sz]),
     "mixq_unprocess_weights_int8": (_i, [_vp, _vp, _sz, _sz]),
+    "mixq_debug_set_gemm_variant": (None, [_i]),
     "mixq_version": (ctypes.c_char_p, []),
     "mixq_error_string": (ctypes.c_char_p, [_i]),
 }

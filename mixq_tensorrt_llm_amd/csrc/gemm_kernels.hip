@@ -24,6 +24,8 @@
 //     of GROUP_M row-tiles so that co-resident workgroups share W / qA panels in that XCD's private L2.
 #include "mixq_device.h"
 #include "mixq_launch.h"
+#include <atomic>
+#include <cstdlib>
 
 namespace mixq {
 
@@ -285,9 +287,31 @@ static hipError_t launch_epi(const GemmParams& p, hipStream_t st)
     return launch_cfg<256, 256, 2, 4, EPI>(p, st);
 }
 
+// Schedule selection.  0 = auto (ping-pong 256x256 kernel when the problem fills the chip with 256x256 tiles, else the
+// 2-barrier kernel in a smaller tile), 1 = always the 2-barrier kernel, 2 = ping-pong whenever M > 4.
+// Set through mixq_debug_set_gemm_variant() (tests, A/B measurements) or MIXQ_GEMM_VARIANT=v1|pp in the environment.
+static std::atomic<int> g_variant{-1};
+
+void set_gemm_variant(int v) { g_variant.store(v); }
+
+static int gemm_variant()
+{
+    int v = g_variant.load();
+    if (v < 0) {
+        const char* e = getenv("MIXQ_GEMM_VARIANT");
+        v = (e && e[0] == 'v' && e[1] == '1') ? 1 : (e && e[0] == 'p' && e[1] == 'p') ? 2 : 0;
+        g_variant.store(v);
+    }
+    return v;
+}
+
 hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st)
 {
     if (p.M <= 0 || p.N <= 0) return hipSuccess;
+    const int variant = gemm_variant();
+    const int64_t tiles256 = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256);
+    if (variant >= 100) return launch_gemm_pp_ablate(p, variant - 100, st); // measurement-only ablations
+    if (variant == 2 || (variant == 0 && p.M > 128 && tiles256 >= 96)) return launch_gemm_pp(p, epi, st);
     switch (epi) {
     case EPI_DEQUANT: return launch_epi<EPI_DEQUANT>(p, st);
     case EPI_DEQUANT_SILU: return launch_epi<EPI_DEQUANT_SILU>(p, st);

@@ -100,6 +100,8 @@ int mixq_registry_has_creator(const char* name, const char* version, const char*
 
 const char* mixq_plugin_type(void) { return "MixQ"; }
 const char* mixq_plugin_version(void) { return "1"; }
+void mixq_debug_set_gemm_variant(int variant) { mixq::set_gemm_variant(variant < 0 ? 0 : variant); }
+
 const char* mixq_version(void) { return "mixq-mi355x 0.1 (gfx950)"; }
 
 const char* mixq_error_string(int code)

@@ -132,6 +132,57 @@ def test_int32_accumulators_bit_exact(oracle, M, N, K):
     assert np.array_equal(got, want)
 
 
+@pytest.fixture
+def variant():
+    """Force a main-loop schedule (1 = 2-barrier kernel, 2 = 256x256 ping-pong kernel); auto again afterwards."""
+    from mixq_tensorrt_llm_amd import _lib
+    lib = _lib.load()
+    yield lib.mixq_debug_set_gemm_variant
+    lib.mixq_debug_set_gemm_variant(0)
+
+
+@pytest.mark.parametrize("which", [1, 2])
+@pytest.mark.parametrize("M,N,K", [(5, 16, 16), (33, 144, 272), (129, 256, 384), (256, 512, 128), (300, 768, 640),
+                                   (513, 1280, 896), (700, 528, 2064), (1024, 1024, 4096)])
+def test_every_schedule_gives_identical_int32(oracle, variant, which, M, N, K):
+    """Ragged M, N not a multiple of the tile, K not a multiple of the 128-byte slice, odd and even slice counts."""
+    from mixq_tensorrt_llm_amd import mixlib
+    variant(which)
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    a = rng.integers(-128, 128, size=(M, K), dtype=np.int8)
+    b = rng.integers(-128, 128, size=(N, K), dtype=np.int8)
+    got = mixlib.gemm(to_dev(a), to_dev(b), M, N, K).cpu().numpy()
+    want = a.astype(np.int32) @ b.astype(np.int32).T
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("which", [1, 2])
+def test_every_schedule_full_operator(oracle, variant, which):
+    variant(which)
+    M, N, K = 300, 768, 1280
+    A, W, act = make_layer(M, N, K, seed=31)
+    p = oracle.pack_linear_weights(W, act)
+    got = run_enqueue(A, p)
+    want = oracle.linear_prefill(A, p["weight"], p["weights_scaling_factor"], p["fp_weight"], p["fp_ind"])
+    assert rel_err(got, want) < REL_TOL
+
+
+def test_schedules_agree_bitwise_on_the_full_operator(variant):
+    from mixq_tensorrt_llm_amd import mixlib
+    g = torch.Generator(device="cpu").manual_seed(5)
+    M, N, K = 1100, 1536, 2176
+    A = torch.randn((M, K), generator=g).to(torch.float16).to(dev())
+    W = torch.randint(-127, 128, (N, K), dtype=torch.int8, generator=g).to(dev())
+    sW = (torch.rand(N, generator=g) * 1e-3 + 1e-4).to(torch.float16).to(dev())
+    fpw = (torch.randn((N, 128), generator=g) * 0.02).to(torch.float16).to(dev())
+    ind = torch.randperm(K, generator=g)[:128].to(torch.int32).to(dev())
+    outs = []
+    for which in (1, 2):
+        variant(which)
+        outs.append(mixlib.mixq_linear(A, W, sW, fpw, ind))
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_int32_extremes_do_not_saturate(oracle):
     from mixq_tensorrt_llm_amd import mixlib
     M, N, K = 32, 128, 28672

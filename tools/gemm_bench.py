@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Kernel-level A/B harness: time mixq_gemm_mixed (and the quant pre-pass) on one shape with HIP events.
+usage: python tools/gemm_bench.py [--M 8192 --N 12288 --K 4096 --O 128 --variant 0|1|2 --iters 20 --what gemm|quant|both]"""
+import argparse
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from mixq_tensorrt_llm_amd import _lib  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--M", type=int, default=8192)
+    ap.add_argument("--N", type=int, default=12288)
+    ap.add_argument("--K", type=int, default=4096)
+    ap.add_argument("--O", type=int, default=128)
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--what", default="both")
+    ap.add_argument("--zero", action="store_true", help="zero-filled operands (DVFS ceiling probe)")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    lib.mixq_debug_set_gemm_variant(a.variant)
+    g = torch.Generator(device=dev).manual_seed(0)
+    M, N, K, O = a.M, a.N, a.K, a.O
+    A = torch.randn((M, K), device=dev, generator=g).to(torch.float16)
+    W = torch.randn((N, K), device=dev, generator=g).mul_(32).round_().clamp_(-127, 127).to(torch.int8)
+    ind = torch.randperm(K, device=dev, generator=g)[:O].to(torch.int32)
+    A[:, ind.long()] *= 20
+    if a.zero:
+        A.zero_(), W.zero_()
+    sW = (torch.rand(N, device=dev, generator=g) * 4e-4 + 4e-4).to(torch.float16)
+    fpW = (torch.randn((N, O), device=dev, generator=g) * 0.02).to(torch.float16)
+    qA = torch.empty((M, K), dtype=torch.int8, device=dev)
+    sA = torch.empty(M, dtype=torch.float16, device=dev)
+    fpA = torch.empty((M, O), dtype=torch.float16, device=dev)
+    out = torch.empty((M, N), dtype=torch.float16, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+
+    def quant():
+        assert lib.mixq_quant_extract(M, K, p(A), p(qA), p(sA), p(fpA), p(ind), O, 0, st) == 0
+
+    def gemm():
+        assert lib.mixq_gemm_mixed(p(qA), p(W), p(sA), p(sW), p(fpA), p(fpW), p(out), M, N, K, O, st) == 0
+
+    quant()
+    gemm()
+    torch.cuda.synchronize()
+    for name, fn in (("quant", quant), ("gemm", gemm)):
+        if a.what not in (name, "both"):
+            continue
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / a.iters
+        if name == "gemm":
+            tops = (2.0 * M * N * K + 2.0 * M * N * O) / ms / 1e9
+            print(f"gemm  variant={a.variant} M={M} N={N} K={K}: {ms*1e3:.1f} us  {tops:.0f} TOPS  ({tops/5033*100:.1f}% of 5033)")
+        else:
+            gb = (2.0 * M * K + M * K + 2 * M + 2.0 * M * O) / 1e9
+            print(f"quant M={M} K={K}: {ms*1e3:.1f} us  {gb/ms*1e3:.0f} GB/s algorithmic")
+
+
+if __name__ == "__main__":
+    main()

@@ -18,6 +18,8 @@ if [ "$MODE" = "full" ]; then
 else
   timeout 600 python bench.py --tokens 131072 --steps 1 --warmup 1 2>&1 | tail -3 | tee "$OUT/bench.log"
 fi
+echo "== bench A/B (v1 two-barrier kernel)"
+timeout 600 python bench.py --tokens 131072 --steps 1 --warmup 1 --variant 1 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('v1', d['value'], d['roofline']['achieved'], d['roofline']['avg_launch_ms'])"
 echo "== rocprofv3 kernel trace"
 rm -rf "$OUT/prof" ; mkdir -p "$OUT/prof"
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/prof" -o mixq -- \
