@@ -172,6 +172,10 @@ MIXQ_API int mixq_unprocess_weights_int8(int8_t* row_major, const uint8_t* prepr
 /* Test / measurement knob: main-loop schedule of the fused GEMM.  0 = auto (default), 1 = 2-barrier double-buffered
  * kernel only, 2 = 256x256 ping-pong kernel for every M > 4.  Results are identical bit for bit in all modes. */
 MIXQ_API void mixq_debug_set_gemm_variant(int variant);
+/* Measurement knob: when non-NULL, every workgroup of the ping-pong GEMM launched by mixq_gemm_mixed writes 8 uint64
+ * shader-clock stamps (start, prologue done, main loop done, outlier operands staged, dequant math done, tile staged,
+ * stores issued, stores drained) to buffer[block*8 ..].  NULL (default) disables it. */
+MIXQ_API void mixq_debug_set_stamp_buffer(void* device_u64_8_per_block);
 MIXQ_API const char* mixq_version(void);
 MIXQ_API const char* mixq_error_string(int code);
 

@@ -1,18 +1,22 @@
 // Ping-pong ("8-phase") variant of the fused W8A8O16 GEMM for large problems on gfx950.
 //
-// Same math, same operand roles, same epilogue as gemm_kernels.hip (see its header for the reference lines replaced);
+// Same math, same operand roles, same results as gemm_kernels.hip (see its header for the reference lines replaced);
 // what changes is the main-loop schedule, built for one 512-thread workgroup per CU (256 x 256 output tile, 128 KiB LDS):
 //
 //   * the 8 waves form two groups of 4 (one wave of each group on every SIMD).  A K slice (128 B per row) is processed
-//     in 4 phases; every phase is a LOAD segment (ds_read_b128 of the next fragments + 2 global_load_lds of a later
+//     in 4 phases; every phase is a LOAD segment (ds_read_b128 of the next fragments + 2 global_load_lds of the next
 //     slice) followed by a COMPUTE segment (8 x v_mfma_i32_32x32x32_i8), separated by s_barrier.  Group 1 runs one
 //     segment behind group 0, so on each SIMD one wave is always in its MFMA segment while its partner fetches:
-//     the matrix pipe never waits for LDS or HBM latency.
+//     the matrix pipe does not wait for LDS or HBM latency.
 //   * global -> LDS copies are never drained inside the loop: each wave waits `vmcnt(4)` at the end of a LOAD segment,
 //     i.e. only for copies issued two segments earlier; the two most recent pairs stay in flight across barriers.
+//     The copies are issued from inline asm in the SGPR-base form (`global_load_lds_dwordx4 voff, s[base]`): the
+//     per-thread 32-bit offsets never change and the base advances by 128 B per slice on the scalar unit, so a LOAD
+//     segment carries no address VALU and no compiler-inserted waits.
 //   * wave tile = 128 (m) x 64 (n) = 4 x 2 MFMA tiles.  Phase order (m-half, n-half): (0,0) (0,1) (1,1) (1,0), so each
 //     LOAD segment fetches 8 or 4 fragments: Y0 | X1 | Y1 | X0-of-the-next-slice.  Two slices are unrolled per loop
-//     iteration so the two X fragment sets swap roles with static register names.
+//     iteration so the two X fragment sets swap roles with static register names.  The loop body is branch-free: the
+//     last two slices (next slice may be partial in K / no next slice) are peeled into their own instantiations.
 //   * LDS image per buffer: [X half 0 | X half 1 | Y half 0 | Y half 1], 16 KiB each, rows ordered
 //     [half][wave][row] so that every region is one contiguous run of 128-byte rows; 16-B slot = chunk ^ ((row>>1)&7).
 //
@@ -20,8 +24,12 @@
 //   RAW  a region issued at slot s is first read at slot s+3; every wave has passed `vmcnt(4)` at the end of slot
 //        s+2 (which retires everything issued up to slot s) and a barrier lies between.
 //   WAR  a region is re-issued 5 slots after its last read.
+//
+// Epilogue: fp16 outlier side GEMM (operands staged in the dead main-loop LDS, 8 unrolled k-steps per 32x32 tile),
+// dequant FMA, results packed to fp16 in registers, staged through LDS and written as whole 512-byte rows.
 #include "mixq_device.h"
 #include "mixq_launch.h"
+#include <type_traits>
 
 namespace mixq {
 
@@ -32,6 +40,10 @@ constexpr int REGION = 128 * KS;        // 16 KiB: 128 rows
 constexpr int BUF = 4 * REGION;         // 64 KiB per slice buffer
 constexpr int X0 = 0, X1 = REGION, Y0 = 2 * REGION, Y1 = 3 * REGION;
 constexpr int OSLICE = 256;
+
+enum { STEADY = 0, PENULT = 1, LAST = 2 };
+
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 #define MIXQ_SEG_END()                                  \
     do {                                                \
@@ -47,11 +59,27 @@ __device__ __forceinline__ void wait_vmcnt()
     else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
 }
+
+// 16-byte LDS-DMA, SGPR-base form.  LDS destination = M0 (wave-uniform) + lane*16; M0 is saved/restored inside the
+// statement (it is compiler-reserved).  The compiler does not count this load: every consumer sits behind one of the
+// explicit vmcnt waits + a barrier.
+__device__ __forceinline__ void glds16_sbase(const char* sbase, unsigned voff, unsigned lds_addr)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %3\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_addr)
+                 : "memory");
+}
 } // namespace pp
 
 // ABL: measurement-only ablations (wrong results): 1 = no global_load_lds in the loop, 2 = no vmcnt waits,
 // 4 = no ds_reads in the loop.  ABL = 0 is the product kernel.
-template <int EPI, int ABL = 0>
+template <int EPI, bool HAS_O, bool HAS_Y, int ABL = 0>
 __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p)
 {
     using namespace pp;
@@ -62,7 +90,7 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int group = wave >> 2;          // 0: waves 0-3, 1: waves 4-7 (one of each per SIMD)
     const int wm = wave & 1;              // 2 wave rows along m (128 each)
-    const int wn = wave >> 1;             // 4 wave columns along n (64 each); wn = 0..3 mixes both groups
+    const int wn = wave >> 1;             // 4 wave columns along n (64 each)
     const int lr = lane & 31, lh = lane >> 5;
 
     // ---- block -> tile mapping (XCD-aware, grouped; identical to gemm_kernels.hip) -------------------
@@ -88,8 +116,11 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
     // ---- staging sources: region r in {X0,X1,Y0,Y1}, two 16-B copies per thread per region per slice --------
     // LDS row q (0..127) of region (side, half h):  X: n_local = (q/32)*64 + h*32 + q%32   (q/32 = wn)
     //                                               Y: m_local = (q/64)*128 + h*64 + q%64  (q/64 = wm)
+    // Address = wave-uniform 64-bit base (tile origin + slice offset, SGPRs) + constant per-thread 32-bit offset.
     const int64_t K = p.K;
-    const char* src[4][2];
+    const char* const baseB = reinterpret_cast<const char*>(p.B) + (int64_t)n0 * K;
+    const char* const baseA = reinterpret_cast<const char*>(p.A) + (int64_t)m0 * K;
+    unsigned off[4][2];
     int koff_src;
     {
         const int slot = tid & 7;
@@ -101,25 +132,32 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
                 const int sw = (q >> 1) & 7;
                 const int nl = (q >> 5) * 64 + h * 32 + (q & 31);
                 const int ml = (q >> 6) * 128 + h * 64 + (q & 63);
-                const int gn = min(n0 + nl, p.N - 1), gm = min(m0 + ml, p.M - 1);
-                src[h][i] = reinterpret_cast<const char*>(p.B) + (int64_t)gn * K + ((slot ^ sw) << 4);
-                src[2 + h][i] = reinterpret_cast<const char*>(p.A) + (int64_t)gm * K + ((slot ^ sw) << 4);
+                const int rn = min(n0 + nl, p.N - 1) - n0, rm = min(m0 + ml, p.M - 1) - m0; // clamped rows, >= 0
+                off[h][i] = (unsigned)rn * (unsigned)p.K + ((slot ^ sw) << 4);
+                off[2 + h][i] = (unsigned)rm * (unsigned)p.K + ((slot ^ sw) << 4);
             }
         koff_src = (slot ^ (((tid >> 3) >> 1) & 7)) << 4; // same for i = 0,1 (64 rows apart)
     }
     const int nk = (p.K + KS - 1) / KS;
     const bool ktail = (p.K % KS) != 0;
+    const unsigned lds0 = (unsigned)(size_t)(MIXQ_LDS_PTR(smem)) + wave * 1024; // this wave's 1-KiB DMA window
 
-    auto issue = [&](int region, int kt) __attribute__((always_inline)) { // 2 x global_load_lds: region `region` of slice kt
+    // 2 x LDS-DMA: region `region` of slice kt.  TAILCHK: slice kt may be partial in K (chunks past K <- zero page).
+    auto issue = [&](int region, int kt, bool tailchk) __attribute__((always_inline)) {
         if (ABL & 1) return;
-        char* dst = smem + (kt & 1) * BUF + region * REGION;
-        const int64_t kbyte = (int64_t)kt * KS;
-        const bool oob = ktail && (kt == nk - 1) && (kbyte + koff_src >= K);
+        const unsigned dst = lds0 + (kt & 1) * BUF + region * REGION;
+        const char* base = (region < 2 ? baseB : baseA) + (int64_t)kt * KS; // scalar
+        if (tailchk && ktail) {
+            const bool oob = (int64_t)kt * KS + koff_src >= K;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const char* s = oob ? static_cast<const char*>(p.zeros) : src[region][i] + kbyte;
-            glds16(s, dst + (i * T + wave * 64) * 16);
+            for (int i = 0; i < 2; ++i) {
+                const char* s = oob ? static_cast<const char*>(p.zeros) : base + off[region][i];
+                glds16(s, smem + (kt & 1) * BUF + region * REGION + (i * T + wave * 64) * 16);
+            }
+            return;
         }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16_sbase(base, off[region][i], dst + i * T * 16);
     };
 
     // ---- fragment read offsets ---------------------------------------------------------------------------
@@ -165,57 +203,95 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
     };
 
     // One K slice.  Xcur holds X half 0 of this slice on entry; Xoth receives X half 1, then X half 0 of slice kt+1.
-    auto slice = [&](v4i (&Xcur)[4], v4i (&Xoth)[4], int kt) __attribute__((always_inline)) {
-        const bool more = kt + 1 < nk; // wave-uniform
+    auto slice = [&](v4i (&Xcur)[4], v4i (&Xoth)[4], int kt, auto steady_tag) __attribute__((always_inline)) {
+        constexpr bool steady = decltype(steady_tag)::value;   // compile-time: a full next slice exists, no checks
+        const bool more = steady || (kt + 1 < nk);             // wave-uniform
         // phase 1: (Y0, X0)
         read_y(kt, 0);
-        if (more) issue(0, kt + 1);
+        if (more) issue(0, kt + 1, !steady);
         if (!(ABL & 2)) { if (more) wait_vmcnt<4>(); else wait_vmcnt<2>(); }
         MIXQ_SEG_END();
         mma(Xcur, 0, 0);
         MIXQ_SEG_END();
         // phase 2: (Y0, X1)
         read_x(Xoth, kt, 1);
-        if (more) issue(2, kt + 1);
+        if (more) issue(2, kt + 1, !steady);
         if (!(ABL & 2)) { if (more) wait_vmcnt<4>(); else wait_vmcnt<0>(); }
         MIXQ_SEG_END();
         mma(Xoth, 1, 0);
         MIXQ_SEG_END();
         // phase 3: (Y1, X1)
         read_y(kt, 1);
-        if (more) issue(1, kt + 1);
+        if (more) issue(1, kt + 1, !steady);
         if (more && !(ABL & 2)) wait_vmcnt<4>();
         MIXQ_SEG_END();
         mma(Xoth, 1, 1);
         MIXQ_SEG_END();
         // phase 4: (Y1, X0); the LOAD segment already fetches X half 0 of the next slice into the free set
         if (more) read_x(Xoth, kt + 1, 0);
-        if (more) issue(3, kt + 1);
+        if (more) issue(3, kt + 1, !steady);
         if (more && !(ABL & 2)) wait_vmcnt<4>();
         MIXQ_SEG_END();
         mma(Xcur, 0, 1);
         MIXQ_SEG_END();
     };
+    using steady_t = std::true_type;
+    using tail_t = std::false_type;
 
+    // optional timeline stamps (p.dbg != nullptr): wave 0 / lane 0 of every block writes s_memtime at 8 points
+    auto stamp = [&](int idx) __attribute__((always_inline)) {
+        if (p.dbg != nullptr && tid == 0)
+            static_cast<unsigned long long*>(p.dbg)[(size_t)blockIdx.x * 8 + idx] = __builtin_readcyclecounter();
+    };
+    stamp(0);
     // ---- prologue: slice 0 completely, then stagger the groups ----------------------------------------------
-    issue(0, 0);
-    issue(2, 0);
-    issue(1, 0);
-    issue(3, 0);
+    issue(0, 0, true);
+    issue(2, 0, true);
+    issue(1, 0, true);
+    issue(3, 0, true);
     wait_vmcnt<0>();
     MIXQ_SEG_END();
     read_x(XA, 0, 0);
+    stamp(1);
     if (group == 1) MIXQ_SEG_END(); // group 1 now runs one segment behind group 0
 
-    for (int kt = 0; kt < nk; kt += 2) {
-        slice(XA, XB, kt);
-        if (kt + 1 < nk) slice(XB, XA, kt + 1);
+    {
+        int kt = 0;
+        for (; kt + 3 < nk; kt += 2) { // both slices of the pair have a full successor: branch-free body
+            slice(XA, XB, kt, steady_t{});
+            slice(XB, XA, kt + 1, steady_t{});
+        }
+        for (; kt < nk; kt += 2) { // last 1-3 slices: the next slice may be partial in K or absent (runtime checks)
+            slice(XA, XB, kt, tail_t{});
+            if (kt + 1 < nk) slice(XB, XA, kt + 1, tail_t{});
+        }
     }
     if (group == 0) MIXQ_SEG_END(); // re-align the groups
+    stamp(2);
 
-    // ---- outlier side GEMM + epilogue (same as the 2-barrier kernel) -------------------------------------------
-    const bool has_outliers = (EPI != EPI_INT32) && p.O > 0;
-    if (has_outliers) {
+    if (EPI == EPI_INT32) { // debug / unfused API: raw accumulators, 16-byte stores straight from the MFMA layout
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = m0 + wm * 128 + j * 32 + lr;
+                const int nb0 = n0 + wn * 64 + i * 32 + 4 * lh;
+                if (m < p.M) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int nb = nb0 + 8 * g;
+                        if (nb < p.N) {
+                            v4i o = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                            *reinterpret_cast<v4i*>(static_cast<int32_t*>(p.D) + (int64_t)m * p.N + nb) = o;
+                        }
+                    }
+                }
+            }
+        return;
+    }
+
+    // ---- outlier operands -> LDS (256-B rows, slot = chunk ^ (row & 15)); chunks past O come from the zero page ----
+    if (HAS_O) {
         __syncthreads();
         constexpr int OXL = BN * 16 / T, OYL = BM * 16 / T;
         const int obytes = p.O * 2;
@@ -241,83 +317,88 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    stamp(3);
 
-    const int osteps = has_outliers ? (p.O + 15) / 16 : 0;
-
-    if (EPI == EPI_INT32) { // debug / unfused API: raw accumulators, 16-byte stores straight from the MFMA layout
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int m = m0 + wm * 128 + j * 32 + lr;
-                const int nb0 = n0 + wn * 64 + i * 32 + 4 * lh;
-                if (m < p.M) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int nb = nb0 + 8 * g;
-                        if (nb < p.N) {
-                            v4i o = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                            *reinterpret_cast<v4i*>(static_cast<int32_t*>(p.D) + (int64_t)m * p.N + nb) = o;
-                        }
-                    }
-                }
-            }
-        return;
-    }
-
-    // ---- dequant math, tile by tile, results packed to fp16 in registers (acc registers die as we go) ----------
+    // ---- dequant math, tile by tile, results packed to fp16 in registers (acc registers die as we go).
+    // The side GEMM always runs 8 k-steps of 16 outlier columns (chunks past O were staged as zeros); everything is
+    // unrolled and branch-free, so the MFMA chain of one tile overlaps the VALU work of its neighbours.
     uint2 outp[2][4][4]; // [n tile][m tile][quad] : 4 consecutive n for row m
+    const int obase = (lh ^ (lr & 15)) << 4; // 16-B slot of k-step ks = obase ^ (ks << 5)
+    float sa[4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int j = 0; j < 4; ++j) sa[j] = h2f(p.sA[min(m0 + wm * 128 + j * 32 + lr, p.M - 1)]); // clamped rows never stored
+
+    // side GEMM of tile t = i*4 + j : 8 k-steps of 16 outlier columns (chunks past O were staged as zeros)
+    auto side = [&](int i, int j) __attribute__((always_inline)) {
+        v16f P;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            // acc[i][j]: n tile = wn*64 + i*32, m tile = wm*128 + j*32   (i = X half, j = Y half*2 + jy)
-            const int m = min(m0 + wm * 128 + j * 32 + lr, p.M - 1); // clamped rows are computed but never stored
-            const int nb0 = n0 + wn * 64 + i * 32 + 4 * lh;
-            v16f P;
+        for (int e = 0; e < 16; ++e) P[e] = 0.f;
+        if (HAS_O) {
+            const char* xo = smem + (wn * 64 + i * 32 + lr) * OSLICE;
+            const char* yo = smem + BN * OSLICE + (wm * 128 + j * 32 + lr) * OSLICE;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) P[e] = 0.f;
-            if (has_outliers) {
-                const char* xo = smem + (wn * 64 + i * 32 + lr) * OSLICE;
-                const char* yo = smem + BN * OSLICE + (wm * 128 + j * 32 + lr) * OSLICE;
-                const int sw16 = lr & 15;
-                for (int ks = 0; ks < osteps; ++ks) {
-                    const int off = ((ks * 2 + lh) ^ sw16) << 4;
-                    v8h xf = *reinterpret_cast<const v8h*>(xo + off);
-                    v8h yf = *reinterpret_cast<const v8h*>(yo + off);
-                    P = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf, yf, P, 0, 0, 0);
+            for (int kh = 0; kh < 2; ++kh) { // two batches of 4 k-steps keep the fragment registers at 32
+                v8h xf[4], yf[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    xf[ks] = *reinterpret_cast<const v8h*>(xo + (obase ^ ((kh * 4 + ks) << 5)));
+                    yf[ks] = *reinterpret_cast<const v8h*>(yo + (obase ^ ((kh * 4 + ks) << 5)));
                 }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) P = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf[ks], yf[ks], P, 0, 0, 0);
             }
-            const float sa = h2f(p.sA[m]);
+        }
+        return P;
+    };
+    // dequant of tile (i, j) with its side product P
+    auto dequant = [&](int i, int j, const v16f& P) __attribute__((always_inline)) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int nb = min(nb0 + 8 * g, p.N - 4);
-                const uint2 swb = *reinterpret_cast<const uint2*>(p.sW + nb);
-                const uint16_t swh[4] = {(uint16_t)(swb.x & 0xffffu), (uint16_t)(swb.x >> 16),
-                                         (uint16_t)(swb.y & 0xffffu), (uint16_t)(swb.y >> 16)};
-                uint16_t yh[4] = {0, 0, 0, 0};
-                if (p.Y != nullptr) {
-                    const uint2 yb = *reinterpret_cast<const uint2*>(p.Y + (int64_t)m * p.N + nb);
-                    yh[0] = (uint16_t)(yb.x & 0xffffu), yh[1] = (uint16_t)(yb.x >> 16);
-                    yh[2] = (uint16_t)(yb.y & 0xffffu), yh[3] = (uint16_t)(yb.y >> 16);
-                }
-                uint16_t oh[4];
+        for (int g = 0; g < 4; ++g) {
+            const int nb = min(n0 + wn * 64 + i * 32 + 4 * lh + 8 * g, p.N - 4);
+            const uint2 swb = *reinterpret_cast<const uint2*>(p.sW + nb);
+            const float swf[4] = {h2f((uint16_t)(swb.x & 0xffffu)), h2f((uint16_t)(swb.x >> 16)),
+                                  h2f((uint16_t)(swb.y & 0xffffu)), h2f((uint16_t)(swb.y >> 16))};
+            uint16_t yh[4] = {0, 0, 0, 0};
+            if (HAS_Y) {
+                const int m = min(m0 + wm * 128 + j * 32 + lr, p.M - 1);
+                const uint2 yb = *reinterpret_cast<const uint2*>(p.Y + (int64_t)m * p.N + nb);
+                yh[0] = (uint16_t)(yb.x & 0xffffu), yh[1] = (uint16_t)(yb.x >> 16);
+                yh[2] = (uint16_t)(yb.y & 0xffffu), yh[3] = (uint16_t)(yb.y >> 16);
+            }
+            uint16_t oh[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float c = has_outliers ? h2f(f2h_bits_of_f32_result(P[4 * g + e])) : h2f(yh[e]);
-                    float v = __builtin_fmaf((float)acc[i][j][4 * g + e], h2f(swh[e]) * sa, c);
+            for (int e2 = 0; e2 < 4; e2 += 2) {
+                const v2f s2 = v2f{swf[e2], swf[e2 + 1]} * sa[j]; // exact: fp16 x fp16 products
+#pragma unroll
+                for (int e = e2; e < e2 + 2; ++e) {
+                    // addend: the fp16-rounded outlier product (cuBLAS writes fp16) or the caller's y
+                    const float c = HAS_O ? h2f(f2h_bits_of_f32_result(P[4 * g + e])) : h2f(yh[e]);
+                    float v = __builtin_fmaf((float)acc[i][j][4 * g + e], s2[e - e2], c);
                     if (EPI == EPI_DEQUANT_SILU) v = v / (1.f + __expf(-v));
                     oh[e] = f2h_bits_of_f32_result(v);
                 }
-                outp[i][j][g].x = (unsigned)oh[0] | ((unsigned)oh[1] << 16);
-                outp[i][j][g].y = (unsigned)oh[2] | ((unsigned)oh[3] << 16);
             }
+            outp[i][j][g].x = (unsigned)oh[0] | ((unsigned)oh[1] << 16);
+            outp[i][j][g].y = (unsigned)oh[2] | ((unsigned)oh[3] << 16);
+        }
+    };
+    // software pipeline over the 8 tiles: the MFMA chain of tile t+1 runs under the VALU work of tile t
+    {
+        v16f Pcur = side(0, 0);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            v16f Pnext = Pcur;
+            if (t + 1 < 8) Pnext = side((t + 1) >> 2, (t + 1) & 3);
+            dequant(t >> 2, t & 3, Pcur);
+            Pcur = Pnext;
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
+    stamp(4);
 
     // ---- stage the 256 x 256 fp16 tile in LDS (512-byte rows, 16-B chunk c of row r at chunk c ^ (r & 31)), then
     //      write it out as whole rows: every store instruction covers two complete 512-byte row segments ----------
-    __syncthreads(); // everyone is done with the outlier operands in LDS
+    __syncthreads(); // everyone is done with the main-loop / outlier operands in LDS
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -331,6 +412,7 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
         }
     __syncthreads();
     {
+        stamp(5);
         uint16_t* D = static_cast<uint16_t*>(p.D);
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
@@ -340,14 +422,19 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
             const int m = m0 + r, n = n0 + c * 8;
             if (m < p.M && n < p.N) *reinterpret_cast<uint4*>(D + (int64_t)m * p.N + n) = v;
         }
+        stamp(6);
+        if (p.dbg != nullptr) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stamp(7);
+        }
     }
 }
 
-template <int EPI, int ABL = 0>
-static hipError_t launch_pp_epi(const GemmParams& p, hipStream_t st)
+template <int EPI, bool HAS_O, bool HAS_Y, int ABL = 0>
+static hipError_t launch_pp_cfg(const GemmParams& p, hipStream_t st)
 {
     constexpr size_t lds = 2 * (size_t)pp::BUF;
-    auto kern = gemm_w8a8o16_pp_kernel<EPI, ABL>;
+    auto kern = gemm_w8a8o16_pp_kernel<EPI, HAS_O, HAS_Y, ABL>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -360,16 +447,24 @@ static hipError_t launch_pp_epi(const GemmParams& p, hipStream_t st)
     return hipGetLastError();
 }
 
+template <int EPI>
+static hipError_t launch_pp_epi(const GemmParams& p, hipStream_t st)
+{
+    const bool has_o = p.O > 0, has_y = p.Y != nullptr;
+    if (has_o) return launch_pp_cfg<EPI, true, false>(p, st); // the API never passes both an addend and outliers
+    if (has_y) return launch_pp_cfg<EPI, false, true>(p, st);
+    return launch_pp_cfg<EPI, false, false>(p, st);
+}
+
 hipError_t launch_gemm_pp_ablate(const GemmParams& p, int abl, hipStream_t st)
 {
     switch (abl) {
-    case 1: return launch_pp_epi<EPI_DEQUANT, 1>(p, st);
-    case 2: return launch_pp_epi<EPI_DEQUANT, 2>(p, st);
-    case 3: return launch_pp_epi<EPI_DEQUANT, 3>(p, st);
-    case 4: return launch_pp_epi<EPI_DEQUANT, 4>(p, st);
-    case 5: return launch_pp_epi<EPI_DEQUANT, 5>(p, st);
-    case 7: return launch_pp_epi<EPI_DEQUANT, 7>(p, st);
-    default: return launch_pp_epi<EPI_DEQUANT, 0>(p, st);
+    case 1: return launch_pp_cfg<EPI_DEQUANT, true, false, 1>(p, st);
+    case 2: return launch_pp_cfg<EPI_DEQUANT, true, false, 2>(p, st);
+    case 4: return launch_pp_cfg<EPI_DEQUANT, true, false, 4>(p, st);
+    case 5: return launch_pp_cfg<EPI_DEQUANT, true, false, 5>(p, st);
+    case 7: return launch_pp_cfg<EPI_DEQUANT, true, false, 7>(p, st);
+    default: return launch_pp_cfg<EPI_DEQUANT, true, false, 0>(p, st);
     }
 }
 
@@ -378,7 +473,7 @@ hipError_t launch_gemm_pp(const GemmParams& p, int epi, hipStream_t st)
     switch (epi) {
     case EPI_DEQUANT: return launch_pp_epi<EPI_DEQUANT>(p, st);
     case EPI_DEQUANT_SILU: return launch_pp_epi<EPI_DEQUANT_SILU>(p, st);
-    default: return launch_pp_epi<EPI_INT32>(p, st);
+    default: return launch_pp_cfg<EPI_INT32, false, false>(p, st);
     }
 }
 

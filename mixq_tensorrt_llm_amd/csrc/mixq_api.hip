@@ -100,6 +100,9 @@ int mixq_registry_has_creator(const char* name, const char* version, const char*
 
 const char* mixq_plugin_type(void) { return "MixQ"; }
 const char* mixq_plugin_version(void) { return "1"; }
+static void* g_dbg_stamps = nullptr;
+void mixq_debug_set_stamp_buffer(void* device_u64_8_per_block) { g_dbg_stamps = device_u64_8_per_block; }
+
 void mixq_debug_set_gemm_variant(int variant) { mixq::set_gemm_variant(variant < 0 ? 0 : variant); }
 
 const char* mixq_version(void) { return "mixq-mi355x 0.1 (gfx950)"; }
@@ -337,6 +340,7 @@ int mixq_gemm_mixed(const int8_t* qA, const int8_t* W, const void* sA, const voi
     p.zeros = mixq::zero_page();
     if (!p.zeros) return MIXQ_E_HIP;
     p.M = M, p.N = N, p.K = K;
+    p.dbg = g_dbg_stamps;
     if (O <= kNumOutliers) {
         p.fpA = static_cast<const uint16_t*>(fpA), p.fpW = static_cast<const uint16_t*>(fpW), p.O = O;
         return hip_rc(mixq::launch_gemm(p, mixq::EPI_DEQUANT, st));

@@ -18,6 +18,7 @@ struct GemmParams {
     void* D;              // fp16 [M,N] (EPI_DEQUANT*) or int32 [M,N] (EPI_INT32)
     const void* zeros;    // >= 16 B of device zeros (K / O tails)
     int M, N, K, O;
+    void* dbg;            // measurement only: 8 x uint64 s_memtime stamps per block (ping-pong kernel), else null
 };
 
 hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st);

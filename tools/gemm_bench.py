@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--what", default="both")
     ap.add_argument("--zero", action="store_true", help="zero-filled operands (DVFS ceiling probe)")
+    ap.add_argument("--stamps", action="store_true", help="print the per-tile timeline from in-kernel s_memtime stamps")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.load()
@@ -52,6 +53,8 @@ def main():
     quant()
     gemm()
     torch.cuda.synchronize()
+    if a.stamps:
+        timeline(lib, gemm, M, N, dev)
     for name, fn in (("quant", quant), ("gemm", gemm)):
         if a.what not in (name, "both"):
             continue
@@ -70,6 +73,25 @@ def main():
         else:
             gb = (2.0 * M * K + M * K + 2 * M + 2.0 * M * O) / 1e9
             print(f"quant M={M} K={K}: {ms*1e3:.1f} us  {gb/ms*1e3:.0f} GB/s algorithmic")
+
+
+def timeline(lib, gemm, M, N, dev):
+    import numpy as np
+    nblk = ((M + 255) // 256) * ((N + 255) // 256)
+    buf = torch.zeros(nblk * 8, dtype=torch.int64, device=dev)
+    lib.mixq_debug_set_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
+    gemm()
+    torch.cuda.synchronize()
+    lib.mixq_debug_set_stamp_buffer(None)
+    t = buf.cpu().numpy().reshape(nblk, 8).astype(np.float64)
+    t0 = t[:, 0].min()
+    names = ["prologue", "main loop", "outlier stage", "dequant math", "tile->LDS", "issue stores", "drain stores"]
+    d = np.diff(t, axis=1)
+    print(f"stamps: {nblk} blocks; kernel span {(t[:, 7].max() - t0):.0f} ticks; per-block total mean {(t[:,7]-t[:,0]).mean():.0f}")
+    for i, nme in enumerate(names):
+        print(f"   {nme:14s} mean {d[:, i].mean():9.0f}  min {d[:, i].min():9.0f}  max {d[:, i].max():9.0f} ticks")
+    starts = np.sort(t[:, 0] - t0)
+    print("   block start times (ticks): " + " ".join(f"{starts[int(q * (nblk - 1))]:.0f}" for q in (0, .1, .2, .4, .6, .8, 1.0)))
 
 
 if __name__ == "__main__":
