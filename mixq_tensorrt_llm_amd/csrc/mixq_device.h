@@ -50,16 +50,32 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base)
 //   (int8) __half2int_rn( __hdiv(x, s) )
 // __hdiv = correctly rounded fp16 division = RNE_fp16(fp32 IEEE quotient) (innocuous double rounding);
 // __half2int_rn: RNE, NaN -> 0, +-inf saturate to INT_MAX/INT_MIN; the int8 cast keeps the low 8 bits.
-__device__ __forceinline__ int quant_one(float x, float s)
+__device__ __forceinline__ int half_to_int8_bits(float q)
 {
-    float q = x / s;                    // IEEE-correct fp32 division (hipcc default, no fast-math)
     float qh = (float)((_Float16)q);    // RNE to fp16 (overflow -> inf), back to fp32 exactly
     float r = __builtin_rintf(qh);      // v_rndne_f32
-    // clamp first: (int) of inf/NaN is undefined in C++; every finite fp16 is within +-65504
-    int i = (int)__builtin_fminf(__builtin_fmaxf(r, -65536.f), 65536.f);
-    i = (qh != qh) ? 0 : i;
-    i = (__builtin_isinf(qh)) ? (qh > 0.f ? 0x7fffffff : (int)0x80000000) : i;
+    int i;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(i) : "v"(r)); // hardware semantics: NaN -> 0, out of range saturates
     return i & 0xff;
+}
+
+__device__ __forceinline__ int quant_one(float x, float s)
+{
+    return half_to_int8_bits(x / s);    // IEEE-correct fp32 division (hipcc default, no fast-math)
+}
+
+// Same result as quant_one(x, s) given rs = fl32(1/s), without a division in the common case.
+// q0 = fl32(x * rs) is within 2^-23 relative (< 2 ulp32) of the exact quotient T; RNE_fp16(q0) can differ from
+// RNE_fp16(T) only if an fp16 rounding breakpoint lies between them.  In the normal fp16 range every breakpoint has
+// fp32 mantissa bits [12:0] == 0x1000, so q0 is safe unless its low 13 bits are within +-3 of 0x1000; then the exact
+// division is used.  Below 2^-14 both round to an fp16 < 0.5 -> integer 0 either way; zero / inf / NaN scales give
+// the same inf / NaN patterns as the division (x*inf, 0*inf, x*0).  (Argument in DESIGN.md 2.2.)
+__device__ __forceinline__ int quant_one_fast(float x, float s, float rs)
+{
+    float q0 = x * rs;
+    const unsigned low = (__builtin_bit_cast(unsigned, q0) + 3u - 0x1000u) & 0x1fffu;
+    if (__builtin_expect(low <= 6u, 0)) q0 = x / s;
+    return half_to_int8_bits(q0);
 }
 
 } // namespace mixq

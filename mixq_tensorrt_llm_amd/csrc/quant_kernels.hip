@@ -97,6 +97,7 @@ __global__ __launch_bounds__(QBLOCK) void quant_extract_kernel(uint16_t* __restr
     const uint16_t amax_bits = amax < 0 ? (uint16_t)0x7fffu : (uint16_t)amax;
     const uint16_t s_bits = f2h_bits(h2f(amax_bits) / 127.0f); // __hdiv(max, 127.0)
     const float s = h2f(s_bits);
+    const float rs = 1.0f / s; // IEEE; inf for a zero scale, 0 for an infinite one (same special cases as x / s)
     if (row_ok && t == 0) sA[row] = s_bits;
 
     // ---- quantise: 8 fp16 -> 8 int8 per vector, one 8-byte store per lane ----
@@ -109,8 +110,8 @@ __global__ __launch_bounds__(QBLOCK) void quant_extract_kernel(uint16_t* __restr
             unsigned o[2] = {0u, 0u};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                int q0 = quant_one(h2f((uint16_t)(w[e] & 0xffffu)), s);
-                int q1 = quant_one(h2f((uint16_t)(w[e] >> 16)), s);
+                int q0 = quant_one_fast(h2f((uint16_t)(w[e] & 0xffffu)), s, rs);
+                int q1 = quant_one_fast(h2f((uint16_t)(w[e] >> 16)), s, rs);
                 o[e >> 1] |= (unsigned)(q0 | (q1 << 8)) << ((e & 1) * 16);
             }
             dst[idx] = make_uint2(o[0], o[1]);

@@ -72,6 +72,41 @@ def test_quant_rows_bit_exact(oracle, M, K):
     assert np.array_equal(q2.cpu().numpy(), qo)
 
 
+def test_quant_every_fp16_value_against_many_scales(oracle):
+    """The quantiser multiplies by a per-row reciprocal and falls back to an exact division only near fp16 rounding
+    breakpoints (mixq_device.h: quant_one_fast).  Exhaustive check of that shortcut: every finite fp16 magnitude as x,
+    both signs, against 48 different row maxima (-> 48 scales), bit-exact against the division-based oracle."""
+    from mixq_tensorrt_llm_amd import mixlib
+    allpos = np.arange(0, 0x7c00, dtype=np.uint16).view(np.float16)          # every finite non-negative fp16
+    rng = np.random.default_rng(42)
+    caps = np.concatenate([np.float16([1e-7, 6.1e-5, 1e-3, 0.0999, 1.0, 127.0, 254.0, 333.3, 1000.0, 65504.0]),
+                           np.exp(rng.uniform(np.log(1e-4), np.log(6e4), 38)).astype(np.float16)])
+    K = 32768
+    rows = []
+    for c in caps:
+        v = allpos[allpos <= c]
+        for sign in (1, -1):
+            r = np.zeros(K, np.float16)
+            r[: v.size] = v * np.float16(sign)
+            r[v.size:] = np.resize(v, K - v.size) if v.size else 0      # pad with repeats: keeps amax == c'
+            rows.append(r)
+    A = np.stack(rows)
+    x = to_dev(A)
+    s = torch.empty(A.shape[0], dtype=torch.float16, device=dev())
+    q = mixlib.FindRowScale(x, s, A.shape[0], K, 8).cpu().numpy()
+    qo, so = oracle.quant_rows(A)
+    assert np.array_equal(bits(s.cpu().numpy()), bits(so))
+    bad = np.argwhere(q != qo)
+    assert bad.size == 0, f"{len(bad)} mismatches, first {bad[:3].tolist()}"
+    # the wave-per-row kernels (K <= 8192) use the same shortcut: random rows with many scales
+    B = (rng.standard_normal((512, 4096)) * np.exp(rng.uniform(-6, 6, (512, 1)))).astype(np.float16)
+    xb = to_dev(B)
+    sb = torch.empty(512, dtype=torch.float16, device=dev())
+    qb = mixlib.FindRowScale(xb, sb, 512, 4096, 8).cpu().numpy()
+    qbo, sbo = oracle.quant_rows(B)
+    assert np.array_equal(qb, qbo) and np.array_equal(bits(sb.cpu().numpy()), bits(sbo))
+
+
 @pytest.mark.parametrize("M,K,O", [(7, 512, 128), (40, 4096, 128), (12, 11008, 128), (5, 28672, 128), (9, 1024, 8)])
 def test_fused_quant_extract_both_flavours(oracle, M, K, O):
     from mixq_tensorrt_llm_amd import _lib, mixlib
