@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--tokens", type=int, default=512 * 2048, help="tokens per step per DP replica")
-    ap.add_argument("--chunk", type=int, default=8192, help="M of each operator call")
+    ap.add_argument("--chunk", type=int, default=16384, help="M of each operator call (SURVEY §8: 8192-16384)")
     ap.add_argument("--tp", type=int, default=1, help="rows-of-W sharding degree (1 = pure DP, no collective)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=0, help="GEMM schedule: 0 auto, 1 two-barrier, 2 ping-pong (A/B runs)")
@@ -248,6 +248,13 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     int8_gop_per_token = sum(2.0 * n * k for _, n, k in LLAMA2_7B["linears"]) * LLAMA2_7B["layers"] / 1e9
 
+    traffic = None
+    try:  # PMC-derived HBM-side bytes per GEMM launch, measured for exactly this mix (profiles/pmc_traffic.json)
+        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if t.get("chunk") == chunk and tp == 1 and args.variant == 0:
+            traffic = t["bytes_per_launch"]
+    except Exception:
+        traffic = None
     if rank == 0:
         res = {
             "metric": "prefill_tokens_per_sec", "value": value, "unit": "tokens/s", "n_gpus": world,
@@ -261,7 +268,7 @@ def main():
                        "int8_gop_per_token": int8_gop_per_token},
             "gemm_tops_end_to_end": value * int8_gop_per_token / 1e3 / world,
             "roofline": {"bound": "mfma", "achieved": achieved_tops, "peak": INT8_MFMA_PEAK_TOPS, "unit": "TOP/s",
-                         "frac": achieved_tops / INT8_MFMA_PEAK_TOPS, "traffic": None,
+                         "frac": achieved_tops / INT8_MFMA_PEAK_TOPS, "traffic": traffic,
                          "kernel": "gemm_w8a8o16_kernel<256,256,2,4,0>" if args.variant == 1
                          else "gemm_w8a8o16_pp_kernel<0>",
                          "avg_launch_ms": avg_launch_s * 1e3, "launches": n_launch,

@@ -288,7 +288,8 @@ static hipError_t launch_epi(const GemmParams& p, hipStream_t st)
 }
 
 // Schedule selection.  0 = auto (ping-pong 256x256 kernel when the problem fills the chip with 256x256 tiles, else the
-// 2-barrier kernel in a smaller tile), 1 = always the 2-barrier kernel, 2 = ping-pong whenever M > 4.
+// 2-barrier kernel in a smaller tile), 1 = always the 2-barrier kernel, 2 = ping-pong whenever M > 4,
+// 3 = persistent ping-pong (gemm_pp2_kernels.hip) whenever it applies.
 // Set through mixq_debug_set_gemm_variant() (tests, A/B measurements) or MIXQ_GEMM_VARIANT=v1|pp in the environment.
 static std::atomic<int> g_variant{-1};
 
@@ -311,6 +312,7 @@ hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st)
     const int variant = gemm_variant();
     const int64_t tiles256 = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256);
     if (variant >= 100) return launch_gemm_pp_ablate(p, variant - 100, st); // measurement-only ablations
+    if (variant == 3 && gemm_pp2_supported(p, epi)) return launch_gemm_pp2(p, epi, st);
     if (variant == 2 || (variant == 0 && p.M > 128 && tiles256 >= 96)) return launch_gemm_pp(p, epi, st);
     switch (epi) {
     case EPI_DEQUANT: return launch_epi<EPI_DEQUANT>(p, st);

@@ -23,6 +23,8 @@ struct GemmParams {
 
 hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st);
 hipError_t launch_gemm_pp(const GemmParams& p, int epi, hipStream_t st);  // 256x256 ping-pong schedule
+bool gemm_pp2_supported(const GemmParams& p, int epi);
+hipError_t launch_gemm_pp2(const GemmParams& p, int epi, hipStream_t st); // persistent ping-pong schedule
 hipError_t launch_gemm_pp_ablate(const GemmParams& p, int abl, hipStream_t st);  // timing experiments only
 void set_gemm_variant(int v);
 hipError_t launch_gemm_fp16(const void* fpA, const void* fpW, void* Out, int M, int N, int O, hipStream_t st);

@@ -176,7 +176,7 @@ def variant():
     lib.mixq_debug_set_gemm_variant(0)
 
 
-@pytest.mark.parametrize("which", [1, 2])
+@pytest.mark.parametrize("which", [1, 2, 3])
 @pytest.mark.parametrize("M,N,K", [(5, 16, 16), (33, 144, 272), (129, 256, 384), (256, 512, 128), (300, 768, 640),
                                    (513, 1280, 896), (700, 528, 2064), (1024, 1024, 4096)])
 def test_every_schedule_gives_identical_int32(oracle, variant, which, M, N, K):
@@ -191,10 +191,11 @@ def test_every_schedule_gives_identical_int32(oracle, variant, which, M, N, K):
     assert np.array_equal(got, want)
 
 
-@pytest.mark.parametrize("which", [1, 2])
-def test_every_schedule_full_operator(oracle, variant, which):
+@pytest.mark.parametrize("M,N,K", [(300, 768, 1280), (700, 528, 2112), (520, 1024, 512), (257, 272, 704)])
+@pytest.mark.parametrize("which", [1, 2, 3])
+def test_every_schedule_full_operator(oracle, variant, which, M, N, K):
+    """which = 3 (persistent kernel): ragged M/N, partial last K slice, odd slice counts, several tiles per block."""
     variant(which)
-    M, N, K = 300, 768, 1280
     A, W, act = make_layer(M, N, K, seed=31)
     p = oracle.pack_linear_weights(W, act)
     got = run_enqueue(A, p)
@@ -212,9 +213,21 @@ def test_schedules_agree_bitwise_on_the_full_operator(variant):
     fpw = (torch.randn((N, 128), generator=g) * 0.02).to(torch.float16).to(dev())
     ind = torch.randperm(K, generator=g)[:128].to(torch.int32).to(dev())
     outs = []
-    for which in (1, 2):
+    for which in (1, 2, 3):
         variant(which)
         outs.append(mixlib.mixq_linear(A, W, sW, fpw, ind))
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    # many tiles per persistent block (tile seams, buffer parity flips with an odd slice count)
+    M2, N2, K2 = 4200, 5136, 1152 + 128
+    A2 = torch.randn((M2, K2), generator=g).to(torch.float16).to(dev())
+    W2 = torch.randint(-127, 128, (N2, K2), dtype=torch.int8, generator=g).to(dev())
+    sW2 = (torch.rand(N2, generator=g) * 1e-3 + 1e-4).to(torch.float16).to(dev())
+    fpw2 = (torch.randn((N2, 128), generator=g) * 0.02).to(torch.float16).to(dev())
+    ind2 = torch.randperm(K2, generator=g)[:128].to(torch.int32).to(dev())
+    outs = []
+    for which in (2, 3):
+        variant(which)
+        outs.append(mixlib.mixq_linear(A2, W2, sW2, fpw2, ind2))
     assert torch.equal(outs[0], outs[1])
 
 

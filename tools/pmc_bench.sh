@@ -1,0 +1,22 @@
+#!/usr/bin/env bash
+# HBM traffic of the bench's kernels from PMC counters (separate rocprofv3 passes, kernel-trace only).
+# Writes gpurun_out/pmc_bench/summary.txt: per-kernel mean FETCH_SIZE / WRITE_SIZE (KiB, raw) per dispatch.
+set -u
+OUT="$PWD/gpurun_out/pmc_bench"; rm -rf "$OUT"; mkdir -p "$OUT"
+export TMPDIR=/tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/$c" -o p -- \
+      python "$OLDPWD/bench.py" --tokens 32768 --steps 1 --warmup 0 --no-cpu-baseline ) > "$OUT/$c.log" 2>&1
+done
+python - "$OUT" <<'PY' | tee "$OUT/summary.txt"
+import csv, glob, sys, collections
+d = sys.argv[1]
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    for f in glob.glob(f"{d}/{c}/**/*counter_collection.csv", recursive=True):
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if "mixq::" in r["Kernel_Name"] and r["Counter_Name"] == c:
+                agg[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+        for k, v in sorted(agg.items()):
+            print(f"{c} {k} mean_per_dispatch_KiB {sum(v)/len(v):.1f} n {len(v)}")
+PY
