@@ -50,6 +50,23 @@ def main():
     def gemm():
         assert lib.mixq_gemm_mixed(p(qA), p(W), p(sA), p(sW), p(fpA), p(fpW), p(out), M, N, K, O, st) == 0
 
+    if a.what == "decode":
+        Wq = torch.randint(0, 256, (K, N), dtype=torch.uint8, device=dev, generator=g)
+        for m in (1, 2, 4):
+            x = torch.randn((m, K), device=dev, generator=g).to(torch.float16)
+            o = torch.empty((m, N), dtype=torch.float16, device=dev)
+            fn = lambda: lib.mixq_w8a16_gemm_forward(p(x), p(Wq), p(sW), p(o), m, N, K, st)
+            for _ in range(5):
+                assert fn() == 0
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / a.iters
+            print(f"decode m={m} N={N} K={K}: {ms*1e3:.1f} us  {N*K/ms/1e6:.0f} GB/s (weight bytes)")
+        return
     quant()
     gemm()
     torch.cuda.synchronize()
