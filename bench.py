@@ -101,11 +101,13 @@ def cpu_baseline(seconds_target=15.0):
             oracle.linear_prefill(A, L["W"], L["sW"], L["fpW"], L["ind"])
         return time.perf_counter() - t0
 
-    probe_m = 16
-    t = run(probe_m)
-    M = int(max(16, min(4096, probe_m * seconds_target / max(t, 1e-3))))
-    M -= M % 16
-    t = run(M)
+    M, t = 64, 0.0
+    for _ in range(4):  # grow the sample until it costs ~10-30 s of CPU work (small M under-uses the threads)
+        t = run(M)
+        if t >= 0.6 * seconds_target or M >= 16384:
+            break
+        M = int(min(16384, max(M * 2, M * seconds_target / max(t, 1e-3))))
+        M -= M % 16
     tok_s = M / (t * LLAMA2_7B["layers"])
     return {"value": tok_s, "unit": "tokens/s", "cores": oracle.num_threads(), "kind": "port",
             "sample": f"oracle.linear_prefill on 1 of 32 Llama-2-7B layers (qkv+gate+proj), M={M} tokens, "
