@@ -138,6 +138,14 @@ MIXQ_API int mixq_quant_extract(int M, int K, void* A_f16, int8_t* qA, void* sA_
  * caller-supplied per-row fp16 scale. */
 MIXQ_API int mixq_int8_quantize_with_scale(int rows, int cols, const void* src_f16, const void* scale_f16,
                                            int8_t* output, void* stream);
+/* SURVEY §8f row 1 -- the producer in front of the operator (P-flavour fused norm):
+ * layernorm_forward_cuda (quantkernel/mix_cuda/layernorm/layernorm.cu:100-117): out = fp16(clamp((x*rstd)*gamma)), T5-style RMSNorm. */
+MIXQ_API int mixq_rmsnorm(int M, int K, const void* x_f16, const void* gamma_f16, void* out_f16, float eps, void* stream);
+/* layernorm_forward_cuda_extract_outliers (layernorm.cu:122-198, 316-346): RMSNorm, then outliers[m,j] = out[m,ind[j]],
+ * those columns zeroed in `out`, then per-row scale + int8 quantisation of the zeroed row -- one pass over x. */
+MIXQ_API int mixq_rmsnorm_extract_quant(int M, int K, const void* x_f16, const void* gamma_f16, void* out_f16, float eps,
+                                        const int32_t* ind, int len, void* outliers_f16, int8_t* q, void* scale_f16,
+                                        void* stream);
 /* int8FusedDequantizeCUDA (kernel/i8gemm.cu:151-194): D = fp16(float(A.B^T) * (scale_col[n]*scale_row[m]) + y).
  * A int8 [M,K], B int8 [N,K], scale_row fp16 [M], scale_col fp16 [N], y/D fp16 [M,N] (y may alias D, may be NULL = 0).
  * `workspace` is unused (kept for signature parity). */

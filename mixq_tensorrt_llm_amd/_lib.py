@@ -84,6 +84,8 @@ SIGNATURES = {
     "mixq_extract_outliers_set_zero": (_i, [_i, _i, _vp, _vp, _vp, _i, _vp]),
     "mixq_quant_extract": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "mixq_int8_quantize_with_scale": (_i, [_i, _i, _vp, _vp, _vp, _vp]),
+    "mixq_rmsnorm": (_i, [_i, _i, _vp, _vp, _vp, ctypes.c_float, _vp]),
+    "mixq_rmsnorm_extract_quant": (_i, [_i, _i, _vp, _vp, _vp, ctypes.c_float, _vp, _i, _vp, _vp, _vp, _vp]),
     "mixq_int8_fused_dequantize": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "mixq_int8_fused_dequantize_silu": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "mixq_gemm_mixed": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -292,6 +292,26 @@ int mixq_int8_quantize_with_scale(int rows, int cols, const void* src, const voi
     return hip_rc(mixq::launch_quant_with_scale(src, scale, output, rows, cols, static_cast<hipStream_t>(stream)));
 }
 
+int mixq_rmsnorm(int M, int K, const void* x, const void* gamma, void* out, float eps, void* stream)
+{
+    if (M < 0 || K <= 0 || (M > 0 && (!x || !gamma || !out))) return MIXQ_E_BADARG;
+    if (K % 8 || K > 32768) return MIXQ_E_SHAPE;
+    if (!aligned16(x) || !aligned16(gamma) || !aligned16(out)) return MIXQ_E_ALIGN;
+    return hip_rc(mixq::launch_rmsnorm_quant(x, gamma, out, nullptr, nullptr, nullptr, nullptr, eps, M, K, 0, false,
+                                             static_cast<hipStream_t>(stream)));
+}
+
+int mixq_rmsnorm_extract_quant(int M, int K, const void* x, const void* gamma, void* out, float eps, const int32_t* ind,
+                               int len, void* outliers, int8_t* q, void* scale, void* stream)
+{
+    if (M < 0 || K <= 0 || len < 0 || (M > 0 && (!x || !gamma || !out || !q || !scale))) return MIXQ_E_BADARG;
+    if (len > 0 && (!ind || !outliers)) return MIXQ_E_BADARG;
+    if (K % 8 || K > 32768) return MIXQ_E_SHAPE;
+    if (!aligned16(x) || !aligned16(gamma) || !aligned16(out) || (reinterpret_cast<uintptr_t>(q) & 7u)) return MIXQ_E_ALIGN;
+    return hip_rc(mixq::launch_rmsnorm_quant(x, gamma, out, outliers, ind, q, scale, eps, M, K, len, true,
+                                             static_cast<hipStream_t>(stream)));
+}
+
 static int fused_dequant_impl(const int8_t* A, const int8_t* B, const void* scale_row, const void* scale_col,
                               const void* y, void* D, int M, int N, int K, int epi, void* stream)
 {

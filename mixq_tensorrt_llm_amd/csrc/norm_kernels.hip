@@ -1,0 +1,210 @@
+// Fused RMSNorm -> outlier extraction -> per-token int8 quantisation for gfx950 (the producer on
+// the input side of the MixQ linear; removes one full pass over the activations compared with norm + quant).
+//
+// Replaces (reference, CUDA): quantkernel/mix_cuda/layernorm/layernorm.cu:122-198 generalT5LayerNorm_extract_outliers
+// and :41-98 generalT5LayerNorm (mixlib ops layernorm_forward_cuda_extract_outliers / layernorm_forward_cuda):
+//   rstd = rsqrt( sum x^2 / n + eps )                  fp32
+//   out  = fp16( clamp( (x * rstd) * gamma, +-64504 ) )
+//   outliers[j] = out[ind[j]] ; out[ind[j]] = 0        (P-flavour: outliers leave the int8 path)
+//   scale = fp16(amax/127) ; q = int8(rn(out/scale))   same arithmetic as the stand-alone quantiser
+//
+// One wavefront (K <= 8192) or one 256-thread block (K <= 32768) owns a row and keeps it in registers: x is read once
+// (16-byte loads), out / q / outliers / scale are written once.  The normalised row passes through LDS only so that
+// the <= 128 outlier values can be picked by column index; the outlier columns are zeroed through a K-bit mask.
+#include "mixq_device.h"
+#include "mixq_launch.h"
+
+namespace mixq {
+
+constexpr int NBLOCK = 256;
+
+template <int TPR, int MAXV, bool QUANT>
+__global__ __launch_bounds__(NBLOCK) void rmsnorm_quant_kernel(const uint16_t* __restrict__ X,
+                                                               const uint16_t* __restrict__ gamma,
+                                                               uint16_t* __restrict__ out, uint16_t* __restrict__ outl,
+                                                               const int32_t* __restrict__ ind, int8_t* __restrict__ q,
+                                                               uint16_t* __restrict__ scale, float eps, int M, int K,
+                                                               int O)
+{
+    constexpr int RPB = NBLOCK / TPR;
+    __shared__ float redf[NBLOCK / 64];
+    __shared__ int redi[NBLOCK / 64];
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[]; // [mask: K bits, 16-B padded][RPB rows x K fp16]
+    const int tid = threadIdx.x;
+    const int t = tid % TPR;
+    const int rslot = tid / TPR;
+    const int64_t row = (int64_t)blockIdx.x * RPB + rslot;
+    const bool row_ok = row < M;
+    const int nvec = K >> 3;
+    const int mask_bytes = ((K + 127) / 128) * 16;
+    unsigned* zmask = reinterpret_cast<unsigned*>(dyn);
+    uint16_t* lrow = reinterpret_cast<uint16_t*>(dyn + mask_bytes) + (size_t)rslot * K;
+
+    if (QUANT) {
+        for (int i = tid; i < mask_bytes / 4; i += NBLOCK) zmask[i] = 0u;
+        __syncthreads();
+        for (int j = tid; j < O; j += NBLOCK) {
+            const int c = ind[j];
+            if (c >= 0 && c < K) atomicOr(zmask + (c >> 5), 1u << (c & 31));
+        }
+        __syncthreads();
+    }
+
+    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(X + (row_ok ? row : 0) * (int64_t)K);
+    uint4 x[MAXV];
+    float ss = 0.f;
+#pragma unroll
+    for (int v = 0; v < MAXV; ++v) {
+        const int idx = v * TPR + t;
+        x[v] = (row_ok && idx < nvec) ? src[idx] : make_uint4(0u, 0u, 0u, 0u);
+        const unsigned w[4] = {x[v].x, x[v].y, x[v].z, x[v].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a = h2f((uint16_t)(w[e] & 0xffffu)), b = h2f((uint16_t)(w[e] >> 16));
+            ss = __builtin_fmaf(a, a, ss);
+            ss = __builtin_fmaf(b, b, ss);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    if (TPR > 64) {
+        if ((tid & 63) == 0) redf[tid >> 6] = ss;
+        __syncthreads();
+        ss = (redf[0] + redf[1]) + (redf[2] + redf[3]);
+    }
+    const float rstd = 1.0f / __builtin_sqrtf(ss / (float)K + eps);
+
+    // normalise in place (registers now hold the fp16 result), stage the row in LDS for the gather
+    const uint4* __restrict__ g4 = reinterpret_cast<const uint4*>(gamma);
+    int amax = -1;
+#pragma unroll
+    for (int v = 0; v < MAXV; ++v) {
+        const int idx = v * TPR + t;
+        if (idx < nvec) {
+            const uint4 gv = g4[idx];
+            const unsigned w[4] = {x[v].x, x[v].y, x[v].z, x[v].w};
+            const unsigned gw[4] = {gv.x, gv.y, gv.z, gv.w};
+            unsigned o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = (h2f((uint16_t)(w[e] & 0xffffu)) * rstd) * h2f((uint16_t)(gw[e] & 0xffffu));
+                float b = (h2f((uint16_t)(w[e] >> 16)) * rstd) * h2f((uint16_t)(gw[e] >> 16));
+                a = a > 0.f ? __builtin_fminf(a, 64504.f) : __builtin_fmaxf(a, -64504.f);
+                b = b > 0.f ? __builtin_fminf(b, 64504.f) : __builtin_fmaxf(b, -64504.f);
+                o[e] = (unsigned)f2h_bits_of_f32_result(a) | ((unsigned)f2h_bits_of_f32_result(b) << 16);
+            }
+            x[v] = make_uint4(o[0], o[1], o[2], o[3]);
+            if (QUANT) reinterpret_cast<uint4*>(lrow)[idx] = x[v];
+        }
+    }
+    if (QUANT) {
+        if (TPR > 64) __syncthreads(); // the whole row is in LDS (one wave per row needs no barrier: LDS ops are in order)
+        if (row_ok)
+            for (int j = t; j < O; j += TPR) {
+                const int c = ind[j];
+                outl[row * (int64_t)O + j] = (c >= 0 && c < K) ? lrow[c] : (uint16_t)0;
+            }
+#pragma unroll
+        for (int v = 0; v < MAXV; ++v) {
+            const int idx = v * TPR + t;
+            if (idx < nvec) {
+                const unsigned m8 = (zmask[idx >> 2] >> ((idx & 3) * 8)) & 0xffu;
+                unsigned w[4] = {x[v].x, x[v].y, x[v].z, x[v].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (m8 & (1u << (2 * e))) w[e] &= 0xffff0000u;
+                    if (m8 & (2u << (2 * e))) w[e] &= 0x0000ffffu;
+                    int lo = (int)(w[e] & 0x7fffu), hi = (int)((w[e] >> 16) & 0x7fffu);
+                    lo = lo > 0x7c00 ? -1 : lo;
+                    hi = hi > 0x7c00 ? -1 : hi;
+                    amax = max(amax, max(lo, hi));
+                }
+                x[v] = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        }
+    }
+    // the normalised row (outlier columns zeroed when quantising), one 16-byte store per vector
+    uint4* __restrict__ dsto = reinterpret_cast<uint4*>(out + (row_ok ? row : 0) * (int64_t)K);
+#pragma unroll
+    for (int v = 0; v < MAXV; ++v) {
+        const int idx = v * TPR + t;
+        if (row_ok && idx < nvec) dsto[idx] = x[v];
+    }
+    if (!QUANT) return;
+
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) amax = max(amax, __shfl_xor(amax, off, 64));
+    if (TPR > 64) {
+        if ((tid & 63) == 0) redi[tid >> 6] = amax;
+        __syncthreads();
+        amax = max(max(redi[0], redi[1]), max(redi[2], redi[3]));
+    }
+    const uint16_t amax_bits = amax < 0 ? (uint16_t)0x7fffu : (uint16_t)amax;
+    const uint16_t s_bits = f2h_bits(h2f(amax_bits) / 127.0f);
+    const float s = h2f(s_bits);
+    const float rs = 1.0f / s;
+    if (row_ok && t == 0) scale[row] = s_bits;
+    uint2* __restrict__ dstq = reinterpret_cast<uint2*>(q + (row_ok ? row : 0) * (int64_t)K);
+#pragma unroll
+    for (int v = 0; v < MAXV; ++v) {
+        const int idx = v * TPR + t;
+        if (row_ok && idx < nvec) {
+            const unsigned w[4] = {x[v].x, x[v].y, x[v].z, x[v].w};
+            unsigned o[2] = {0u, 0u};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int q0 = quant_one_fast(h2f((uint16_t)(w[e] & 0xffffu)), s, rs);
+                const int q1 = quant_one_fast(h2f((uint16_t)(w[e] >> 16)), s, rs);
+                o[e >> 1] |= (unsigned)(q0 | (q1 << 8)) << ((e & 1) * 16);
+            }
+            dstq[idx] = make_uint2(o[0], o[1]);
+        }
+    }
+}
+
+template <int TPR, int MAXV>
+static hipError_t launch_norm(const uint16_t* X, const uint16_t* gamma, uint16_t* out, uint16_t* outl,
+                              const int32_t* ind, int8_t* q, uint16_t* scale, float eps, int M, int K, int O,
+                              bool quant, hipStream_t st)
+{
+    constexpr int RPB = NBLOCK / TPR;
+    const dim3 grid((unsigned)((M + RPB - 1) / RPB)), block(NBLOCK);
+    if (quant) {
+        const size_t lds = (size_t)((K + 127) / 128) * 16 + (size_t)RPB * K * 2;
+        static bool attr_done = false; // rows of 8192 x 4 waves need more than the default 64 KiB of dynamic LDS
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rmsnorm_quant_kernel<TPR, MAXV, true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+            if (e != hipSuccess) return e;
+            attr_done = true;
+        }
+        hipLaunchKernelGGL((rmsnorm_quant_kernel<TPR, MAXV, true>), grid, block, lds, st, X, gamma, out, outl, ind, q,
+                           scale, eps, M, K, O);
+    } else {
+        hipLaunchKernelGGL((rmsnorm_quant_kernel<TPR, MAXV, false>), grid, block, 0, st, X, gamma, out, outl, ind, q,
+                           scale, eps, M, K, O);
+    }
+    return hipGetLastError();
+}
+
+// quant = false: plain RMSNorm (only `out`).  Returns hipErrorInvalidValue for rows longer than 32768 elements.
+hipError_t launch_rmsnorm_quant(const void* X, const void* gamma, void* out, void* outl, const int32_t* ind, int8_t* q,
+                                void* scale, float eps, int M, int K, int O, bool quant, hipStream_t st)
+{
+    if (M <= 0) return hipSuccess;
+    const uint16_t* x = static_cast<const uint16_t*>(X);
+    const uint16_t* g = static_cast<const uint16_t*>(gamma);
+    uint16_t* o = static_cast<uint16_t*>(out);
+    uint16_t* ol = static_cast<uint16_t*>(outl);
+    uint16_t* sc = static_cast<uint16_t*>(scale);
+    const int nvec = K / 8;
+    if (nvec <= 64 * 2) return launch_norm<64, 2>(x, g, o, ol, ind, q, sc, eps, M, K, O, quant, st);
+    if (nvec <= 64 * 4) return launch_norm<64, 4>(x, g, o, ol, ind, q, sc, eps, M, K, O, quant, st);
+    if (nvec <= 64 * 8) return launch_norm<64, 8>(x, g, o, ol, ind, q, sc, eps, M, K, O, quant, st);
+    if (nvec <= 64 * 16) return launch_norm<64, 16>(x, g, o, ol, ind, q, sc, eps, M, K, O, quant, st);
+    if (nvec <= 256 * 8) return launch_norm<256, 8>(x, g, o, ol, ind, q, sc, eps, M, K, O, quant, st);
+    if (nvec <= 256 * 16) return launch_norm<256, 16>(x, g, o, ol, ind, q, sc, eps, M, K, O, quant, st);
+    return hipErrorInvalidValue;
+}
+
+} // namespace mixq

@@ -11,7 +11,8 @@ import torch
 from . import _lib
 
 __all__ = ["FindRowScale", "ExtractOutliersAndSetToZeros", "int8FusedDequantize", "int8FusedDequantizeSilu", "gemm",
-           "dequantizeInt8", "Int8quantize", "FindRowScaleFusedExtracOutliers", "int_to_half", "int_matrix_to_half",
+           "dequantizeInt8", "Int8quantize", "FindRowScaleFusedExtracOutliers", "layernorm_forward_cuda",
+           "layernorm_forward_cuda_extract_outliers", "int_to_half", "int_matrix_to_half",
            "int8_matrix_to_half", "w8_a16_gemm", "preprocess_weights", "mixq_linear"]
 
 
@@ -105,6 +106,30 @@ def FindRowScaleFusedExtracOutliers(x, scaleRow, ind, len_ind, rows, cols):
                                               _p(ind) if len_ind else None, len_ind, 1, _st(x)),
                "FindRowScaleFusedExtracOutliers")
     return [q, outl]
+
+
+def layernorm_forward_cuda(_input, _gamma, _out, eps):
+    """layernorm.cu:100-117: T5-style RMSNorm of _input [b, n, c] (or [m, c]) into _out."""
+    _dev(_input, _gamma, _out)
+    c = _input.shape[-1]
+    m = _input.numel() // c
+    _lib.check(_lib.load().mixq_rmsnorm(m, c, _p(_input), _p(_gamma), _p(_out), ctypes.c_float(eps), _st(_input)),
+               "layernorm_forward_cuda")
+
+
+def layernorm_forward_cuda_extract_outliers(_input, _gamma, _out, eps, _ind, scaleRow):
+    """layernorm.cu:316-346: fused RMSNorm -> extract(+zero) outliers -> per-row int8 quantisation.
+    Fills _out (normalised, outlier columns zeroed) and scaleRow; returns [outliers fp16 [m,len], quant int8 [m,c]]."""
+    _dev(_input, _gamma, _out, _ind, scaleRow)
+    c = _input.shape[-1]
+    m = _input.numel() // c
+    n = _ind.shape[0]
+    outl = torch.zeros((m, n), dtype=torch.float16, device=_input.device)
+    q = torch.empty((m, c), dtype=torch.int8, device=_input.device)
+    _lib.check(_lib.load().mixq_rmsnorm_extract_quant(m, c, _p(_input), _p(_gamma), _p(_out), ctypes.c_float(eps),
+                                                      _p(_ind), n, _p(outl), _p(q), _p(scaleRow), _st(_input)),
+               "layernorm_forward_cuda_extract_outliers")
+    return [outl, q]
 
 
 def int_to_half(int_ind):

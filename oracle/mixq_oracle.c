@@ -476,3 +476,39 @@ ORACLE_API int mixq_oracle_num_threads(void)
     return 1;
 #endif
 }
+
+/* ------------------- next row f1: fused RMSNorm -> extract -> quantise ------------------ */
+/*
+ * quantkernel/mix_cuda/layernorm/layernorm.cu:122-198 generalT5LayerNorm_extract_outliers (T5 style: no mean, no bias):
+ *   rstd    = rsqrtf( sum_k x^2 / n + eps )                         (fp32; block-reduce order unspecified)
+ *   out[k]  = clamp_inf_for_half( (x[k]*rstd) * gamma[k] )          (reduction.cuh:105-115: clamp to +-64504, RNE fp16)
+ *   outliers[j] = out[ind[j]] ; out[ind[j]] = 0                     (:155-161, P-flavour zeroing)
+ *   amax/scale/quant of the zeroed row exactly as FindRowScaleKernel (:163-196)
+ * The sum is accumulated in double here (the "ideal" value of an order-unspecified fp32 reduction); CUDA's rsqrtf is an
+ * approximation too, so `out` is compared with a 1-ulp (1e-3) tolerance, not bit for bit.
+ * gamma == NULL: plain RMSNorm (layernorm_forward_cuda, :100-117): only `out` is produced.
+ */
+ORACLE_API void mixq_oracle_rmsnorm_extract_quant(int64_t M, int64_t K, const uint16_t* x, const uint16_t* gamma,
+                                                  float eps, const int32_t* ind, int len, uint16_t* out,
+                                                  uint16_t* outliers, int8_t* q, uint16_t* scale)
+{
+    for (int64_t m = 0; m < M; ++m) {
+        const uint16_t* row = x + m * K;
+        double ss = 0.0;
+        for (int64_t k = 0; k < K; ++k) {
+            double v = (double)h2f(row[k]);
+            ss += v * v;
+        }
+        float rstd = (float)(1.0 / sqrt(ss / (double)K + (double)eps));
+        uint16_t* o = out + m * K;
+        for (int64_t k = 0; k < K; ++k) {
+            float v = (h2f(row[k]) * rstd) * h2f(gamma[k]);
+            v = v > 0.0f ? fminf(v, 65504.0f - 1000.0f) : fmaxf(v, -65504.0f + 1000.0f);
+            o[k] = f2h(v);
+        }
+        if (q == NULL) continue;
+        for (int j = 0; j < len; ++j) outliers[m * len + j] = o[ind[j]];
+        for (int j = 0; j < len; ++j) o[ind[j]] = 0;
+        mixq_oracle_quant_rows(1, K, o, q + m * K, scale + m, NULL, 0);
+    }
+}

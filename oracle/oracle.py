@@ -16,7 +16,7 @@ __all__ = [
     "build", "lib", "num_threads", "quant_rows", "extract_outliers", "gemm_s8s8s32", "gemm_fp16",
     "dequant_epilogue", "dequantization", "linear_prefill", "weight_scales", "quantize_weight",
     "select_outliers", "pack_linear_weights", "eetq_symmetric_quantize", "eetq_preprocess", "w8a16_gemv",
-    "int_to_half", "int8_matrix_to_half",
+    "int_to_half", "int8_matrix_to_half", "rmsnorm_extract_quant",
 ]
 
 
@@ -228,3 +228,22 @@ def pack_linear_weights(W, act_scale, num_outliers=128):
         weight_as_half=int8_matrix_to_half(Wq), fp_ind_as_half=int_to_half(ind),
         qweight_as_half=int8_matrix_to_half(qweight),
     )
+
+
+def rmsnorm_extract_quant(x, gamma, eps, ind=None):
+    """layernorm.cu:122-198 (ind given) / :100-117 (ind None).  Returns out fp16 [M,K] (outlier columns zeroed),
+    and with ind: outliers fp16 [M,len], q int8 [M,K], scale fp16 [M]."""
+    x, gamma = _h(x), _h(gamma).reshape(-1)
+    M, K = x.shape
+    out = np.empty((M, K), np.float16)
+    if ind is None:
+        lib().mixq_oracle_rmsnorm_extract_quant(_i64(M), _i64(K), _p(x), _p(gamma), ctypes.c_float(eps), None,
+                                                ctypes.c_int(0), _p(out), None, None, None)
+        return out
+    ind = np.ascontiguousarray(ind, np.int32)
+    outl = np.empty((M, ind.size), np.float16)
+    q = np.empty((M, K), np.int8)
+    sc = np.empty((M,), np.float16)
+    lib().mixq_oracle_rmsnorm_extract_quant(_i64(M), _i64(K), _p(x), _p(gamma), ctypes.c_float(eps), _p(ind),
+                                            ctypes.c_int(ind.size), _p(out), _p(outl), _p(q), _p(sc))
+    return out, outl, q, sc
