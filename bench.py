@@ -123,6 +123,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=16384, help="M of each operator call (SURVEY §8: 8192-16384)")
     ap.add_argument("--tp", type=int, default=1, help="rows-of-W sharding degree (1 = pure DP, no collective)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tp-leg", action="store_true", help="skip the informational TP (row-sharded W) leg at N > 1")
+    ap.add_argument("--force-tp-leg", action="store_true", help="run the TP leg even at N = 1 (code-path check)")
     ap.add_argument("--variant", type=int, default=0, help="GEMM schedule: 0 auto, 1 two-barrier, 2 ping-pong (A/B runs)")
     args = ap.parse_args()
 
@@ -133,8 +135,9 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the MixQ operator has no CPU path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.force_tp_leg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     tp = args.tp
     assert world % tp == 0
@@ -257,6 +260,7 @@ def main():
             traffic = t["bytes_per_launch"]
     except Exception:
         traffic = None
+    res = None
     if rank == 0:
         res = {
             "metric": "prefill_tokens_per_sec", "value": value, "unit": "tokens/s", "n_gpus": world,
@@ -283,10 +287,107 @@ def main():
             except Exception as e:  # the checker failing must not hide the measurement
                 res["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {e}"}
-        print(json.dumps(res), flush=True)
-    if world > 1:
+    # ---- N > 1, DP run: an extra, UNTIMED-for-`value` leg that exercises the north-star TP layout on the same GPUs
+    # (rows of W sharded `world` ways + one RCCL all-gather of the fp16 output) and reports what xGMI delivers.
+    # A watchdog prints the main result and exits if the collective does not come back.
+    if (world > 1 or args.force_tp_leg) and tp == 1 and not args.no_tp_leg:
+        import threading
+
+        def bail():
+            if rank == 0:
+                res["tp_leg"] = {"error": "watchdog: TP leg did not finish in 120 s"}
+                print(json.dumps(res), flush=True)
+            os._exit(0)
+
+        wd = threading.Timer(120.0, bail)
+        wd.daemon = True
+        wd.start()
+        try:
+            leg = tp_leg(lib, hip, parallel, TensorDesc, dev, rank, world, chunk, gen, st_ptr, stream)
+            if rank == 0:
+                res["tp_leg"] = leg
+        except Exception as e:  # noqa: BLE001 -- the main measurement must survive
+            if rank == 0:
+                res["tp_leg"] = {"error": repr(e)}
+        wd.cancel()
+    if world > 1 or args.force_tp_leg:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        try:  # RCCL prints its version banner through C stdio; flush it so that the JSON line is the last line
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(res), flush=True)
+
+
+def tp_leg(lib, hip, parallel, TensorDesc, dev, rank, world, chunk, gen, st_ptr, stream, iters=10):
+    """One Llama-2-7B layer (qkv, gate, proj) with W row-sharded over all ranks: per call enqueue on the shard, then one
+    all_gather of the [chunk, N/world] fp16 output.  Reports compute-only, gather-only and overlapped times."""
+    tp = world
+    calls, keep, outs = [], [], []
+    max_ws = 0
+    for name, N, K in LLAMA2_7B["linears"]:
+        n0, n1 = parallel.shard_bounds(N, tp, rank)
+        t = synth_layer(N, K, dev, gen, n0, n1)
+        A = synth_activation(chunk, K, t["ind_i32"], dev, gen)
+        out = torch.empty((chunk, n1 - n0), dtype=torch.float16, device=dev)
+        ins = [A, t["weight"], t["weights_scaling_factor"], t["fp_weight"], t["fp_ind"], t["qweight"],
+               t["weights_scaling_factor"]]
+        in_desc = (TensorDesc * 7)(*[TensorDesc.make(x.shape) for x in ins])
+        out_desc = TensorDesc.make(out.shape)
+        in_ptrs = (ctypes.c_void_p * 7)(*[x.data_ptr() for x in ins])
+        out_ptrs = (ctypes.c_void_p * 1)(out.data_ptr())
+        h = lib.mixq_create(chunk, n1 - n0, K)
+        max_ws = max(max_ws, lib.mixq_workspace_size(h, chunk, n1 - n0, K))
+        calls.append((ctypes.c_void_p(h), in_desc, out_desc, in_ptrs, out_ptrs))
+        keep.append((t, ins))
+        outs.append(out)
+    ws = torch.empty(max_ws, dtype=torch.uint8, device=dev)
+    ws_ptr = ctypes.c_void_p(ws.data_ptr())
+    gath = [torch.empty((world * chunk, o.shape[1]), dtype=torch.float16, device=dev) for o in outs]
+    comm = torch.cuda.Stream(dev)
+
+    def compute():
+        for (h, in_desc, out_desc, in_ptrs, out_ptrs) in calls:
+            rc = lib.mixq_enqueue(h, in_desc, ctypes.byref(out_desc), in_ptrs, out_ptrs, ws_ptr, st_ptr)
+            assert rc == 0
+
+    def gather():
+        for o, g in zip(outs, gath):
+            dist.all_gather_into_tensor(g, o)
+
+    def both():  # gather of call i overlaps the GEMM of call i+1 (side stream)
+        for (h, in_desc, out_desc, in_ptrs, out_ptrs), o, g in zip(calls, outs, gath):
+            rc = lib.mixq_enqueue(h, in_desc, ctypes.byref(out_desc), in_ptrs, out_ptrs, ws_ptr, st_ptr)
+            assert rc == 0
+            comm.wait_stream(stream)
+            with torch.cuda.stream(comm):
+                dist.all_gather_into_tensor(g, o)
+        stream.wait_stream(comm)
+
+    def timed(fn):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        t = torch.tensor([(time.perf_counter() - t0) / iters], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    t_c, t_g, t_b = timed(compute), timed(gather), timed(both)
+    recv_bytes = sum((world - 1) * chunk * o.shape[1] * 2 for o in outs)  # bytes each GPU receives per layer pass
+    return {"tp": tp, "layer_ms": {"compute_only": t_c * 1e3, "allgather_only": t_g * 1e3, "overlapped": t_b * 1e3},
+            "allgather_recv_GBps_per_gpu": recv_bytes / t_g / 1e9,
+            "tokens_per_s_if_all_32_layers": chunk / (t_b * LLAMA2_7B["layers"]),
+            "note": "untimed for `value`: rows of W sharded over all ranks + one RCCL all-gather of each fp16 output"}
+
+
 
 
 if __name__ == "__main__":
