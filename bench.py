@@ -133,6 +133,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the MixQ operator has no CPU path)"
+    if rank != 0:  # only rank 0 talks on stdout (library banners of the other ranks go to stderr)
+        os.dup2(2, 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or args.force_tp_leg:
@@ -319,6 +321,11 @@ def main():
         except Exception:
             pass
         print(json.dumps(res), flush=True)
+    try:  # anything a library prints at exit (RCCL banner) must not follow the JSON line on stdout
+        sys.stdout.flush()
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
+    except Exception:
+        pass
 
 
 def tp_leg(lib, hip, parallel, TensorDesc, dev, rank, world, chunk, gen, st_ptr, stream, iters=10):
