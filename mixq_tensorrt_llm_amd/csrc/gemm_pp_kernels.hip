@@ -365,21 +365,29 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
                 yh[0] = (uint16_t)(yb.x & 0xffffu), yh[1] = (uint16_t)(yb.x >> 16);
                 yh[2] = (uint16_t)(yb.y & 0xffffu), yh[3] = (uint16_t)(yb.y >> 16);
             }
-            uint16_t oh[4];
+            unsigned ow[2];
 #pragma unroll
             for (int e2 = 0; e2 < 4; e2 += 2) {
                 const v2f s2 = v2f{swf[e2], swf[e2 + 1]} * sa[j]; // exact: fp16 x fp16 products
-#pragma unroll
-                for (int e = e2; e < e2 + 2; ++e) {
-                    // addend: the fp16-rounded outlier product (cuBLAS writes fp16) or the caller's y
-                    const float c = HAS_O ? h2f(f2h_bits_of_f32_result(P[4 * g + e])) : h2f(yh[e]);
-                    float v = __builtin_fmaf((float)acc[i][j][4 * g + e], s2[e - e2], c);
-                    if (EPI == EPI_DEQUANT_SILU) v = v / (1.f + __expf(-v));
-                    oh[e] = f2h_bits_of_f32_result(v);
+                // addend pair: the fp16-rounded outlier products (cuBLAS writes fp16) or the caller's y
+                v2f c2;
+                if (HAS_O) {
+                    const v2h p16 = f2h2_of_f32_results(P[4 * g + e2], P[4 * g + e2 + 1]);
+                    c2 = v2f{(float)p16[0], (float)p16[1]};
+                } else {
+                    c2 = v2f{h2f(yh[e2]), h2f(yh[e2 + 1])};
                 }
+                float v0 = __builtin_fmaf((float)acc[i][j][4 * g + e2], s2[0], c2[0]);
+                float v1 = __builtin_fmaf((float)acc[i][j][4 * g + e2 + 1], s2[1], c2[1]);
+                if (EPI == EPI_DEQUANT_SILU) {
+                    v0 = v0 / (1.f + __expf(-v0));
+                    v1 = v1 / (1.f + __expf(-v1));
+                }
+                const v2h o16 = f2h2_of_f32_results(v0, v1);
+                __builtin_memcpy(&ow[e2 >> 1], &o16, 4);
             }
-            outp[i][j][g].x = (unsigned)oh[0] | ((unsigned)oh[1] << 16);
-            outp[i][j][g].y = (unsigned)oh[2] | ((unsigned)oh[3] << 16);
+            outp[i][j][g].x = ow[0];
+            outp[i][j][g].y = ow[1];
         }
     };
     // software pipeline over the 8 tiles: the MFMA chain of tile t+1 runs under the VALU work of tile t

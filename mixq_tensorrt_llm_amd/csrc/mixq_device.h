@@ -39,6 +39,14 @@ __device__ __forceinline__ uint16_t f2h_bits_of_f32_result(float f)
     return f2h_bits(f);
 }
 
+// Two fp32 results -> packed fp16 (RNE), both pinned first (same reason); one v_cvt_pk_f16_f32.
+__device__ __forceinline__ v2h f2h2_of_f32_results(float a, float b)
+{
+    asm("" : "+v"(a), "+v"(b));
+    typedef float v2f_ __attribute__((ext_vector_type(2)));
+    return __builtin_convertvector(v2f_{a, b}, v2h);
+}
+
 // 16-byte async copy global -> LDS.  LDS destination = wave-uniform base + lane*16 (hardware rule); the
 // per-lane part lives entirely in the global source address.
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base)
