@@ -49,14 +49,25 @@ def eetq_quant_weights(Wt: torch.Tensor):
     return out, col_max.to(torch.float16), q
 
 
-def pack_linear_weights(W: torch.Tensor, act_scales: torch.Tensor, num_outliers: int = NUM_OUTLIERS) -> dict:
-    """One layer of model_config_utils.py:421-466.  Returns numpy arrays keyed like the checkpoint tensors."""
+def pack_linear_weights(W: torch.Tensor, act_scales: torch.Tensor, num_outliers: int = NUM_OUTLIERS,
+                        outlier_weights: str = "fp16") -> dict:
+    """One layer of model_config_utils.py:421-466.  Returns numpy arrays keyed like the checkpoint tensors.
+
+    outlier_weights = "fp16": the reference's T-flavour (fp_weight = original fp16 columns, :452).
+    outlier_weights = "int8": the P-flavour / fpA_intB mode of BASELINE config 4 -- fp_weight = dequantised int8 columns
+    ``q_weight[:, ind] * scale_col`` (MixQ/src/mixquant/modules/linear.py:204), so the outlier path carries exactly the
+    information the int8 weights have."""
     assert W.dtype == torch.float16 and W.dim() == 2
+    assert outlier_weights in ("fp16", "int8")
     W = W.cpu().clone()
     sW = weight_scales(W)                                     # :429-430
     qweight, eetq_scales, _ = eetq_quant_weights(W.t().contiguous())   # :437-441 (un-zeroed W^T)
     ind = select_outlier_columns(act_scales, num_outliers)    # :446-448
-    fp_weight = W[:, ind.long()].clone()                      # :452
+    if outlier_weights == "int8":
+        q_cols = quantize_weight(W[:, ind.long()], sW)        # int8 of the un-zeroed outlier columns
+        fp_weight = q_cols.to(torch.float16) * sW[:, None]    # fp16 product, one rounding
+    else:
+        fp_weight = W[:, ind.long()].clone()                  # :452
     W[:, ind.long()] *= 0                                     # :453
     Wq = quantize_weight(W, sW)                               # :460-464
     return dict(weight=Wq.numpy(), weights_scaling_factor=sW.numpy(), fp_weight=fp_weight.numpy(),
