@@ -310,6 +310,7 @@ hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st)
 {
     if (p.M <= 0 || p.N <= 0) return hipSuccess;
     const int variant = gemm_variant();
+    if (variant != 1 && gemm_skinny_supported(p)) return launch_gemm_skinny(p, epi, st); // M <= 64
     const int64_t tiles256 = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256);
     if (variant >= 100) return launch_gemm_pp_ablate(p, variant - 100, st); // measurement-only ablations
     if (variant == 3 && gemm_pp2_supported(p, epi)) return launch_gemm_pp2(p, epi, st);

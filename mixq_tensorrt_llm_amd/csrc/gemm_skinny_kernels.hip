@@ -1,0 +1,160 @@
+// Skinny-M form of the fused W8A8O16 GEMM (5 <= M <= 64: small prefill chunks, BASELINE config 0 = bs 32): the
+// operator is HBM-bound on the N x K int8 weight here (AI ~ 2M op/B), so the kernel is built like a GEMV:
+//
+//   * one 256-thread workgroup per 16 output features: N/16 workgroups (256 for N = 4096: one per CU), 4 waves each;
+//     the waves split K into quarters, so 4 x N/16 wavefronts stream W concurrently with 16-byte loads straight into
+//     MFMA A-fragments (v_mfma_i32_16x16x64_i8: lane l = W row l%16, K bytes (l/16)*16.. of each 64-byte step): every
+//     weight byte is read from HBM exactly once, no LDS staging, 16 steps (1 KiB/lane-group) of loads in flight per wave;
+//   * qA (M x K int8, <= 64 rows) is the MFMA B operand, read through L2 (it is shared by every workgroup);
+//   * the four K-quarter accumulators meet in LDS; wave t then owns m-tile t: fp16 outlier side GEMM on
+//     v_mfma_f32_16x16x32_f16 (operands straight from L2), dequant FMA, 8-byte fp16 stores (4 consecutive n per lane).
+//
+// Same arithmetic and same results as the large-M kernels (integer accumulation is order-independent).
+// Reference lines replaced: see gemm_kernels.hip.
+#include "mixq_device.h"
+#include "mixq_launch.h"
+
+namespace mixq {
+
+template <int MT, int EPI>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmParams p)
+{
+    __shared__ v4i part[4][MT][64]; // [K quarter][m tile][lane]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n0 = blockIdx.x * 16;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int64_t K = p.K;
+
+    // this wave's K range, in 64-byte MFMA steps
+    const int nsteps = (p.K + 63) >> 6;
+    const int per = (nsteps + 3) >> 2;
+    const int s_begin = min(wave * per, nsteps), s_end = min(s_begin + per, nsteps);
+
+    const int8_t* wrow = p.B + (int64_t)min(n0 + lr, p.N - 1) * K + lq * 16;
+    const int8_t* arow[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) arow[t] = p.A + (int64_t)min(t * 16 + lr, p.M - 1) * K + lq * 16;
+
+    v4i acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = v4i{0, 0, 0, 0};
+
+    const v4i zero4 = {0, 0, 0, 0};
+    // Weight loads are issued 16 steps (1 KiB per lane-row quarter) ahead: the kernel is latency-bound (each wave only
+    // streams K/4 bytes of 16 rows), so as much of W as the registers hold is put in flight before the first MFMA.
+    auto do_steps = [&](int s0, int cnt) __attribute__((always_inline)) {
+        v4i wf[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int64_t kb = (int64_t)(s0 + u) * 64;
+            wf[u] = (u < cnt && kb + lq * 16 < K) ? *reinterpret_cast<const v4i*>(wrow + kb) : zero4;
+        }
+#pragma unroll
+        for (int u0 = 0; u0 < 16; u0 += 4) {
+            v4i af[4][MT];
+#pragma unroll
+            for (int u = u0; u < u0 + 4; ++u) {
+                const int64_t kb = (int64_t)(s0 + u) * 64;
+                const bool ok = u < cnt && kb + lq * 16 < K;
+#pragma unroll
+                for (int t = 0; t < MT; ++t) af[u - u0][t] = ok ? *reinterpret_cast<const v4i*>(arow[t] + kb) : zero4;
+            }
+#pragma unroll
+            for (int u = u0; u < u0 + 4; ++u)
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[u], af[u - u0][t], acc[t], 0, 0, 0);
+        }
+    };
+    for (int s = s_begin; s < s_end; s += 16) do_steps(s, min(16, s_end - s));
+
+#pragma unroll
+    for (int t = 0; t < MT; ++t) part[wave][t][lane] = acc[t];
+    __syncthreads();
+
+    // wave t finishes m-tile t : C/D layout of the 16x16 MFMA: m = lane & 15, n = 4 * (lane >> 4) + r
+    for (int t = wave; t < MT; t += 4) {
+        v4i a = part[0][t][lane];
+#pragma unroll
+        for (int w2 = 1; w2 < 4; ++w2) {
+            const v4i b = part[w2][t][lane];
+            a = v4i{a[0] + b[0], a[1] + b[1], a[2] + b[2], a[3] + b[3]};
+        }
+        const int m = t * 16 + lr;
+        const int nb = n0 + 4 * lq;
+        if (EPI == EPI_INT32) {
+            if (m < p.M && nb < p.N) *reinterpret_cast<v4i*>(static_cast<int32_t*>(p.D) + (int64_t)m * p.N + nb) = a;
+            continue;
+        }
+        v4f P = {0.f, 0.f, 0.f, 0.f};
+        if (p.O > 0) {
+            const int obytes = p.O * 2;
+            const char* xw = reinterpret_cast<const char*>(p.fpW) + (int64_t)min(n0 + lr, p.N - 1) * obytes;
+            const char* ya = reinterpret_cast<const char*>(p.fpA) + (int64_t)min(m, p.M - 1) * obytes;
+            for (int k0 = 0; k0 < obytes; k0 += 64) { // 32 outlier columns per step, 8 per lane
+                const int kb = k0 + lq * 16;
+                v8h xf, yf;
+                if (kb < obytes) {
+                    xf = *reinterpret_cast<const v8h*>(xw + kb);
+                    yf = *reinterpret_cast<const v8h*>(ya + kb);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xf[e] = (_Float16)0.f, yf[e] = (_Float16)0.f;
+                }
+                P = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf, yf, P, 0, 0, 0);
+            }
+        }
+        if (m < p.M && nb < p.N) {
+            const float sa = h2f(p.sA[m]);
+            const uint2 swb = *reinterpret_cast<const uint2*>(p.sW + nb);
+            const uint16_t swh[4] = {(uint16_t)(swb.x & 0xffffu), (uint16_t)(swb.x >> 16), (uint16_t)(swb.y & 0xffffu),
+                                     (uint16_t)(swb.y >> 16)};
+            uint16_t yh[4] = {0, 0, 0, 0};
+            if (p.Y != nullptr) {
+                const uint2 yb = *reinterpret_cast<const uint2*>(p.Y + (int64_t)m * p.N + nb);
+                yh[0] = (uint16_t)(yb.x & 0xffffu), yh[1] = (uint16_t)(yb.x >> 16);
+                yh[2] = (uint16_t)(yb.y & 0xffffu), yh[3] = (uint16_t)(yb.y >> 16);
+            }
+            uint16_t oh[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float c = p.O > 0 ? h2f(f2h_bits_of_f32_result(P[e])) : h2f(yh[e]);
+                float v = __builtin_fmaf((float)a[e], h2f(swh[e]) * sa, c);
+                if (EPI == EPI_DEQUANT_SILU) v = v / (1.f + __expf(-v));
+                oh[e] = f2h_bits_of_f32_result(v);
+            }
+            uint2 o;
+            o.x = (unsigned)oh[0] | ((unsigned)oh[1] << 16);
+            o.y = (unsigned)oh[2] | ((unsigned)oh[3] << 16);
+            *reinterpret_cast<uint2*>(static_cast<uint16_t*>(p.D) + (int64_t)m * p.N + nb) = o;
+        }
+    }
+}
+
+template <int EPI>
+static hipError_t launch_skinny_epi(const GemmParams& p, hipStream_t st)
+{
+    const dim3 grid((unsigned)((p.N + 15) / 16)), block(256);
+    const int mt = (p.M + 15) / 16;
+    switch (mt) {
+    case 1: hipLaunchKernelGGL((gemm_skinny_kernel<1, EPI>), grid, block, 0, st, p); break;
+    case 2: hipLaunchKernelGGL((gemm_skinny_kernel<2, EPI>), grid, block, 0, st, p); break;
+    case 3: hipLaunchKernelGGL((gemm_skinny_kernel<3, EPI>), grid, block, 0, st, p); break;
+    default: hipLaunchKernelGGL((gemm_skinny_kernel<4, EPI>), grid, block, 0, st, p); break;
+    }
+    return hipGetLastError();
+}
+
+bool gemm_skinny_supported(const GemmParams& p) { return p.M <= 64 && p.O <= 256; }
+
+hipError_t launch_gemm_skinny(const GemmParams& p, int epi, hipStream_t st)
+{
+    switch (epi) {
+    case EPI_DEQUANT: return launch_skinny_epi<EPI_DEQUANT>(p, st);
+    case EPI_DEQUANT_SILU: return launch_skinny_epi<EPI_DEQUANT_SILU>(p, st);
+    default: return launch_skinny_epi<EPI_INT32>(p, st);
+    }
+}
+
+} // namespace mixq

@@ -23,6 +23,8 @@ struct GemmParams {
 
 hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st);
 hipError_t launch_gemm_pp(const GemmParams& p, int epi, hipStream_t st);  // 256x256 ping-pong schedule
+bool gemm_skinny_supported(const GemmParams& p);
+hipError_t launch_gemm_skinny(const GemmParams& p, int epi, hipStream_t st); // M <= 64: GEMV-like, HBM-bound on W
 bool gemm_pp2_supported(const GemmParams& p, int epi);
 hipError_t launch_gemm_pp2(const GemmParams& p, int epi, hipStream_t st); // persistent ping-pong schedule
 hipError_t launch_gemm_pp_ablate(const GemmParams& p, int abl, hipStream_t st);  // timing experiments only
