@@ -123,6 +123,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=16384, help="M of each operator call (SURVEY §8: 8192-16384)")
     ap.add_argument("--tp", type=int, default=1, help="rows-of-W sharding degree (1 = pure DP, no collective)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--order", choices=["layer", "chunk"], default="layer",
+                    help="layer: each linear sees all tokens before the next one (batched prefill); chunk: chunked prefill")
     ap.add_argument("--no-tp-leg", action="store_true", help="skip the informational TP (row-sharded W) leg at N > 1")
     ap.add_argument("--force-tp-leg", action="store_true", help="run the TP leg even at N = 1 (code-path check)")
     ap.add_argument("--variant", type=int, default=0, help="GEMM schedule: 0 auto, 1 two-barrier, 2 ping-pong (A/B runs)")
@@ -173,17 +175,17 @@ def main():
         for name, N, K in LLAMA2_7B["linears"]:
             n0, n1 = parallel.shard_bounds(N, tp, tp_rank) if tp > 1 else (0, N)
             t = synth_layer(N, K, dev, gen, n0, n1)
-            if K not in acts:
-                acts[K] = [synth_activation(chunk, K, t["ind_i32"], dev, gen) for _ in range(2)]
+            if K not in acts:  # 8 rotating activation chunks per K (>1 GB: never resident in the 256 MiB Infinity Cache)
+                acts[K] = [synth_activation(chunk, K, t["ind_i32"], dev, gen) for _ in range(8)]
             if (n1 - n0) not in outs:
                 outs[n1 - n0] = torch.empty((chunk, n1 - n0), dtype=torch.float16, device=dev)
-            A = acts[K][layer % 2]
+            A = acts[K][0]
             out = outs[n1 - n0]
             ins = [A, t["weight"], t["weights_scaling_factor"], t["fp_weight"], t["fp_ind"], t["qweight"],
                    t["weights_scaling_factor"]]
             in_desc = (TensorDesc * 7)(*[TensorDesc.make(x.shape) for x in ins])
             out_desc = TensorDesc.make(out.shape)
-            in_ptrs = (ctypes.c_void_p * 7)(*[x.data_ptr() for x in ins])
+            in_ptrs = [(ctypes.c_void_p * 7)(*([a.data_ptr()] + [x.data_ptr() for x in ins[1:]])) for a in acts[K]]
             out_ptrs = (ctypes.c_void_p * 1)(out.data_ptr())
             h = lib.mixq_create(chunk, n1 - n0, K)
             max_ws = max(max_ws, lib.mixq_workspace_size(h, chunk, n1 - n0, K))
@@ -195,25 +197,38 @@ def main():
     st_ptr = ctypes.c_void_p(stream.cuda_stream)
     comm_stream = torch.cuda.Stream(dev) if tp > 1 else None
 
+    def schedule():
+        # "layer": batched-prefill order -- every linear consumes all bs x seq tokens (as M-chunks) before the next
+        # linear runs, as an engine executing layer by layer over the whole batch does; its weights are fetched from
+        # HBM once per step.  "chunk": each token chunk walks through all 96 linears (chunked-prefill serving order).
+        if args.order == "layer":
+            for li, call in enumerate(calls):
+                for c in range(n_chunks):
+                    yield call, c
+        else:
+            for c in range(n_chunks):
+                for call in calls:
+                    yield call, c
+
     def one_step(events=None):
         ei = 0
-        for _ in range(n_chunks):
-            for (h, in_desc, out_desc, in_ptrs, out_ptrs, n_loc, K, out) in calls:
-                e0 = e1 = None
-                if events is not None:
-                    e0, e1 = events[ei]
-                    ei += 1
-                rc = lib.mixq_enqueue_profiled(h, in_desc, ctypes.byref(out_desc), in_ptrs, out_ptrs, ws_ptr, st_ptr,
-                                               e0, e1)
-                if rc != 0:
-                    raise _lib.MixQError(rc, "mixq_enqueue")
-                if tp > 1:
-                    # the ONE collective of the path: all-gather the fp16 output columns (RCCL), overlapped with the
-                    # next call's compute on a side stream; the operator's output buffer is consumed before reuse.
-                    comm_stream.wait_stream(stream)
-                    with torch.cuda.stream(comm_stream):
-                        gathered[n_loc] = parallel.all_gather_columns(out, tp_group, tp)
-                    stream.wait_stream(comm_stream)
+        for (h, in_desc, out_desc, in_ptrs_list, out_ptrs, n_loc, K, out), c in schedule():
+            in_ptrs = in_ptrs_list[c % len(in_ptrs_list)]   # rotate the activation buffers of this K
+            e0 = e1 = None
+            if events is not None:
+                e0, e1 = events[ei]
+                ei += 1
+            rc = lib.mixq_enqueue_profiled(h, in_desc, ctypes.byref(out_desc), in_ptrs, out_ptrs, ws_ptr, st_ptr,
+                                           e0, e1)
+            if rc != 0:
+                raise _lib.MixQError(rc, "mixq_enqueue")
+            if tp > 1:
+                # the ONE collective of the path: all-gather the fp16 output columns (RCCL), overlapped with the
+                # next call's compute on a side stream; the operator's output buffer is consumed before reuse.
+                comm_stream.wait_stream(stream)
+                with torch.cuda.stream(comm_stream):
+                    gathered[n_loc] = parallel.all_gather_columns(out, tp_group, tp)
+                stream.wait_stream(comm_stream)
 
     def sync_all():
         torch.cuda.synchronize(dev)

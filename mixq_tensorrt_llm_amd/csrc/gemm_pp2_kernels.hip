@@ -8,7 +8,7 @@
 //     four 32x32 tiles are being dequantised; the first K slice of the NEXT output tile is fetched while the fp16
 //     results are staged through LDS and stored, so the next main loop starts with its operands resident.
 //   * the main loop itself is the ping-pong schedule of gemm_pp_kernels.hip (see that file for the hazard argument);
-//     slice buffers alternate across tile seams (`par`).
+//     slice kt of every tile lives in buffer kt & 1 (all LDS offsets are immediates).
 //
 // Reference lines replaced: see gemm_kernels.hip.  Results are bit-identical to both other schedules (tests).
 #include "mixq_device.h"
@@ -113,17 +113,18 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp2_kernel(const GemmParams 
     const char* baseA;
     const char* baseB;
     unsigned off[4][2];
-    const int slot8 = tid & 7;
-    const int koff_src = (slot8 ^ (((tid >> 3) >> 1) & 7)) << 4;
     auto setup_tile = [&](int v) __attribute__((always_inline)) {
         tile_of(v, m0, n0);
         baseB = reinterpret_cast<const char*>(p.B) + (int64_t)n0 * K;
         baseA = reinterpret_cast<const char*>(p.A) + (int64_t)m0 * K;
+        int st = tid; // opaque: nothing below is hoisted out of the tile loop (see setup_frag_offsets)
+        asm volatile("" : "+v"(st));
+        const int slot8 = st & 7;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int q = i * 64 + (tid >> 3);
+                const int q = i * 64 + (st >> 3);
                 const int sw = (q >> 1) & 7;
                 const int nl = (q >> 5) * 64 + h * 32 + (q & 31);
                 const int ml = (q >> 6) * 128 + h * 64 + (q & 63);
@@ -133,13 +134,14 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp2_kernel(const GemmParams 
             }
     };
 
-    int par = 0; // slice kt of the current tile lives in buffer (kt + par) & 1
-
     // 2 x LDS-DMA: region `region` of slice kt.  tailchk: slice kt may be partial in K (chunks past K <- zero page).
     auto issue = [&](int region, int kt, bool tailchk) __attribute__((always_inline)) {
-        const unsigned dst = lds_wave + ((kt + par) & 1) * BUF + region * REGION;
+        const unsigned dst = lds_wave + (kt & 1) * BUF + region * REGION;
         const char* base = (region < 2 ? baseB : baseA) + (int64_t)kt * KS; // scalar
         if (tailchk && ktail && kt == nk - 1) {
+            int tt = tid;
+            asm volatile("" : "+v"(tt));
+            const int koff_src = ((tt & 7) ^ (((tt >> 3) >> 1) & 7)) << 4;
             const bool oob = (int64_t)kt * KS + koff_src >= K;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -180,23 +182,31 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp2_kernel(const GemmParams 
     };
 
     // ---- fragment read offsets ---------------------------------------------------------------------------
-    const int sw = (lr >> 1) & 7;
-    int koff[4];
+    // (recomputed from an opaque thread id at the top of every tile: values that stay live across the epilogue get
+    //  spilled, and a scratch reload pending at the loop header makes the compiler put `s_waitcnt vmcnt(0)` INSIDE the
+    //  steady loop, which drains the LDS-DMA queue every iteration)
+    int koff[4], xrow, yrow;
+    auto setup_frag_offsets = [&]() __attribute__((always_inline)) {
+        int mt = tid;
+        asm volatile("" : "+v"(mt));
+        const int mlr = mt & 31, mlh = (mt >> 5) & 1;
+        const int sw = (mlr >> 1) & 7;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) koff[ks] = ((ks * 2 + lh) ^ sw) << 4;
-    const int xrow = (wn * 32 + lr) * KS;                 // + X0 / X1
-    const int yrow = (wm * 64 + lr) * KS;                 // + Y0 / Y1, + jy*32*KS
+        for (int ks = 0; ks < 4; ++ks) koff[ks] = ((ks * 2 + mlh) ^ sw) << 4;
+        xrow = (wn * 32 + mlr) * KS;                      // + X0 / X1
+        yrow = (wm * 64 + mlr) * KS;                      // + Y0 / Y1, + jy*32*KS
+    };
 
     v4i XA[4], XB[4], Y[2][4];
     v16i acc[2][4]; // [n tile][m tile]
 
     auto read_x = [&](v4i (&X)[4], int kt, int half) __attribute__((always_inline)) {
-        const char* b = smem + ((kt + par) & 1) * BUF + (half ? X1 : X0) + xrow;
+        const char* b = smem + (kt & 1) * BUF + (half ? X1 : X0) + xrow;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) X[ks] = *reinterpret_cast<const v4i*>(b + koff[ks]);
     };
     auto read_y = [&](int kt, int half) __attribute__((always_inline)) {
-        const char* b = smem + ((kt + par) & 1) * BUF + (half ? Y1 : Y0) + yrow;
+        const char* b = smem + (kt & 1) * BUF + (half ? Y1 : Y0) + yrow;
 #pragma unroll
         for (int jy = 0; jy < 2; ++jy)
 #pragma unroll
@@ -220,7 +230,7 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp2_kernel(const GemmParams 
         constexpr int MODE = decltype(mode_tag)::value;
         const bool more = (MODE != TAIL) || (kt + 1 < nk);  // wave-uniform
         const bool seam = HAS_O && !more;                   // last slice of the tile
-        const unsigned fpa_dst = lds_base + (((kt + par) & 1) ^ 1) * BUF;
+        const unsigned fpa_dst = lds_base + ((kt & 1) ^ 1) * BUF;
         int t_ = tid;
         if (MODE == TAIL) asm volatile("" : "+v"(t_));
         // phase 1: (Y0, X0)
@@ -262,7 +272,7 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp2_kernel(const GemmParams 
 
     int v = blockIdx.x; // virtual block id of the current tile
     auto stamp = [&](int idx) __attribute__((always_inline)) {
-        if (p.dbg != nullptr && tid == 0 && v + (int)gridDim.x >= nwg) // last tile of each block only
+        if (p.dbg != nullptr && tid == 0 && v >= (int)gridDim.x && v < 2 * (int)gridDim.x) // second tile of each block
             static_cast<unsigned long long*>(p.dbg)[(size_t)blockIdx.x * 8 + idx] = __builtin_readcyclecounter();
     };
 
@@ -283,26 +293,28 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp2_kernel(const GemmParams 
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
+        setup_frag_offsets();
         read_x(XA, 0, 0);
-        stamp(1);
         if (group == 1) MIXQ2_SEG_END(); // group 1 now runs one segment behind group 0
         {
             slice(XA, XB, 0, first_t{});
             slice(XB, XA, 1, steady_t{});
+            stamp(1);
             int kt = 2;
             for (; kt + 3 < nk; kt += 2) { // both slices of the pair have a full successor: branch-free body
                 slice(XA, XB, kt, steady_t{});
                 slice(XB, XA, kt + 1, steady_t{});
             }
+            stamp(2);
             for (; kt < nk; kt += 2) { // last 2-3 slices: successor may be partial in K or absent (runtime checks)
                 slice(XA, XB, kt, tail_t{});
                 if (kt + 1 < nk) slice(XB, XA, kt + 1, tail_t{});
             }
         }
         if (group == 0) MIXQ2_SEG_END(); // re-align the groups
-        stamp(2);
+        stamp(3);
 
-        const int b_last = (nk - 1 + par) & 1;           // buffer of the last slice: free now
+        const int b_last = (nk - 1) & 1;                 // buffer of the last slice: free now
         const unsigned lds_fpa = ((b_last ^ 1) * BUF);   // fpA tile (fetched during the last slice)
         const unsigned lds_fpw1 = (b_last * BUF);        // fpW n-half 1 (fetched now)
         int et = tid; // opaque thread id for everything between two main loops (see issue_fpA)
@@ -314,7 +326,7 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp2_kernel(const GemmParams 
             wait_vmcnt<4>(); // fpA + fpW half 0 have landed; only the four copies above may still be in flight
             MIXQ2_SEG_END();
         }
-        stamp(3);
+        stamp(4);
 
         // ---- dequant math, tile by tile, results packed to fp16 in registers (acc registers die as we go) ----
         uint2 outp[2][4][4]; // [n tile][m tile][quad] : 4 consecutive n for row m
@@ -391,15 +403,14 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp2_kernel(const GemmParams 
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        stamp(4);
+        stamp(5);
         MIXQ2_SEG_END(); // everyone is done with the outlier operands: both slice buffers are free
 
         // ---- fetch slice 0 of the next tile into buffer b_last while this tile's results are stored ----------
         const int m0_cur = m0, n0_cur = n0;
         const int vnext = v + gridDim.x;
         const bool have_next = vnext < nwg;
-        par = b_last;
-        if (have_next) {
+        if (have_next) { // slice 0 always lives in buffer 0; the results are staged through buffer 1
             setup_tile(vnext);
             issue(0, 0, true);
             issue(2, 0, true);
@@ -408,7 +419,7 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp2_kernel(const GemmParams 
         }
 
         // ---- results -> LDS (buffer b_last^1, 64 KiB = 128 rows x 512 B at a time) -> whole-row stores --------
-        char* stg = smem + lds_fpa;
+        char* stg = smem + BUF;
         uint16_t* D = static_cast<uint16_t*>(p.D);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -427,7 +438,7 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp2_kernel(const GemmParams 
             }
             if (h == 0) {
                 if (have_next) wait_vmcnt<0>(); // next tile's slice 0 (only DMA in flight: no stores issued yet)
-                stamp(5);
+                stamp(6);
             }
             MIXQ2_SEG_END();
 #pragma unroll
@@ -440,13 +451,9 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp2_kernel(const GemmParams 
             }
             MIXQ2_SEG_END();
         }
-        stamp(6);
+        stamp(7);
         if (!have_next) break;
         v = vnext;
-    }
-    if (p.dbg != nullptr) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        stamp(7);
     }
 }
 

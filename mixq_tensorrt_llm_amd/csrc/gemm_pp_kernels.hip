@@ -1,7 +1,7 @@
 // Ping-pong ("8-phase") variant of the fused W8A8O16 GEMM for large problems on gfx950.
 //
 // Same math, same operand roles, same results as gemm_kernels.hip (see its header for the reference lines replaced);
-// what changes is the main-loop schedule, built for one 512-thread workgroup per CU (256 x 256 output tile, 128 KiB LDS):
+// what changes is the main-loop schedule, built for one 512-thread workgroup per CU (256 x 256 output tile, 160 KiB LDS):
 //
 //   * the 8 waves form two groups of 4 (one wave of each group on every SIMD).  A K slice (128 B per row) is processed
 //     in 4 phases; every phase is a LOAD segment (ds_read_b128 of the next fragments + 2 global_load_lds of the next
@@ -26,7 +26,7 @@
 //   WAR  a region is re-issued 5 slots after its last read.
 //
 // Epilogue: fp16 outlier side GEMM (operands staged in the dead main-loop LDS, 8 unrolled k-steps per 32x32 tile),
-// dequant FMA, results packed to fp16 in registers, staged through LDS and written as whole 512-byte rows.
+// dequant FMA, results packed to fp16 and transposed through a wave-private LDS window into 128-byte row segments.
 #include "mixq_device.h"
 #include "mixq_launch.h"
 #include <type_traits>
@@ -78,7 +78,8 @@ __device__ __forceinline__ void glds16_sbase(const char* sbase, unsigned voff, u
 } // namespace pp
 
 // ABL: measurement-only ablations (wrong results): 1 = no global_load_lds in the loop, 2 = no vmcnt waits,
-// 4 = no ds_reads in the loop.  ABL = 0 is the product kernel.
+// 4 = no ds_reads in the loop, 8 = every tile loads tile (0,0)'s operands (all L2 hits), 16 = no epilogue.
+// ABL = 0 is the product kernel.
 template <int EPI, bool HAS_O, bool HAS_Y, int ABL = 0>
 __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p)
 {
@@ -118,8 +119,8 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
     //                                               Y: m_local = (q/64)*128 + h*64 + q%64  (q/64 = wm)
     // Address = wave-uniform 64-bit base (tile origin + slice offset, SGPRs) + constant per-thread 32-bit offset.
     const int64_t K = p.K;
-    const char* const baseB = reinterpret_cast<const char*>(p.B) + (int64_t)n0 * K;
-    const char* const baseA = reinterpret_cast<const char*>(p.A) + (int64_t)m0 * K;
+    const char* const baseB = reinterpret_cast<const char*>(p.B) + ((ABL & 8) ? 0 : (int64_t)n0 * K);
+    const char* const baseA = reinterpret_cast<const char*>(p.A) + ((ABL & 8) ? 0 : (int64_t)m0 * K);
     unsigned off[4][2];
     int koff_src;
     {
@@ -269,7 +270,8 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
     if (group == 0) MIXQ_SEG_END(); // re-align the groups
     stamp(2);
 
-    if (EPI == EPI_INT32) { // debug / unfused API: raw accumulators, 16-byte stores straight from the MFMA layout
+    if ((ABL & 16) && p.M != -1) return; // (p.M is never -1: keeps the accumulators live)
+    if (EPI == EPI_INT32 || (ABL & 16)) { // debug / unfused API: raw accumulators, 16-byte stores straight from the MFMA layout
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -319,16 +321,21 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
     }
     stamp(3);
 
-    // ---- dequant math, tile by tile, results packed to fp16 in registers (acc registers die as we go).
-    // The side GEMM always runs 8 k-steps of 16 outlier columns (chunks past O were staged as zeros); everything is
-    // unrolled and branch-free, so the MFMA chain of one tile overlaps the VALU work of its neighbours.
-    uint2 outp[2][4][4]; // [n tile][m tile][quad] : 4 consecutive n for row m
+    // ---- dequant math + stores, one 32 (m) x 64 (n) block of the wave tile at a time.  Results are packed to fp16 and
+    // transposed through a wave-private 4-KiB LDS window (32 rows x 128 B; the 32 KiB above the slice buffers), then
+    // written as 128-byte row segments (8 rows per store instruction).  No workgroup barrier is involved: LDS
+    // operations of one wave execute in order, so each wave streams side GEMM -> dequant -> ds_write -> ds_read ->
+    // global_store on its own, and the stores of block j fly under the math of block j+1.
+    // The side GEMM always runs 8 k-steps of 16 outlier columns (chunks past O were staged as zeros).
+    // Window layout: 16-B chunk c of row r at chunk c ^ (r & 7); its two 8-B halves are swapped on rows with bit 3 set
+    // (rows r and r+8 would otherwise hit the same banks in one ds_write_b64 pass).
+    char* const wstg = smem + 2 * BUF + wave * 4096;
     const int obase = (lh ^ (lr & 15)) << 4; // 16-B slot of k-step ks = obase ^ (ks << 5)
     float sa[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) sa[j] = h2f(p.sA[min(m0 + wm * 128 + j * 32 + lr, p.M - 1)]); // clamped rows never stored
 
-    // side GEMM of tile t = i*4 + j : 8 k-steps of 16 outlier columns (chunks past O were staged as zeros)
+    // side GEMM of tile (i, j): 8 k-steps of 16 outlier columns
     auto side = [&](int i, int j) __attribute__((always_inline)) {
         v16f P;
 #pragma unroll
@@ -350,7 +357,8 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
         }
         return P;
     };
-    // dequant of tile (i, j) with its side product P
+    const int wrow = lr * 128 + ((lh ^ ((lr >> 3) & 1)) << 3); // this lane's row + 8-B half inside the window
+    // dequant of tile (i, j) with its side product P -> 4 quads (4 consecutive n of row m each) -> window
     auto dequant = [&](int i, int j, const v16f& P) __attribute__((always_inline)) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -386,62 +394,48 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
                 const v2h o16 = f2h2_of_f32_results(v0, v1);
                 __builtin_memcpy(&ow[e2 >> 1], &o16, 4);
             }
-            outp[i][j][g].x = ow[0];
-            outp[i][j][g].y = ow[1];
+            const int c = i * 4 + g; // 16-byte chunk of the 128-byte row
+            *reinterpret_cast<uint2*>(wstg + wrow + ((c ^ (lr & 7)) << 4)) = uint2{ow[0], ow[1]};
         }
     };
-    // software pipeline over the 8 tiles: the MFMA chain of tile t+1 runs under the VALU work of tile t
+    // rows j*32 .. j*32+31 of the wave tile: window -> 4 x (8 rows x 128 B) stores
+    uint16_t* const D = static_cast<uint16_t*>(p.D);
+    auto flush = [&](int j) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rr = q * 8 + (lane >> 3), cc = lane & 7;
+            uint4 v = *reinterpret_cast<const uint4*>(wstg + rr * 128 + ((cc ^ (rr & 7)) << 4));
+            if (q & 1) v = uint4{v.z, v.w, v.x, v.y}; // rows with bit 3 set hold their 8-B halves swapped
+            const int m = m0 + wm * 128 + j * 32 + rr, n = n0 + wn * 64 + cc * 8;
+            if (m < p.M && n < p.N) *reinterpret_cast<uint4*>(D + (int64_t)m * p.N + n) = v;
+        }
+    };
+    // software pipeline over the 8 tiles (j-major): the MFMA chain of tile t+1 runs under the VALU work of tile t
     {
         v16f Pcur = side(0, 0);
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             v16f Pnext = Pcur;
-            if (t + 1 < 8) Pnext = side((t + 1) >> 2, (t + 1) & 3);
-            dequant(t >> 2, t & 3, Pcur);
+            if (t + 1 < 8) Pnext = side((t + 1) & 1, (t + 1) >> 1);
+            dequant(t & 1, t >> 1, Pcur);
+            if (t & 1) flush(t >> 1);
             Pcur = Pnext;
             __builtin_amdgcn_sched_barrier(0);
         }
     }
     stamp(4);
-
-    // ---- stage the 256 x 256 fp16 tile in LDS (512-byte rows, 16-B chunk c of row r at chunk c ^ (r & 31)), then
-    //      write it out as whole rows: every store instruction covers two complete 512-byte row segments ----------
-    __syncthreads(); // everyone is done with the main-loop / outlier operands in LDS
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = wm * 128 + j * 32 + lr;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c = wn * 8 + i * 4 + g; // 16-byte chunk index inside the row; lh picks its 8-byte half
-                *reinterpret_cast<uint2*>(smem + r * 512 + ((c ^ (r & 31)) << 4) + lh * 8) = outp[i][j][g];
-            }
-        }
-    __syncthreads();
-    {
-        stamp(5);
-        uint16_t* D = static_cast<uint16_t*>(p.D);
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int q = it * T + tid;
-            const int r = q >> 5, c = q & 31;
-            const uint4 v = *reinterpret_cast<const uint4*>(smem + r * 512 + ((c ^ (r & 31)) << 4));
-            const int m = m0 + r, n = n0 + c * 8;
-            if (m < p.M && n < p.N) *reinterpret_cast<uint4*>(D + (int64_t)m * p.N + n) = v;
-        }
-        stamp(6);
-        if (p.dbg != nullptr) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            stamp(7);
-        }
+    stamp(5);
+    stamp(6);
+    if (p.dbg != nullptr) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(7);
     }
 }
 
 template <int EPI, bool HAS_O, bool HAS_Y, int ABL = 0>
 static hipError_t launch_pp_cfg(const GemmParams& p, hipStream_t st)
 {
-    constexpr size_t lds = 2 * (size_t)pp::BUF;
+    constexpr size_t lds = 2 * (size_t)pp::BUF + 32768; // slice buffers + 8 x 4-KiB store windows
     auto kern = gemm_w8a8o16_pp_kernel<EPI, HAS_O, HAS_Y, ABL>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -472,6 +466,10 @@ hipError_t launch_gemm_pp_ablate(const GemmParams& p, int abl, hipStream_t st)
     case 4: return launch_pp_cfg<EPI_DEQUANT, true, false, 4>(p, st);
     case 5: return launch_pp_cfg<EPI_DEQUANT, true, false, 5>(p, st);
     case 7: return launch_pp_cfg<EPI_DEQUANT, true, false, 7>(p, st);
+    case 8: return launch_pp_cfg<EPI_DEQUANT, true, false, 8>(p, st);
+    case 16: return launch_pp_cfg<EPI_DEQUANT, true, false, 16>(p, st);
+    case 24: return launch_pp_cfg<EPI_DEQUANT, true, false, 24>(p, st);
+    case 21: return launch_pp_cfg<EPI_DEQUANT, true, false, 21>(p, st);
     default: return launch_pp_cfg<EPI_DEQUANT, true, false, 0>(p, st);
     }
 }

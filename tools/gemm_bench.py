@@ -71,7 +71,7 @@ def main():
     gemm()
     torch.cuda.synchronize()
     if a.stamps:
-        timeline(lib, gemm, M, N, dev)
+        timeline(lib, gemm, M, N, dev, a.variant)
     for name, fn in (("quant", quant), ("gemm", gemm)):
         if a.what not in (name, "both"):
             continue
@@ -92,7 +92,7 @@ def main():
             print(f"quant M={M} K={K}: {ms*1e3:.1f} us  {gb/ms*1e3:.0f} GB/s algorithmic")
 
 
-def timeline(lib, gemm, M, N, dev):
+def timeline(lib, gemm, M, N, dev, variant=0):
     import numpy as np
     nblk = ((M + 255) // 256) * ((N + 255) // 256)
     buf = torch.zeros(nblk * 8, dtype=torch.int64, device=dev)
@@ -101,8 +101,12 @@ def timeline(lib, gemm, M, N, dev):
     torch.cuda.synchronize()
     lib.mixq_debug_set_stamp_buffer(None)
     t = buf.cpu().numpy().reshape(nblk, 8).astype(np.float64)
+    t = t[t[:, 0] > 0]   # the persistent variant stamps one tile per resident workgroup
+    nblk = len(t)
     t0 = t[:, 0].min()
     names = ["prologue", "main loop", "outlier stage", "dequant math", "tile->LDS", "issue stores", "drain stores"]
+    if variant == 3:  # persistent kernel: stamps of the second tile of every resident workgroup
+        names = ["slices 0-1", "steady slices", "tail slices", "fpW half 1", "dequant math", "next slice 0 + LDS", "stores"]
     d = np.diff(t, axis=1)
     print(f"stamps: {nblk} blocks; kernel span {(t[:, 7].max() - t0):.0f} ticks; per-block total mean {(t[:,7]-t[:,0]).mean():.0f}")
     for i, nme in enumerate(names):
