@@ -250,7 +250,7 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
     issue(2, 0, true);
     issue(1, 0, true);
     issue(3, 0, true);
-    wait_vmcnt<0>();
+    wait_vmcnt<4>(); // X0 and Y0 have landed; X1 / Y1 are retired by the vmcnt(4) of phases 1 / 2 like in steady state
     MIXQ_SEG_END();
     read_x(XA, 0, 0);
     stamp(1);
@@ -358,17 +358,24 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
         return P;
     };
     const int wrow = lr * 128 + ((lh ^ ((lr >> 3) & 1)) << 3); // this lane's row + 8-B half inside the window
+    // weight scales of this lane's 2 x 4 column quads (the same for all four j): loaded once, kept as packed fp16
+    uint2 swq[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            swq[i][g] = *reinterpret_cast<const uint2*>(p.sW + min(n0 + wn * 64 + i * 32 + 4 * lh + 8 * g, p.N - 4));
     // dequant of tile (i, j) with its side product P -> 4 quads (4 consecutive n of row m each) -> window
     auto dequant = [&](int i, int j, const v16f& P) __attribute__((always_inline)) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int nb = min(n0 + wn * 64 + i * 32 + 4 * lh + 8 * g, p.N - 4);
-            const uint2 swb = *reinterpret_cast<const uint2*>(p.sW + nb);
+            const uint2 swb = swq[i][g];
             const float swf[4] = {h2f((uint16_t)(swb.x & 0xffffu)), h2f((uint16_t)(swb.x >> 16)),
                                   h2f((uint16_t)(swb.y & 0xffffu)), h2f((uint16_t)(swb.y >> 16))};
             uint16_t yh[4] = {0, 0, 0, 0};
             if (HAS_Y) {
                 const int m = min(m0 + wm * 128 + j * 32 + lr, p.M - 1);
+                const int nb = min(n0 + wn * 64 + i * 32 + 4 * lh + 8 * g, p.N - 4);
                 const uint2 yb = *reinterpret_cast<const uint2*>(p.Y + (int64_t)m * p.N + nb);
                 yh[0] = (uint16_t)(yb.x & 0xffffu), yh[1] = (uint16_t)(yb.x >> 16);
                 yh[2] = (uint16_t)(yb.y & 0xffffu), yh[3] = (uint16_t)(yb.y >> 16);
@@ -380,7 +387,7 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
                 // addend pair: the fp16-rounded outlier products (cuBLAS writes fp16) or the caller's y
                 v2f c2;
                 if (HAS_O) {
-                    const v2h p16 = f2h2_of_f32_results(P[4 * g + e2], P[4 * g + e2 + 1]);
+                    const v2h p16 = f2h2(P[4 * g + e2], P[4 * g + e2 + 1]); // MFMA outputs: nothing to fuse with
                     c2 = v2f{(float)p16[0], (float)p16[1]};
                 } else {
                     c2 = v2f{h2f(yh[e2]), h2f(yh[e2 + 1])};
@@ -399,15 +406,26 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
         }
     };
     // rows j*32 .. j*32+31 of the wave tile: window -> 4 x (8 rows x 128 B) stores
-    uint16_t* const D = static_cast<uint16_t*>(p.D);
+    // store address = wave-uniform base (SGPRs) + a per-lane 32-bit offset that never changes
+    char* const dwave = static_cast<char*>(p.D) + ((int64_t)(m0 + wm * 128) * p.N + n0 + wn * 64) * 2;
+    const unsigned dlane = ((unsigned)(lane >> 3) * (unsigned)p.N + (lane & 7) * 8) * 2;
+    const int rd = (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4); // window read offset (rr & 7 == lane >> 3)
+    const bool n_ok = n0 + wn * 64 + (lane & 7) * 8 < p.N;
+    const bool interior = m0 + BM <= p.M && n0 + BN <= p.N; // wave-uniform: no store predicates needed
     auto flush = [&](int j) __attribute__((always_inline)) {
+        uint4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const uint4*>(wstg + q * 1024 + rd);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) // (opaque: keeps the four reads together, ahead of the predicated stores)
+            asm volatile("" : "+v"(v[q].x), "+v"(v[q].y), "+v"(v[q].z), "+v"(v[q].w));
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int rr = q * 8 + (lane >> 3), cc = lane & 7;
-            uint4 v = *reinterpret_cast<const uint4*>(wstg + rr * 128 + ((cc ^ (rr & 7)) << 4));
-            if (q & 1) v = uint4{v.z, v.w, v.x, v.y}; // rows with bit 3 set hold their 8-B halves swapped
-            const int m = m0 + wm * 128 + j * 32 + rr, n = n0 + wn * 64 + cc * 8;
-            if (m < p.M && n < p.N) *reinterpret_cast<uint4*>(D + (int64_t)m * p.N + n) = v;
+            if (q & 1) v[q] = uint4{v[q].z, v[q].w, v[q].x, v[q].y}; // rows with bit 3 set hold their 8-B halves swapped
+            const int row = j * 32 + q * 8;            // wave-uniform
+            char* dst = dwave + (int64_t)row * p.N * 2 + dlane;
+            if (interior) *reinterpret_cast<uint4*>(dst) = v[q];
+            else if (n_ok && m0 + wm * 128 + row + (lane >> 3) < p.M) *reinterpret_cast<uint4*>(dst) = v[q];
         }
     };
     // software pipeline over the 8 tiles (j-major): the MFMA chain of tile t+1 runs under the VALU work of tile t

@@ -47,6 +47,13 @@ __device__ __forceinline__ v2h f2h2_of_f32_results(float a, float b)
     return __builtin_convertvector(v2f_{a, b}, v2h);
 }
 
+// Two fp32 values that are NOT results of an fp32 FMA/add in this kernel (e.g. MFMA accumulators) -> packed fp16 (RNE).
+__device__ __forceinline__ v2h f2h2(float a, float b)
+{
+    typedef float v2f_ __attribute__((ext_vector_type(2)));
+    return __builtin_convertvector(v2f_{a, b}, v2h);
+}
+
 // 16-byte async copy global -> LDS.  LDS destination = wave-uniform base + lane*16 (hardware rule); the
 // per-lane part lives entirely in the global source address.
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base)
