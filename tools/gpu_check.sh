@@ -26,4 +26,4 @@ rm -rf "$OUT/prof" ; mkdir -p "$OUT/prof"
     python "$OLDPWD/bench.py" --tokens 65536 --steps 1 --warmup 1 --no-cpu-baseline ) > "$OUT/rocprof.log" 2>&1
 tail -3 "$OUT/rocprof.log"
 find "$OUT/prof" -name "*kernel_stats*" | head -3
-for f in $(find "$OUT/prof" -name "*kernel_stats.csv" | head -1); do head -12 "$f"; done
+for f in $(find "$OUT/prof" -name "*kernel_stats.csv" | head -1); do head -6 "$f" | cut -c1-220; done
