@@ -93,4 +93,56 @@ __device__ __forceinline__ int quant_one_fast(float x, float s, float rs)
     return half_to_int8_bits(q0);
 }
 
+// max of the two 16-bit halves of a and b, per half (v_pk_max_u16)
+__device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b)
+{
+    typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(v2u16, a), __builtin_bit_cast(v2u16, b)));
+}
+
+// 8 fp16 -> 8 int8 with the semantics of quant_one(), for rows in which every element is finite and the scale s is
+// finite and non-zero (then |x / s| < 512).  Per pair of elements: fp32 products with rs = fl32(1/s) (v_pk_mul_f32),
+// one RNE conversion to packed fp16 (= fp16(x / s) unless the product sits next to a rounding breakpoint, see
+// quant_one_fast), and round-to-integer + low-8-bits in ONE packed fp16 add: h + 1536 has ulp 1, so its mantissa
+// field is 512 + rint(h) and the low byte of the bit pattern is the two's-complement int8.  The fp16 value is pinned
+// in a VGPR before the add (a fused fp32 -> fp16 add would round once instead of twice).  Elements whose product lies
+// within 3 ulp32 of a breakpoint are recomputed with the exact division.
+__device__ __forceinline__ uint2 quant_vec8_finite(const uint4& xv, float s, float rs)
+{
+    typedef float v2f_ __attribute__((ext_vector_type(2)));
+    const unsigned w[4] = {xv.x, xv.y, xv.z, xv.w};
+    unsigned rb[4];
+    unsigned rmin = 0xffffffffu;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const v2h hx = __builtin_bit_cast(v2h, w[e]);
+        const v2f_ q = v2f_{(float)hx[0], (float)hx[1]} * v2f_{rs, rs};
+        const float q0 = q[0], q1 = q[1]; // (copies: __builtin_bit_cast of a vector-element lvalue reads element 0)
+        const unsigned a0 = (__builtin_bit_cast(unsigned, q0) + 3u - 0x1000u) & 0x1fffu;
+        const unsigned a1 = (__builtin_bit_cast(unsigned, q1) + 3u - 0x1000u) & 0x1fffu;
+        rmin = min(rmin, min(a0, a1));
+        unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(q, v2h));
+        asm("" : "+v"(hb));
+        const v2h r = __builtin_bit_cast(v2h, hb) + v2h{(_Float16)1536.f, (_Float16)1536.f};
+        rb[e] = __builtin_bit_cast(unsigned, r);
+    }
+    uint2 o;
+    o.x = __builtin_amdgcn_perm(rb[1], rb[0], 0x06040200u);
+    o.y = __builtin_amdgcn_perm(rb[3], rb[2], 0x06040200u);
+    if (__builtin_expect(rmin <= 6u, 0)) {
+        unsigned ow[2] = {o.x, o.y};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = h2f((uint16_t)(w[e >> 1] >> ((e & 1) * 16)));
+            const unsigned low = (__builtin_bit_cast(unsigned, x * rs) + 3u - 0x1000u) & 0x1fffu;
+            if (low <= 6u) {
+                const unsigned b = (unsigned)quant_one(x, s);
+                ow[e >> 2] = (ow[e >> 2] & ~(0xffu << ((e & 3) * 8))) | (b << ((e & 3) * 8));
+            }
+        }
+        o.x = ow[0], o.y = ow[1];
+    }
+    return o;
+}
+
 } // namespace mixq

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(NBLOCK) void rmsnorm_quant_kernel(const uint16_t* _
 
     // normalise in place (registers now hold the fp16 result), stage the row in LDS for the gather
     const uint4* __restrict__ g4 = reinterpret_cast<const uint4*>(gamma);
-    int amax = -1;
+    unsigned m2 = 0u;
 #pragma unroll
     for (int v = 0; v < MAXV; ++v) {
         const int idx = v * TPR + t;
@@ -114,10 +114,7 @@ __global__ __launch_bounds__(NBLOCK) void rmsnorm_quant_kernel(const uint16_t* _
                 for (int e = 0; e < 4; ++e) {
                     if (m8 & (1u << (2 * e))) w[e] &= 0xffff0000u;
                     if (m8 & (2u << (2 * e))) w[e] &= 0x0000ffffu;
-                    int lo = (int)(w[e] & 0x7fffu), hi = (int)((w[e] >> 16) & 0x7fffu);
-                    lo = lo > 0x7c00 ? -1 : lo;
-                    hi = hi > 0x7c00 ? -1 : hi;
-                    amax = max(amax, max(lo, hi));
+                    m2 = pk_max_u16(m2, w[e] & 0x7fff7fffu); // |x| bit patterns, NaN patterns included
                 }
                 x[v] = make_uint4(w[0], w[1], w[2], w[3]);
             }
@@ -132,12 +129,35 @@ __global__ __launch_bounds__(NBLOCK) void rmsnorm_quant_kernel(const uint16_t* _
     }
     if (!QUANT) return;
 
+    auto row_max = [&](int val) __attribute__((always_inline)) {
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) amax = max(amax, __shfl_xor(amax, off, 64));
-    if (TPR > 64) {
-        if ((tid & 63) == 0) redi[tid >> 6] = amax;
-        __syncthreads();
-        amax = max(max(redi[0], redi[1]), max(redi[2], redi[3]));
+        for (int off = 32; off >= 1; off >>= 1) val = max(val, __shfl_xor(val, off, 64));
+        if (TPR > 64) {
+            __syncthreads(); // (also orders a second use of redi[])
+            if ((tid & 63) == 0) redi[tid >> 6] = val;
+            __syncthreads();
+            val = max(max(redi[0], redi[1]), max(redi[2], redi[3]));
+        }
+        return val;
+    };
+    const int amax_all = row_max((int)max(m2 & 0xffffu, m2 >> 16));
+    int amax = amax_all;
+    if (amax_all > 0x7c00) { // a NaN in the row: max with NaNs dropped (__hmax); -1 = every element is NaN
+        amax = -1;
+#pragma unroll
+        for (int v = 0; v < MAXV; ++v) {
+            const unsigned w[4] = {x[v].x, x[v].y, x[v].z, x[v].w};
+            if (v * TPR + t < nvec) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    int lo = (int)(w[e] & 0x7fffu), hi = (int)((w[e] >> 16) & 0x7fffu);
+                    lo = lo > 0x7c00 ? -1 : lo;
+                    hi = hi > 0x7c00 ? -1 : hi;
+                    amax = max(amax, max(lo, hi));
+                }
+            }
+        }
+        amax = row_max(amax);
     }
     const uint16_t amax_bits = amax < 0 ? (uint16_t)0x7fffu : (uint16_t)amax;
     const uint16_t s_bits = f2h_bits(h2f(amax_bits) / 127.0f);
@@ -145,19 +165,26 @@ __global__ __launch_bounds__(NBLOCK) void rmsnorm_quant_kernel(const uint16_t* _
     const float rs = 1.0f / s;
     if (row_ok && t == 0) scale[row] = s_bits;
     uint2* __restrict__ dstq = reinterpret_cast<uint2*>(q + (row_ok ? row : 0) * (int64_t)K);
+    if (amax_all < 0x7c00 && s_bits != 0) { // every element finite, scale finite and non-zero (row-uniform)
 #pragma unroll
-    for (int v = 0; v < MAXV; ++v) {
-        const int idx = v * TPR + t;
-        if (row_ok && idx < nvec) {
-            const unsigned w[4] = {x[v].x, x[v].y, x[v].z, x[v].w};
-            unsigned o[2] = {0u, 0u};
+        for (int v = 0; v < MAXV; ++v) {
+            const int idx = v * TPR + t;
+            if (row_ok && idx < nvec) dstq[idx] = quant_vec8_finite(x[v], s, rs);
+        }
+    } else {
+        for (int v = 0; v < MAXV; ++v) {
+            const int idx = v * TPR + t;
+            if (row_ok && idx < nvec) {
+                const unsigned w[4] = {x[v].x, x[v].y, x[v].z, x[v].w};
+                unsigned o[2] = {0u, 0u};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int q0 = quant_one_fast(h2f((uint16_t)(w[e] & 0xffffu)), s, rs);
-                const int q1 = quant_one_fast(h2f((uint16_t)(w[e] >> 16)), s, rs);
-                o[e >> 1] |= (unsigned)(q0 | (q1 << 8)) << ((e & 1) * 16);
+                for (int e = 0; e < 4; ++e) {
+                    const int q0 = quant_one(h2f((uint16_t)(w[e] & 0xffffu)), s);
+                    const int q1 = quant_one(h2f((uint16_t)(w[e] >> 16)), s);
+                    o[e >> 1] |= (unsigned)(q0 | (q1 << 8)) << ((e & 1) * 16);
+                }
+                dstq[idx] = make_uint2(o[0], o[1]);
             }
-            dstq[idx] = make_uint2(o[0], o[1]);
         }
     }
 }

@@ -74,25 +74,42 @@ __global__ __launch_bounds__(QBLOCK) void quant_extract_kernel(uint16_t* __restr
         }
     }
 
-    // ---- amax over |x| bit patterns; NaN -> -1 so that an all-NaN row is distinguishable ----
-    int amax = -1;
+    // ---- amax over |x| bit patterns (order-preserving for non-NaN): packed 16-bit max, NaN patterns included ----
+    unsigned m2 = 0u;
 #pragma unroll
     for (int v = 0; v < MAXV; ++v) {
-        const unsigned w[4] = {x[v].x, x[v].y, x[v].z, x[v].w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            int lo = (int)(w[e] & 0x7fffu), hi = (int)((w[e] >> 16) & 0x7fffu);
-            lo = lo > 0x7c00 ? -1 : lo;
-            hi = hi > 0x7c00 ? -1 : hi;
-            amax = max(amax, max(lo, hi));
-        }
+        m2 = pk_max_u16(m2, x[v].x & 0x7fff7fffu);
+        m2 = pk_max_u16(m2, x[v].y & 0x7fff7fffu);
+        m2 = pk_max_u16(m2, x[v].z & 0x7fff7fffu);
+        m2 = pk_max_u16(m2, x[v].w & 0x7fff7fffu);
     }
+    auto row_max = [&](int val) __attribute__((always_inline)) {
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) amax = max(amax, __shfl_xor(amax, off, 64));
-    if (TPR > 64) {
-        if ((tid & 63) == 0) red[tid >> 6] = amax;
-        __syncthreads();
-        amax = max(max(red[0], red[1]), max(red[2], red[3]));
+        for (int off = 32; off >= 1; off >>= 1) val = max(val, __shfl_xor(val, off, 64));
+        if (TPR > 64) {
+            __syncthreads(); // (also orders a second use of red[])
+            if ((tid & 63) == 0) red[tid >> 6] = val;
+            __syncthreads();
+            val = max(max(red[0], red[1]), max(red[2], red[3]));
+        }
+        return val;
+    };
+    const int amax_all = row_max((int)max(m2 & 0xffffu, m2 >> 16));
+    int amax = amax_all;
+    if (amax_all > 0x7c00) { // the row holds a NaN: redo the max with NaNs dropped the way __hmax drops them
+        amax = -1;           // (-1 = every element is NaN)
+#pragma unroll
+        for (int v = 0; v < MAXV; ++v) {
+            const unsigned w[4] = {x[v].x, x[v].y, x[v].z, x[v].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int lo = (int)(w[e] & 0x7fffu), hi = (int)((w[e] >> 16) & 0x7fffu);
+                lo = lo > 0x7c00 ? -1 : lo;
+                hi = hi > 0x7c00 ? -1 : hi;
+                amax = max(amax, max(lo, hi));
+            }
+        }
+        amax = row_max(amax);
     }
     const uint16_t amax_bits = amax < 0 ? (uint16_t)0x7fffu : (uint16_t)amax;
     const uint16_t s_bits = f2h_bits(h2f(amax_bits) / 127.0f); // __hdiv(max, 127.0)
@@ -102,19 +119,26 @@ __global__ __launch_bounds__(QBLOCK) void quant_extract_kernel(uint16_t* __restr
 
     // ---- quantise: 8 fp16 -> 8 int8 per vector, one 8-byte store per lane ----
     uint2* __restrict__ dst = reinterpret_cast<uint2*>(qA + (row_ok ? row : 0) * (int64_t)K);
+    if (amax_all < 0x7c00 && s_bits != 0) { // every element finite, scale finite and non-zero (row-uniform)
 #pragma unroll
-    for (int v = 0; v < MAXV; ++v) {
-        const int idx = v * TPR + t;
-        if (row_ok && idx < nvec) {
-            const unsigned w[4] = {x[v].x, x[v].y, x[v].z, x[v].w};
-            unsigned o[2] = {0u, 0u};
+        for (int v = 0; v < MAXV; ++v) {
+            const int idx = v * TPR + t;
+            if (row_ok && idx < nvec) dst[idx] = quant_vec8_finite(x[v], s, rs);
+        }
+    } else { // inf / NaN elements, zero scale (zero or tiny row): quotients may be inf / NaN -> exact chain
+        for (int v = 0; v < MAXV; ++v) {
+            const int idx = v * TPR + t;
+            if (row_ok && idx < nvec) {
+                const unsigned w[4] = {x[v].x, x[v].y, x[v].z, x[v].w};
+                unsigned o[2] = {0u, 0u};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                int q0 = quant_one_fast(h2f((uint16_t)(w[e] & 0xffffu)), s, rs);
-                int q1 = quant_one_fast(h2f((uint16_t)(w[e] >> 16)), s, rs);
-                o[e >> 1] |= (unsigned)(q0 | (q1 << 8)) << ((e & 1) * 16);
+                for (int e = 0; e < 4; ++e) {
+                    int q0 = quant_one(h2f((uint16_t)(w[e] & 0xffffu)), s);
+                    int q1 = quant_one(h2f((uint16_t)(w[e] >> 16)), s);
+                    o[e >> 1] |= (unsigned)(q0 | (q1 << 8)) << ((e & 1) * 16);
+                }
+                dst[idx] = make_uint2(o[0], o[1]);
             }
-            dst[idx] = make_uint2(o[0], o[1]);
         }
     }
 
