@@ -171,6 +171,18 @@ MIXQ_API int mixq_dequantization(void* out_f16, const int32_t* x, const void* sc
 MIXQ_API int mixq_w8a16_gemm_forward(const void* input_f16, const uint8_t* weight, const void* scale_f16,
                                      void* output_f16, int m, int n, int k, void* stream);
 
+/* ---- dynamic outliers of the P-flavour forward (MixQ/src/mixquant/modules/linear.py) ------------- */
+/* FindOutliers (linear.py:155-161): torch.unique(torch.where(A.abs() > sigma)[1]) -> ascending int32 column indices of
+ * fp16 A [M,K] that hold at least one |a| > sigma (NaN compares false).  `mask_ws` = device scratch of
+ * mixq_find_outliers_workspace_size(K) bytes; at most `capacity` indices are written to ind_out, *count_out (device
+ * int32) receives the true count.  Asynchronous on `stream`; K % 8 == 0, A 16-byte aligned. */
+MIXQ_API size_t mixq_find_outliers_workspace_size(int K);
+MIXQ_API int mixq_find_outliers(const void* A_f16, int M, int K, float sigma, void* mask_ws, int32_t* ind_out,
+                                int32_t* count_out, int capacity, void* stream);
+/* weight_cache columns (linear.py:207-209): out[n,j] = fp16( fp16(q_weight[n, ind[j]]) * scale_col[n] ), fp16 [N,len]. */
+MIXQ_API int mixq_dequant_weight_columns(const int8_t* q_weight, const void* scale_col_f16, const int32_t* ind, int len,
+                                         void* out_f16, int N, int K, void* stream);
+
 /* ---- host helpers ----------------------------------------------------------------------------- */
 /* preprocess_weights (weightonlykernel/cutlass_kernels/cutlass_preprocessors.cc:536-545), int8, arch 80-90:
  * row-major int8 [rows=K, cols=N] -> interleaved uint8.  Host memory.  And its inverse. */

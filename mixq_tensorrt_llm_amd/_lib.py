@@ -83,6 +83,9 @@ SIGNATURES = {
     "mixq_extract_outliers": (_i, [_i, _i, _vp, _vp, _vp, _i, _vp]),
     "mixq_extract_outliers_set_zero": (_i, [_i, _i, _vp, _vp, _vp, _i, _vp]),
     "mixq_quant_extract": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "mixq_find_outliers_workspace_size": (ctypes.c_size_t, [_i]),
+    "mixq_find_outliers": (_i, [_vp, _i, _i, ctypes.c_float, _vp, _vp, _vp, _i, _vp]),
+    "mixq_dequant_weight_columns": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _vp]),
     "mixq_int8_quantize_with_scale": (_i, [_i, _i, _vp, _vp, _vp, _vp]),
     "mixq_rmsnorm": (_i, [_i, _i, _vp, _vp, _vp, ctypes.c_float, _vp]),
     "mixq_rmsnorm_extract_quant": (_i, [_i, _i, _vp, _vp, _vp, ctypes.c_float, _vp, _i, _vp, _vp, _vp, _vp]),

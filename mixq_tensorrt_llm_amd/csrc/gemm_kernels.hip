@@ -343,12 +343,24 @@ __global__ __launch_bounds__(256) void gemm_fp16_kernel(const uint16_t* __restri
     for (int k0 = 0; k0 < O; k0 += 16) {
         const int k = k0 + lh * 8;
         v8h xf, yf;
-        if (k + 8 <= O) {
-            xf = *reinterpret_cast<const v8h*>(fpW + (int64_t)nrow * O + k);
-            yf = *reinterpret_cast<const v8h*>(fpA + (int64_t)mrow * O + k);
-        } else {
+        if ((O & 7) == 0) { // rows are 16-byte aligned: vector loads (k + 8 <= O always holds for k < O)
+            if (k < O) {
+                xf = *reinterpret_cast<const v8h*>(fpW + (int64_t)nrow * O + k);
+                yf = *reinterpret_cast<const v8h*>(fpA + (int64_t)mrow * O + k);
+            } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) xf[e] = (_Float16)0.f, yf[e] = (_Float16)0.f;
+                for (int e = 0; e < 8; ++e) xf[e] = (_Float16)0.f, yf[e] = (_Float16)0.f;
+            }
+        } else { // any O (dynamic outlier sets of the P-flavour): element loads with a zero tail
+            uint16_t xb[8], yb[8]; // (arrays, not vector-element lvalues: see mixq_device.h on __builtin_bit_cast)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool ok = k + e < O;
+                xb[e] = ok ? fpW[(int64_t)nrow * O + k + e] : (uint16_t)0;
+                yb[e] = ok ? fpA[(int64_t)mrow * O + k + e] : (uint16_t)0;
+            }
+            __builtin_memcpy(&xf, xb, 16);
+            __builtin_memcpy(&yf, yb, 16);
         }
         P = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf, yf, P, 0, 0, 0);
     }

@@ -273,6 +273,28 @@ int mixq_extract_outliers_set_zero(int M, int K, void* A, void* fpA, const int32
     return hip_rc(mixq::launch_extract(A, fpA, ind, M, K, len, true, static_cast<hipStream_t>(stream)));
 }
 
+size_t mixq_find_outliers_workspace_size(int K) { return K > 0 ? (size_t)((K + 31) / 32) * 4 : 0; }
+
+int mixq_find_outliers(const void* A, int M, int K, float sigma, void* mask_ws, int32_t* ind_out, int32_t* count_out,
+                       int capacity, void* stream)
+{
+    if (M < 0 || K <= 0 || capacity < 0 || !mask_ws || !count_out || (capacity > 0 && !ind_out) || (M > 0 && !A))
+        return MIXQ_E_BADARG;
+    if (K % 8) return MIXQ_E_SHAPE;
+    if (M > 0 && !aligned16(A)) return MIXQ_E_ALIGN;
+    return hip_rc(mixq::launch_find_outliers(A, M, K, sigma, static_cast<unsigned*>(mask_ws), ind_out, count_out,
+                                             capacity, static_cast<hipStream_t>(stream)));
+}
+
+int mixq_dequant_weight_columns(const int8_t* q_weight, const void* scale_col, const int32_t* ind, int len, void* out,
+                                int N, int K, void* stream)
+{
+    if (N < 0 || K <= 0 || len < 0 || (N > 0 && len > 0 && (!q_weight || !scale_col || !ind || !out)))
+        return MIXQ_E_BADARG;
+    return hip_rc(mixq::launch_dequant_columns(q_weight, scale_col, ind, len, out, N, K,
+                                               static_cast<hipStream_t>(stream)));
+}
+
 int mixq_quant_extract(int M, int K, void* A, int8_t* qA, void* sA, void* fpA, const int32_t* ind, int len,
                        int zero_outliers, void* stream)
 {
@@ -392,8 +414,9 @@ int mixq_gemm_fp16(const void* fpA, const void* fpW, void* Out, int M, int N, in
     if (M < 0 || N < 0 || O < 0) return MIXQ_E_BADARG;
     if (M == 0 || N == 0) return MIXQ_OK;
     if (!fpA || !fpW || !Out) return MIXQ_E_BADARG;
-    if (O % 8 || N % 4) return MIXQ_E_SHAPE;
-    if (!aligned16(fpA) || !aligned16(fpW) || !aligned16(Out)) return MIXQ_E_ALIGN;
+    if (N % 4) return MIXQ_E_SHAPE; // any O: rows of odd length take the element-load path
+    if ((O % 8 == 0 && (!aligned16(fpA) || !aligned16(fpW))) || (reinterpret_cast<uintptr_t>(Out) & 7u))
+        return MIXQ_E_ALIGN;
     return hip_rc(mixq::launch_gemm_fp16(fpA, fpW, Out, M, N, O, static_cast<hipStream_t>(stream)));
 }
 

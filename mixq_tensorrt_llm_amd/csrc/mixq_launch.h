@@ -38,6 +38,10 @@ hipError_t launch_quant_with_scale(const void* src, const void* scale, int8_t* d
 hipError_t launch_extract(void* A, void* fpA, const int32_t* ind, int M, int K, int O, bool zero, hipStream_t st);
 hipError_t launch_rmsnorm_quant(const void* X, const void* gamma, void* out, void* outl, const int32_t* ind, int8_t* q,
                                 void* scale, float eps, int M, int K, int O, bool quant, hipStream_t st);
+hipError_t launch_find_outliers(const void* A, int M, int K, float sigma, unsigned* mask, int32_t* ind, int32_t* count,
+                                int capacity, hipStream_t st);
+hipError_t launch_dequant_columns(const int8_t* W, const void* sW, const int32_t* ind, int len, void* out, int N, int K,
+                                  hipStream_t st);
 hipError_t launch_w8a16(const void* A, const uint8_t* Wq, const void* scale, void* Out, int M, int N, int K,
                         hipStream_t st);
 

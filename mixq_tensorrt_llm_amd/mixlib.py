@@ -53,7 +53,7 @@ def ExtractOutliersAndSetToZeros(ind, input):
 
 
 def _fused(name, A, B, scale_row, scale_col, y, M, N, K):
-    _dev(A, B, scale_row, scale_col, y)
+    _dev(*(t for t in (A, B, scale_row, scale_col, y) if t is not None))  # y = None: no addend (zeros in the reference)
     D = torch.empty((M, N), dtype=torch.float16, device=A.device)
     fn = getattr(_lib.load(), name)
     _lib.check(fn(_p(A), _p(B), _p(scale_row), _p(scale_col), _p(y), _p(D), M, N, K, None, _st(A)), name)

@@ -1,0 +1,183 @@
+"""P-flavour MixQ linear with DYNAMIC outlier detection (reference: MixQ/src/mixquant/modules/linear.py:24-286,
+MixQ/src/mixquant/Cache.py:5-24) on MI355X.
+
+``MixLinear_GEMM`` keeps the reference's state machine: int8 ``q_weight`` [N,K] with per-row ``scale_col``; an outlier
+index set ``ind`` that starts empty and grows while ``add_outliers`` is on (the first ``cache.stop`` calls, until more
+than 256 columns are collected): whenever some row scale exceeds ``sigma / 127``, the columns holding an |a| > sigma are
+found, moved out of the int8 path (zeroed in the activation, their weights dequantised into ``weight_cache``), and the
+rows are re-quantised.  The product is  fp16(float(qA . qW^T) * (scale_col * x_scale) + outliers . weight_cache^T).
+
+Every tensor op of the forward is a launch of libmixq_mi355x.so (no torch.mm / torch.where / torch.unique on the data
+path): FindOutliers -> `mixq_find_outliers`, weight_cache columns -> `mixq_dequant_weight_columns`, the outlier product
+-> `mixq_gemm_fp16`, the rest are the mixlib ops.  torch is used for allocation, `hstack` of the growing state and the
+quantize-time `from_linear` (like the reference).  bit = 8 only (the 4-bit branch is SURVEY §8f "next").
+"""
+import ctypes
+
+import torch
+
+from . import _lib, mixlib
+
+
+def _st(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def find_outliers(activation: torch.Tensor, sigma: float, capacity: int = None) -> torch.Tensor:
+    """linear.py:155-161 ``torch.unique(torch.where(A.abs() > sigma)[1]).to(int32)``: ascending column indices."""
+    assert activation.is_cuda and activation.dtype == torch.float16 and activation.dim() == 2
+    a = activation.contiguous()
+    m, k = a.shape
+    cap = k if capacity is None else capacity
+    lib = _lib.load()
+    ws = torch.empty((lib.mixq_find_outliers_workspace_size(k) + 3) // 4, dtype=torch.int32, device=a.device)
+    ind = torch.empty(cap, dtype=torch.int32, device=a.device)
+    cnt = torch.zeros(1, dtype=torch.int32, device=a.device)
+    _lib.check(lib.mixq_find_outliers(_p(a), m, k, ctypes.c_float(float(sigma)), _p(ws), _p(ind), _p(cnt), cap, _st(a)),
+               "find_outliers")
+    n = int(cnt.item())  # the reference's torch.unique synchronises too (data-dependent output size)
+    return ind[: min(n, cap)]
+
+
+def dequant_weight_columns(q_weight: torch.Tensor, scale_col: torch.Tensor, ind: torch.Tensor) -> torch.Tensor:
+    """linear.py:207-209 ``q_weight[:, ind].to(float16) * scale_col.T`` -> fp16 [N, len(ind)]."""
+    assert q_weight.is_cuda and q_weight.dtype == torch.int8 and ind.dtype == torch.int32
+    n, k = q_weight.shape
+    out = torch.empty((n, ind.shape[0]), dtype=torch.float16, device=q_weight.device)
+    _lib.check(_lib.load().mixq_dequant_weight_columns(_p(q_weight), _p(scale_col), _p(ind), ind.shape[0], _p(out), n,
+                                                       k, _st(q_weight)), "dequant_weight_columns")
+    return out
+
+
+def outlier_product(activation_outliers: torch.Tensor, weight_cache: torch.Tensor) -> torch.Tensor:
+    """linear.py:241 ``torch.mm(activation_outliers, weight_cache.T)``: fp16 out, fp32 accumulate."""
+    m, o = activation_outliers.shape
+    n = weight_cache.shape[0]
+    out = torch.empty((m, n), dtype=torch.float16, device=activation_outliers.device)
+    _lib.check(_lib.load().mixq_gemm_fp16(_p(activation_outliers.contiguous()), _p(weight_cache.contiguous()), _p(out),
+                                          m, n, o, _st(out)), "gemm_fp16")
+    return out
+
+
+class MixLibCache:
+    """Cache.py:5-24: per-model scratch shared by the layers (row scales, sigma, the running outlier state)."""
+
+    def __init__(self, inputdim=1024, sigma=6, bit=8, device="cuda"):
+        self.device = device
+        self.x_scale = torch.zeros((inputdim, 1), dtype=torch.float16, device=device)
+        self.sigma = torch.zeros((1, 1), dtype=torch.float16, device=device)
+        self.sigma[0] = sigma
+        self.zeros = None  # (the reference keeps an [inputdim, 36864] zero matrix as the "no outliers" addend; a null
+        #                     addend is passed to the fused GEMM instead)
+        self.ind = None
+        self.new_ind = None
+        self.shape = None
+        self.activation_outliers = None
+        self.q_xcache = None
+        self.is_prefill = False
+        self.bit = bit
+        self.max_outliers = 256
+        self.stop = 2
+
+
+class MixLinear_GEMM:
+    """linear.py:24-286, bit = 8 (and the weight_only W8A16 mode)."""
+
+    def __init__(self, in_features, out_features, bias, dev, bit=8, weight_only=False, cache=None):
+        assert bit == 8, "the 4-bit branch is not built (SURVEY §8f)"
+        self.in_features, self.out_features, self.bit = in_features, out_features, bit
+        self.weight_only = weight_only
+        self.cache = cache
+        if weight_only:
+            self.q_weight = torch.empty((in_features, out_features), dtype=torch.uint8, device=dev)
+            self.scale_col = torch.empty((out_features,), dtype=torch.float16, device=dev)
+        else:
+            self.scale_col = torch.empty((1, out_features), dtype=torch.float16, device=dev)
+            self.q_weight = torch.empty((out_features, in_features), dtype=torch.int8, device=dev)
+            self.ind = torch.zeros((0,), dtype=torch.int32, device=dev)
+            self.weight_cache = None
+        self.bias = torch.empty((out_features,), dtype=torch.float16, device=dev) if bias else None
+        self.cnt = 0
+        self.add_outliers = True
+        self.sigma = None
+        if cache is not None:
+            self.sigma = torch.ones((1, 1), dtype=torch.float16, device=dev)
+            self.sigma[0] = cache.sigma[0]
+
+    @classmethod
+    def from_linear(cls, weight, bias=None, bit=8, weight_only=False, cache=None, dev="cuda"):
+        """linear.py:88-149 (``linear.weight`` fp16 [N,K], optional bias)."""
+        n, k = weight.shape
+        q = cls(k, n, bias is not None, dev, bit=bit, weight_only=weight_only, cache=cache)
+        if weight_only:  # :102-106 EETQ quant_weights of W^T
+            from . import pack
+            qweight, scales, _ = pack.eetq_quant_weights(weight.t().contiguous())
+            q.q_weight.copy_(qweight.to(dev))
+            q.scale_col.copy_(scales.to(dev))
+        else:            # :113-120: scale = fp16(max|w| / 127) per row; q = round(w / scale) (no clamp)
+            w = weight.to(dev)
+            scale = (torch.max(torch.abs(w), dim=1)[0].unsqueeze(1) / 127).to(torch.float16).reshape((1, n))
+            q.scale_col.copy_(scale)
+            tmp = w.clone()
+            tmp /= q.scale_col.T
+            q.q_weight.copy_(tmp.round().to(torch.int8))
+        if bias is not None:
+            q.bias.copy_(bias.to(dev).half())
+        return q
+
+    def FindOutliers(self, activation):
+        """linear.py:155-161."""
+        return find_outliers(activation, float(self.sigma[0, 0]))
+
+    @torch.no_grad()
+    def forward(self, x, cache=None, unfused=True):
+        """linear.py:163-286.  ``unfused=True`` quantises ``x`` here (the fused variant gets q_xcache / x_scale /
+        activation_outliers from the preceding norm layer through the cache, exactly like the reference)."""
+        cache = self.cache if cache is None else cache
+        cache.shape = x.shape[:-1] + (self.out_features,)
+        inputs = x.reshape(-1, x.shape[-1])
+        M = inputs.shape[0]
+        if self.weight_only:
+            y = mixlib.w8_a16_gemm(inputs, self.q_weight, self.scale_col)
+            if self.bias is not None:
+                y += self.bias
+            return y.reshape(cache.shape)
+
+        if unfused:
+            if self.ind.shape[0]:
+                cache.activation_outliers = mixlib.ExtractOutliersAndSetToZeros(self.ind, inputs)
+            cache.q_xcache = mixlib.FindRowScale(inputs, cache.x_scale, M, self.in_features, self.bit)
+        cache.ind = self.ind
+
+        if self.add_outliers:
+            # :201 (a device->host read of one scalar, like the reference's `if tensor > tensor`)
+            if bool(cache.x_scale[0:M].max() > self.sigma / (2 ** (self.bit - 1) - 1)):
+                ind = self.FindOutliers(inputs)
+                cache.new_ind = ind
+                activation_outliers = mixlib.ExtractOutliersAndSetToZeros(ind, inputs)
+                weight_cache = dequant_weight_columns(self.q_weight, self.scale_col, ind)
+                if self.ind.shape[0] == 0:
+                    cache.activation_outliers = activation_outliers
+                    self.weight_cache = weight_cache
+                else:
+                    cache.activation_outliers = torch.hstack((cache.activation_outliers, activation_outliers))
+                    self.weight_cache = torch.hstack((self.weight_cache, weight_cache))
+                self.ind = torch.hstack((self.ind, ind))
+                cache.ind = self.ind
+                cache.q_xcache = mixlib.FindRowScale(inputs, cache.x_scale, M, self.in_features, self.bit)
+            self.cnt += 1
+            if self.cnt >= cache.stop or self.ind.shape[0] > 256:
+                self.add_outliers = False
+
+        y = outlier_product(cache.activation_outliers, self.weight_cache) if self.ind.shape[0] else None
+        y1 = mixlib.int8FusedDequantize(cache.q_xcache, self.q_weight, cache.x_scale, self.scale_col, y, M,
+                                        self.out_features, self.in_features)
+        if self.bias is not None:
+            y1 += self.bias
+        return y1.reshape(cache.shape)
+
+    __call__ = forward

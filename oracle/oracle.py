@@ -16,7 +16,8 @@ __all__ = [
     "build", "lib", "num_threads", "quant_rows", "extract_outliers", "gemm_s8s8s32", "gemm_fp16",
     "dequant_epilogue", "dequantization", "linear_prefill", "weight_scales", "quantize_weight",
     "select_outliers", "pack_linear_weights", "eetq_symmetric_quantize", "eetq_preprocess", "w8a16_gemv",
-    "int_to_half", "int8_matrix_to_half", "rmsnorm_extract_quant",
+    "int_to_half", "int8_matrix_to_half", "rmsnorm_extract_quant", "find_outliers", "dequant_weight_columns",
+    "MixLinearState", "mixlinear_forward",
 ]
 
 
@@ -247,3 +248,72 @@ def rmsnorm_extract_quant(x, gamma, eps, ind=None):
     lib().mixq_oracle_rmsnorm_extract_quant(_i64(M), _i64(K), _p(x), _p(gamma), ctypes.c_float(eps), _p(ind),
                                             ctypes.c_int(ind.size), _p(out), _p(outl), _p(q), _p(sc))
     return out, outl, q, sc
+
+
+# ---- P-flavour forward with dynamic outliers (MixQ/src/mixquant/modules/linear.py:155-286), numpy restatement ----
+def find_outliers(A, sigma):
+    """linear.py:155-161: torch.unique(torch.where(A.abs() > sigma)[1]).to(int32); fp16 compare, NaN -> False."""
+    A = _h(A)
+    with np.errstate(invalid="ignore"):
+        hit = np.abs(A) > np.float16(sigma)
+    return np.unique(np.where(hit)[1]).astype(np.int32)
+
+
+def dequant_weight_columns(q_weight, scale_col, ind):
+    """linear.py:207-209: q_weight[:, ind].to(float16) * scale_col.T  (fp16 x fp16 -> fp16, one rounding)."""
+    q_weight = np.ascontiguousarray(q_weight, np.int8)
+    s = _h(scale_col).reshape(-1, 1)
+    return (q_weight[:, np.asarray(ind, np.int64)].astype(np.float16) * s).astype(np.float16)
+
+
+class MixLinearState:
+    """The mutable state of one MixLinear_GEMM layer + its cache, for `mixlinear_forward` (bit = 8)."""
+
+    def __init__(self, q_weight, scale_col, sigma=6.0, stop=2, bias=None):
+        self.q_weight = np.ascontiguousarray(q_weight, np.int8)
+        self.scale_col = _h(scale_col).reshape(-1)
+        self.sigma = np.float16(sigma)
+        self.stop = stop
+        self.bias = None if bias is None else _h(bias)
+        self.ind = np.zeros((0,), np.int32)
+        self.weight_cache = None
+        self.cnt = 0
+        self.add_outliers = True
+
+
+def mixlinear_forward(st, x):
+    """linear.py:163-286 with unfused=True (quantisation inside the layer).  Mutates `st` and zeroes the outlier columns
+    of `x` in place, exactly like the reference mutates its input.  Returns fp16 [M, N]."""
+    assert x.dtype == np.float16 and x.flags.c_contiguous and x.ndim == 2
+    act_out = None
+    if st.ind.size:
+        act_out = extract_outliers(x, st.ind, set_zero=True)
+    qx, xs = quant_rows(x)
+    if st.add_outliers:
+        # :201  x_scale.max() > sigma / 127 (fp16 tensor ops; NaN scales make the comparison False or propagate as in torch.max)
+        thr = np.float16(st.sigma / np.float16(127))
+        with np.errstate(invalid="ignore"):
+            mx = np.max(xs) if not np.isnan(xs).any() else np.float16(np.nan)
+            trig = bool(mx > thr)
+        if trig:
+            ind = find_outliers(x, st.sigma)
+            new_out = extract_outliers(x, ind, set_zero=True)
+            wc = dequant_weight_columns(st.q_weight, st.scale_col, ind)
+            if st.ind.size == 0:
+                act_out, st.weight_cache = new_out, wc
+            else:
+                act_out = np.hstack((act_out, new_out))
+                st.weight_cache = np.hstack((st.weight_cache, wc))
+            st.ind = np.hstack((st.ind, ind)).astype(np.int32)
+            qx, xs = quant_rows(x)
+        st.cnt += 1
+        if st.cnt >= st.stop or st.ind.size > 256:
+            st.add_outliers = False
+    acc = gemm_s8s8s32(qx, st.q_weight)
+    y = None
+    if st.ind.size:
+        y = gemm_fp16(np.ascontiguousarray(act_out), np.ascontiguousarray(st.weight_cache))
+    out = dequant_epilogue(acc, xs, st.scale_col, C=y)
+    if st.bias is not None:
+        out = (out + st.bias[None, :]).astype(np.float16)
+    return out

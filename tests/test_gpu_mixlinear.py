@@ -1,0 +1,134 @@
+"""GPU (-m gpu): P-flavour `MixLinear_GEMM` with dynamic outlier detection (MixQ/src/mixquant/modules/linear.py:155-286)
+through the C ABI, against the oracle's numpy restatement of the same state machine."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+REL_TOL = 1e-3
+
+
+def rel_err(got, want):
+    g, w = got.astype(np.float64), want.astype(np.float64)
+    return np.abs(g - w).max() / max(np.abs(w).max(), 1e-30)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+
+
+@pytest.mark.parametrize("M,K", [(1, 64), (7, 4096), (333, 4096), (1024, 11008), (64, 32768 + 64)])
+def test_find_outliers_matches_unique_where(oracle, M, K):
+    from mixq_tensorrt_llm_amd import mixlinear
+    rng = np.random.default_rng(M * 7 + K)
+    A = rng.standard_normal((M, K)).astype(np.float16)
+    cols = rng.choice(K, size=min(K, 37), replace=False)
+    A[rng.integers(0, M, cols.size), cols] = np.float16(9.5) * rng.choice([-1, 1], cols.size)
+    A[0, K - 1] = np.float16(-6.01)          # just above sigma, last column
+    A[M - 1, 0] = np.float16(6.0)            # == sigma: NOT an outlier (strict >)
+    if M > 2:
+        A[1, 5] = np.nan                     # NaN never compares greater
+        A[2, 9] = np.inf
+    got = mixlinear.find_outliers(dev(A), 6.0).cpu().numpy()
+    want = oracle.find_outliers(A, 6.0)
+    assert got.dtype == np.int32 and np.array_equal(got, want)
+    # capacity smaller than the set: the first `capacity` indices, no overflow
+    cap = max(1, want.size // 2)
+    assert np.array_equal(mixlinear.find_outliers(dev(A), 6.0, capacity=cap).cpu().numpy(), want[:cap])
+    # nothing above sigma -> empty
+    assert mixlinear.find_outliers(dev(np.zeros((M, K), np.float16)), 6.0).numel() == 0
+
+
+def test_dequant_weight_columns_bit_exact(oracle):
+    from mixq_tensorrt_llm_amd import mixlinear
+    rng = np.random.default_rng(5)
+    N, K = 1000, 4096
+    W = rng.integers(-128, 128, (N, K), dtype=np.int8)
+    s = (rng.random(N) * 1e-2 + 1e-4).astype(np.float16)
+    ind = np.sort(rng.choice(K, 77, replace=False)).astype(np.int32)
+    got = mixlinear.dequant_weight_columns(dev(W), dev(s.reshape(1, N)), dev(ind)).cpu().numpy()
+    want = oracle.dequant_weight_columns(W, s, ind)
+    assert np.array_equal(got.view(np.uint16), want.view(np.uint16))
+
+
+@pytest.mark.parametrize("odd_o", [37, 136, 129])
+def test_outlier_product_any_width(oracle, odd_o):
+    """The side product of a dynamic outlier set has an arbitrary width O (not a multiple of 8)."""
+    from mixq_tensorrt_llm_amd import mixlinear
+    rng = np.random.default_rng(odd_o)
+    a = (rng.standard_normal((70, odd_o)) * 8).astype(np.float16)
+    w = (rng.standard_normal((96, odd_o)) * 0.02).astype(np.float16)
+    got = mixlinear.outlier_product(dev(a), dev(w)).cpu().numpy()
+    assert rel_err(got, oracle.gemm_fp16(a, w)) < REL_TOL
+
+
+def make_layer(rng, N, K, bias):
+    W = (rng.standard_normal((N, K)) * 0.02).astype(np.float16)
+    b = (rng.standard_normal(N) * 0.1).astype(np.float16) if bias else None
+    return W, b
+
+
+@pytest.mark.parametrize("bias", [False, True])
+def test_mixlinear_dynamic_outliers_state_machine(oracle, bias):
+    """Three forwards: call 1 finds outlier set S1, call 2 extends it with new columns (hstack order), call 3 runs with
+    the frozen set (cache.stop = 2).  ind / weight_cache / output follow the oracle at every step; x is mutated (its
+    outlier columns zeroed) like in the reference."""
+    from mixq_tensorrt_llm_amd import mixlinear
+    rng = np.random.default_rng(11)
+    N, K, M = 512, 1024, 48
+    W, b = make_layer(rng, N, K, bias)
+    cache = mixlinear.MixLibCache(inputdim=1024, sigma=6, device="cuda:0")
+    layer = mixlinear.MixLinear_GEMM.from_linear(torch.from_numpy(W), None if b is None else torch.from_numpy(b),
+                                                 cache=cache, dev="cuda:0")
+    # from_linear parity: scale / int8 weight (linear.py:113-120)
+    sc = (np.abs(W).max(axis=1) / np.float16(127)).astype(np.float16)
+    assert np.array_equal(layer.scale_col.cpu().numpy().reshape(-1).view(np.uint16), sc.view(np.uint16))
+    qw = np.rint(W.astype(np.float16) / sc[:, None]).astype(np.int8)
+    assert np.array_equal(layer.q_weight.cpu().numpy(), qw)
+    st = oracle.MixLinearState(qw, sc, sigma=6.0, stop=2, bias=b)
+
+    sets = [[3, 500, 77], [900, 12, 77], [5]]   # column 77 repeats: already zeroed by the first extraction -> not re-found
+    for step, hot in enumerate(sets):
+        x = rng.standard_normal((M, K)).astype(np.float16)
+        x[rng.integers(0, M, len(hot)), hot] = np.float16(20.0)
+        x_ref = x.copy()
+        xt = dev(x)
+        got = layer.forward(xt, cache).cpu().numpy()
+        want = oracle.mixlinear_forward(st, x_ref)
+        assert np.array_equal(layer.ind.cpu().numpy(), st.ind), f"step {step}: outlier index set"
+        assert layer.add_outliers == st.add_outliers and layer.cnt == st.cnt
+        if st.ind.size:
+            assert np.array_equal(layer.weight_cache.cpu().numpy().view(np.uint16), st.weight_cache.view(np.uint16))
+        assert np.array_equal(xt.cpu().numpy().view(np.uint16), x_ref.view(np.uint16)), "input mutation (zeroed outliers)"
+        assert rel_err(got, want) < REL_TOL, f"step {step}"
+    assert st.ind.tolist() == [3, 77, 500, 12, 900]  # sorted within a call, appended across calls; frozen afterwards
+    assert not layer.add_outliers
+
+
+def test_mixlinear_no_outliers_and_3d_input(oracle):
+    from mixq_tensorrt_llm_amd import mixlinear
+    rng = np.random.default_rng(3)
+    N, K = 256, 512
+    W, _ = make_layer(rng, N, K, False)
+    cache = mixlinear.MixLibCache(inputdim=256, sigma=6, device="cuda:0")
+    layer = mixlinear.MixLinear_GEMM.from_linear(torch.from_numpy(W), cache=cache, dev="cuda:0")
+    st = oracle.MixLinearState(layer.q_weight.cpu().numpy(), layer.scale_col.cpu().numpy(), sigma=6.0)
+    x = (rng.standard_normal((2, 9, K)) * 0.5).astype(np.float16)       # nothing above sigma
+    got = layer.forward(dev(x), cache).cpu().numpy()
+    assert got.shape == (2, 9, N)
+    want = oracle.mixlinear_forward(st, x.reshape(-1, K).copy())
+    assert layer.ind.numel() == 0 and rel_err(got.reshape(-1, N), want) < REL_TOL
+
+
+def test_mixlinear_weight_only_mode(oracle):
+    from mixq_tensorrt_llm_amd import mixlinear
+    rng = np.random.default_rng(4)
+    N, K = 512, 1024
+    W, _ = make_layer(rng, N, K, False)
+    layer = mixlinear.MixLinear_GEMM.from_linear(torch.from_numpy(W), weight_only=True,
+                                                 cache=mixlinear.MixLibCache(64, device="cuda:0"), dev="cuda:0")
+    x = rng.standard_normal((3, K)).astype(np.float16)
+    got = layer.forward(dev(x)).cpu().numpy()
+    q_un, scales = oracle.eetq_symmetric_quantize(W.T.copy())
+    assert rel_err(got, oracle.w8a16_gemv(x, q_un, scales)) < 5e-3

@@ -3,6 +3,7 @@ tests/golden/gen_golden.py) and against independent restatements (numpy float16 
 import os
 
 import numpy as np
+import pytest
 
 from conftest import GOLDEN
 
@@ -130,3 +131,28 @@ def test_w8a16_gemv_matches_float64(oracle):
     ref = A.astype(np.float64) @ (q.astype(np.float64) * sc.astype(np.float64)[None, :])
     assert np.allclose(out.astype(np.float64), ref, rtol=2e-2, atol=2e-3)
     assert np.abs(q).max() <= 128 and np.abs(q.astype(np.int32)).max() >= 126
+
+
+def test_dynamic_outlier_helpers_against_the_reference_torch_expressions(oracle):
+    """linear.py:155-161 and :207-209 are plain torch expressions; evaluate them verbatim with CPU torch and compare the
+    oracle's numpy restatement (pins `find_outliers` / `dequant_weight_columns`)."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(21)
+    A = rng.standard_normal((50, 512)).astype(np.float16).clip(-5, 5)
+    A[rng.integers(0, 50, 40), rng.integers(0, 512, 40)] = np.float16(8.25)
+    A[3, 10] = np.nan
+    A[4, 11] = np.inf
+    A[5, 12] = np.float16(6.0)
+    sigma = torch.zeros((1, 1), dtype=torch.float16)
+    sigma[0] = 6
+    At = torch.from_numpy(A)
+    want = torch.unique(torch.where(At.abs() > sigma)[1]).to(torch.int32).numpy()
+    got = oracle.find_outliers(A, 6.0)
+    assert np.array_equal(got, want)
+    assert 11 in got and 12 not in got and 10 not in got   # inf is an outlier; == sigma and NaN are not
+    q = torch.from_numpy(rng.integers(-128, 128, (64, 512), dtype=np.int8))
+    scale_col = torch.from_numpy((rng.random((1, 64)) * 1e-2 + 1e-4).astype(np.float16))
+    ind = torch.from_numpy(want[:17].astype(np.int64))
+    want_wc = (q[:, ind].to(torch.float16) * scale_col.T).numpy()
+    got_wc = oracle.dequant_weight_columns(q.numpy(), scale_col.numpy(), want[:17])
+    assert np.array_equal(got_wc.view(np.uint16), want_wc.view(np.uint16))
