@@ -183,6 +183,31 @@ MIXQ_API int mixq_find_outliers(const void* A_f16, int M, int K, float sigma, vo
 MIXQ_API int mixq_dequant_weight_columns(const int8_t* q_weight, const void* scale_col_f16, const int32_t* ind, int len,
                                          void* out_f16, int N, int K, void* stream);
 
+/* ---- 4-bit (W4A4) flavour: the `bit == 4` branch of MixQ/src/mixquant/modules/linear.py -------------- */
+/* Packed int4 = cutlass::int4b_t pairs in a byte: element 2i in the low nibble, 2i+1 in the high nibble.
+ * FindRowScale(bit = 4) (cult.cu:2515-2567, 2588-2606): scale[m] = fp16(amax / 7), dst[m, i] = int4(rn(x/scale)) pairs;
+ * src fp16 [rows, cols], dst uint8 [rows, cols/2].  cols % 8 == 0. */
+MIXQ_API int mixq_int4quant(int rows, int cols, const void* src_f16, uint8_t* dst_packed, void* scale_f16,
+                            void* stream);
+/* int4FusedDequantize[Silu] (cult.cu:2005-2060, 2119-2181): D = fp16(float(A.B^T) * (scale_col[n]*scale_row[m]) + y)
+ * with A uint8 [M, k_packed], B uint8 [N, k_packed] packed int4, K = 2 * k_packed (the reference also takes the packed
+ * count).  gfx950 has no int4 MFMA: both operands are sign-extended to int8 in `workspace`
+ * (mixq_int4_fused_workspace_size bytes, caller-owned, 16-byte aligned) and the int8 MFMA kernels run on them; the
+ * int32 accumulators are identical.  k_packed % 16 == 0, N % 16 == 0.  y may be NULL (no addend). */
+MIXQ_API size_t mixq_int4_fused_workspace_size(int M, int N, int k_packed);
+MIXQ_API int mixq_int4_fused_dequantize(const uint8_t* A, const uint8_t* B, const void* scale_row, const void* scale_col,
+                                        const void* y, void* D, int M, int N, int k_packed, char* workspace,
+                                        void* stream);
+MIXQ_API int mixq_int4_fused_dequantize_silu(const uint8_t* A, const uint8_t* B, const void* scale_row,
+                                             const void* scale_col, const void* y, void* D, int M, int N, int k_packed,
+                                             char* workspace, void* stream);
+/* unpack_int4_to_fp16 (cult.cu:3020-3043, 3088-3118): out[r, c] = fp16(int4 value of weight[r, ind[c]]),
+ * weight uint8 [rows, cols_packed], out fp16 [rows, n]. */
+MIXQ_API int mixq_unpack_int4_to_fp16(const uint8_t* weight, const int32_t* ind, int rows, int cols_packed, int n,
+                                      void* out_f16, void* stream);
+/* Sign-extending unpack of a packed int4 buffer (packed_bytes % 16 == 0) to int8 -- e.g. once per layer at load time. */
+MIXQ_API int mixq_unpack_int4_to_int8(const uint8_t* src, int8_t* dst, size_t packed_bytes, void* stream);
+
 /* ---- host helpers ----------------------------------------------------------------------------- */
 /* preprocess_weights (weightonlykernel/cutlass_kernels/cutlass_preprocessors.cc:536-545), int8, arch 80-90:
  * row-major int8 [rows=K, cols=N] -> interleaved uint8.  Host memory.  And its inverse. */

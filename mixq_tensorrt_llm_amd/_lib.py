@@ -83,6 +83,12 @@ SIGNATURES = {
     "mixq_extract_outliers": (_i, [_i, _i, _vp, _vp, _vp, _i, _vp]),
     "mixq_extract_outliers_set_zero": (_i, [_i, _i, _vp, _vp, _vp, _i, _vp]),
     "mixq_quant_extract": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "mixq_int4quant": (_i, [_i, _i, _vp, _vp, _vp, _vp]),
+    "mixq_int4_fused_workspace_size": (ctypes.c_size_t, [_i, _i, _i]),
+    "mixq_int4_fused_dequantize": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "mixq_int4_fused_dequantize_silu": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "mixq_unpack_int4_to_fp16": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "mixq_unpack_int4_to_int8": (_i, [_vp, _vp, ctypes.c_size_t, _vp]),
     "mixq_find_outliers_workspace_size": (ctypes.c_size_t, [_i]),
     "mixq_find_outliers": (_i, [_vp, _i, _i, ctypes.c_float, _vp, _vp, _vp, _i, _vp]),
     "mixq_dequant_weight_columns": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _vp]),

@@ -6,7 +6,7 @@ OUT="${HERE}/../libmixq_mi355x.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -fno-fast-math -Wall -Wno-unused-function)
 OBJS=()
-for f in quant_kernels gemm_kernels gemm_pp_kernels gemm_pp2_kernels gemm_skinny_kernels decode_kernels norm_kernels outlier_kernels mixq_api; do
+for f in quant_kernels gemm_kernels gemm_pp_kernels gemm_pp2_kernels gemm_skinny_kernels decode_kernels norm_kernels outlier_kernels int4_kernels mixq_api; do
   src="${HERE}/${f}.hip"; obj="${HERE}/${f}.o"
   if [[ ! -f "$obj" || "$src" -nt "$obj" || "${HERE}/mixq_device.h" -nt "$obj" || "${HERE}/mixq_launch.h" -nt "$obj" || "${HERE}/../../include/mixq.h" -nt "$obj" ]]; then
     "$HIPCC" "${FLAGS[@]}" ${EXTRA_HIPCC_FLAGS:-} -c "$src" -o "$obj" &

@@ -365,6 +365,68 @@ int mixq_int8_fused_dequantize_silu(const int8_t* A, const int8_t* B, const void
     return fused_dequant_impl(A, B, scale_row, scale_col, y, D, M, N, K, mixq::EPI_DEQUANT_SILU, stream);
 }
 
+int mixq_int4quant(int rows, int cols, const void* src, uint8_t* dst, void* scale, void* stream)
+{
+    if (rows < 0 || cols <= 0 || (rows > 0 && (!src || !dst || !scale))) return MIXQ_E_BADARG;
+    if (cols % 8) return MIXQ_E_SHAPE;
+    if (rows > 0 && (!aligned16(src) || (reinterpret_cast<uintptr_t>(dst) & 3u))) return MIXQ_E_ALIGN;
+    return hip_rc(mixq::launch_quant4_rows(src, dst, scale, rows, cols, static_cast<hipStream_t>(stream)));
+}
+
+static size_t align16_up(size_t v) { return (v + 15) & ~static_cast<size_t>(15); }
+
+size_t mixq_int4_fused_workspace_size(int M, int N, int k_packed)
+{
+    if (M < 0 || N < 0 || k_packed < 0) return 0;
+    return align16_up((size_t)M * 2 * k_packed) + align16_up((size_t)N * 2 * k_packed);
+}
+
+static int int4_fused_impl(const uint8_t* A, const uint8_t* B, const void* scale_row, const void* scale_col,
+                           const void* y, void* D, int M, int N, int k_packed, char* workspace, int epi, void* stream)
+{
+    if (M < 0 || N < 0 || k_packed <= 0) return MIXQ_E_BADARG;
+    if (M == 0 || N == 0) return MIXQ_OK;
+    if (!A || !B || !workspace) return MIXQ_E_BADARG;
+    if (k_packed % 16) return MIXQ_E_SHAPE;
+    if (!aligned16(A) || !aligned16(B) || !aligned16(workspace)) return MIXQ_E_ALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int8_t* a8 = reinterpret_cast<int8_t*>(workspace);
+    int8_t* b8 = a8 + align16_up((size_t)M * 2 * k_packed);
+    hipError_t e = mixq::launch_unpack_s4(A, a8, (size_t)M * k_packed, st);
+    if (e == hipSuccess) e = mixq::launch_unpack_s4(B, b8, (size_t)N * k_packed, st);
+    if (e != hipSuccess) return hip_rc(e);
+    return fused_dequant_impl(a8, b8, scale_row, scale_col, y, D, M, N, 2 * k_packed, epi, stream);
+}
+
+int mixq_int4_fused_dequantize(const uint8_t* A, const uint8_t* B, const void* scale_row, const void* scale_col,
+                               const void* y, void* D, int M, int N, int k_packed, char* workspace, void* stream)
+{
+    return int4_fused_impl(A, B, scale_row, scale_col, y, D, M, N, k_packed, workspace, mixq::EPI_DEQUANT, stream);
+}
+
+int mixq_int4_fused_dequantize_silu(const uint8_t* A, const uint8_t* B, const void* scale_row, const void* scale_col,
+                                    const void* y, void* D, int M, int N, int k_packed, char* workspace, void* stream)
+{
+    return int4_fused_impl(A, B, scale_row, scale_col, y, D, M, N, k_packed, workspace, mixq::EPI_DEQUANT_SILU, stream);
+}
+
+int mixq_unpack_int4_to_fp16(const uint8_t* weight, const int32_t* ind, int rows, int cols_packed, int n, void* out,
+                             void* stream)
+{
+    if (rows < 0 || cols_packed <= 0 || n < 0 || (rows > 0 && n > 0 && (!weight || !ind || !out))) return MIXQ_E_BADARG;
+    return hip_rc(mixq::launch_unpack_s4_columns(weight, ind, rows, cols_packed, n, out,
+                                                 static_cast<hipStream_t>(stream)));
+}
+
+int mixq_unpack_int4_to_int8(const uint8_t* src, int8_t* dst, size_t packed_bytes, void* stream)
+{
+    if (packed_bytes == 0) return MIXQ_OK;
+    if (!src || !dst) return MIXQ_E_BADARG;
+    if (packed_bytes % 16) return MIXQ_E_SHAPE;
+    if (!aligned16(src) || !aligned16(dst)) return MIXQ_E_ALIGN;
+    return hip_rc(mixq::launch_unpack_s4(src, dst, packed_bytes, static_cast<hipStream_t>(stream)));
+}
+
 int mixq_gemm_mixed(const int8_t* qA, const int8_t* W, const void* sA, const void* sW, const void* fpA,
                     const void* fpW, void* Out, int M, int N, int K, int O, void* stream)
 {

@@ -42,6 +42,10 @@ hipError_t launch_find_outliers(const void* A, int M, int K, float sigma, unsign
                                 int capacity, hipStream_t st);
 hipError_t launch_dequant_columns(const int8_t* W, const void* sW, const int32_t* ind, int len, void* out, int N, int K,
                                   hipStream_t st);
+hipError_t launch_quant4_rows(const void* A, uint8_t* q, void* sA, int M, int K, hipStream_t st);
+hipError_t launch_unpack_s4(const uint8_t* src, int8_t* dst, size_t packed_bytes, hipStream_t st);
+hipError_t launch_unpack_s4_columns(const uint8_t* weight, const int32_t* ind, int rows, int cols_packed, int n,
+                                    void* out, hipStream_t st);
 hipError_t launch_w8a16(const void* A, const uint8_t* Wq, const void* scale, void* Out, int M, int N, int K,
                         hipStream_t st);
 

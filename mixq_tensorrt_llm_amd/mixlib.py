@@ -13,7 +13,8 @@ from . import _lib
 __all__ = ["FindRowScale", "ExtractOutliersAndSetToZeros", "int8FusedDequantize", "int8FusedDequantizeSilu", "gemm",
            "dequantizeInt8", "Int8quantize", "FindRowScaleFusedExtracOutliers", "layernorm_forward_cuda",
            "layernorm_forward_cuda_extract_outliers", "int_to_half", "int_matrix_to_half",
-           "int8_matrix_to_half", "w8_a16_gemm", "preprocess_weights", "mixq_linear"]
+           "int8_matrix_to_half", "w8_a16_gemm", "preprocess_weights", "mixq_linear", "int4FusedDequantize",
+           "int4FusedDequantizeSilu", "unpack_int4_to_fp16"]
 
 
 def _st(t):
@@ -33,8 +34,13 @@ def _dev(*ts):
 
 def FindRowScale(x, scaleRow, rows, cols, bit=8):
     """cult.cu:2569-2608.  Writes the per-row fp16 scale into ``scaleRow`` and returns the int8 rows."""
-    assert bit == 8, "only the 8-bit path is on the int8_mix hot path (int4 is SURVEY §8f 'next')"
     _dev(x, scaleRow)
+    if bit == 4:  # cult.cu:2588-2606: packed int4 pairs, scale = amax / 7
+        assert cols % 2 == 0
+        out = torch.empty((rows, cols // 2), dtype=torch.uint8, device=x.device)
+        _lib.check(_lib.load().mixq_int4quant(rows, cols, _p(x), _p(out), _p(scaleRow), _st(x)), "FindRowScale(4)")
+        return out
+    assert bit == 8
     out = torch.empty((rows, cols), dtype=torch.int8, device=x.device)
     _lib.check(_lib.load().mixq_int8quant(rows, cols, _p(x), _p(out), _p(scaleRow), _st(x)), "FindRowScale")
     return out
@@ -68,6 +74,39 @@ def int8FusedDequantize(A, B, scale_row, scale_col, y, M, N, K):
 def int8FusedDequantizeSilu(A, B, scale_row, scale_col, y, M, N, K):
     """cult.cu:2067-2117: same with SiLU applied before the fp16 rounding."""
     return _fused("mixq_int8_fused_dequantize_silu", A, B, scale_row, scale_col, y, M, N, K)
+
+
+def _fused4(name, A, B, scale_row, scale_col, y, M, N, K):
+    _dev(*(t for t in (A, B, scale_row, scale_col, y) if t is not None))
+    lib = _lib.load()
+    D = torch.empty((M, N), dtype=torch.float16, device=A.device)
+    ws = torch.empty(max(16, lib.mixq_int4_fused_workspace_size(M, N, K)), dtype=torch.uint8, device=A.device)
+    _lib.check(getattr(lib, name)(_p(A), _p(B), _p(scale_row), _p(scale_col), _p(y), _p(D), M, N, K, _p(ws), _st(A)),
+               name)
+    return D
+
+
+def int4FusedDequantize(A, B, scale_row, scale_col, y, M, N, K):
+    """cult.cu:2005-2060: packed-int4 A [M,K] / B [N,K] (K = packed bytes per row = in_features // 2, as the reference
+    passes it).  No int4 MFMA on gfx950: operands are sign-extended to int8 and run on the int8 kernels (same int32)."""
+    return _fused4("mixq_int4_fused_dequantize", A, B, scale_row, scale_col, y, M, N, K)
+
+
+def int4FusedDequantizeSilu(A, B, scale_row, scale_col, y, M, N, K):
+    """cult.cu:2119-2181."""
+    return _fused4("mixq_int4_fused_dequantize_silu", A, B, scale_row, scale_col, y, M, N, K)
+
+
+def unpack_int4_to_fp16(weight, ind):
+    """cult.cu:3088-3118: fp16 [rows, len(ind)] = the int4 values of columns `ind` of packed `weight` [rows, cols/2]."""
+    _dev(weight, ind)
+    assert weight.dtype == torch.uint8 and ind.dtype == torch.int32
+    rows, colsp = weight.shape
+    n = ind.shape[0]
+    out = torch.zeros((rows, n), dtype=torch.float16, device=weight.device)
+    _lib.check(_lib.load().mixq_unpack_int4_to_fp16(_p(weight), _p(ind), rows, colsp, n, _p(out), _st(weight)),
+               "unpack_int4_to_fp16")
+    return out
 
 
 def gemm(mat1, mat2, m, n, k):

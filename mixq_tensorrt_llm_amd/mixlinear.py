@@ -10,7 +10,8 @@ rows are re-quantised.  The product is  fp16(float(qA . qW^T) * (scale_col * x_s
 Every tensor op of the forward is a launch of libmixq_mi355x.so (no torch.mm / torch.where / torch.unique on the data
 path): FindOutliers -> `mixq_find_outliers`, weight_cache columns -> `mixq_dequant_weight_columns`, the outlier product
 -> `mixq_gemm_fp16`, the rest are the mixlib ops.  torch is used for allocation, `hstack` of the growing state and the
-quantize-time `from_linear` (like the reference).  bit = 8 only (the 4-bit branch is SURVEY §8f "next").
+quantize-time `from_linear` (like the reference).  bit = 8 and bit = 4 (W4A4: packed int4 storage, sign-extended to
+int8 for the MFMA kernels -- gfx950 has no int4 matrix instruction) and the weight-only W8A16 mode.
 """
 import ctypes
 
@@ -53,6 +54,17 @@ def dequant_weight_columns(q_weight: torch.Tensor, scale_col: torch.Tensor, ind:
     return out
 
 
+def two_compl(x: torch.Tensor, bits: int) -> torch.Tensor:
+    """linear.py:11-12."""
+    return torch.where(x < 0, 2 ** bits + x, x)
+
+
+def pack_to_i4(X: torch.Tensor) -> torch.Tensor:
+    """linear.py:13-17: int8 values in [-8, 7] -> packed pairs, even column in the low nibble."""
+    X_i8 = two_compl(X.to(dtype=torch.int8), 4).to(torch.uint8)
+    return X_i8[:, 0::2] | (X_i8[:, 1::2] << 4)
+
+
 def outlier_product(activation_outliers: torch.Tensor, weight_cache: torch.Tensor) -> torch.Tensor:
     """linear.py:241 ``torch.mm(activation_outliers, weight_cache.T)``: fp16 out, fp32 accumulate."""
     m, o = activation_outliers.shape
@@ -85,11 +97,13 @@ class MixLibCache:
 
 
 class MixLinear_GEMM:
-    """linear.py:24-286, bit = 8 (and the weight_only W8A16 mode)."""
+    """linear.py:24-286: bit = 8, bit = 4 and the weight_only W8A16 mode."""
 
-    def __init__(self, in_features, out_features, bias, dev, bit=8, weight_only=False, cache=None):
-        assert bit == 8, "the 4-bit branch is not built (SURVEY §8f)"
+    def __init__(self, in_features, out_features, bias, dev, bit=8, weight_only=False, cache=None,
+                 fp_features_num=256):
+        assert bit in (8, 4)
         self.in_features, self.out_features, self.bit = in_features, out_features, bit
+        self.fp_features_num = fp_features_num
         self.weight_only = weight_only
         self.cache = cache
         if weight_only:
@@ -97,9 +111,14 @@ class MixLinear_GEMM:
             self.scale_col = torch.empty((out_features,), dtype=torch.float16, device=dev)
         else:
             self.scale_col = torch.empty((1, out_features), dtype=torch.float16, device=dev)
-            self.q_weight = torch.empty((out_features, in_features), dtype=torch.int8, device=dev)
-            self.ind = torch.zeros((0,), dtype=torch.int32, device=dev)
-            self.weight_cache = None
+            if bit == 8:
+                self.q_weight = torch.empty((out_features, in_features), dtype=torch.int8, device=dev)
+                self.ind = torch.zeros((0,), dtype=torch.int32, device=dev)
+                self.weight_cache = None
+            else:  # :44-54: packed int4 weights + a static set of fp_features_num fp16 outlier columns
+                self.q_weight = torch.empty((out_features, in_features // 2), dtype=torch.uint8, device=dev)
+                self.weight_cache = torch.empty((out_features, fp_features_num), dtype=torch.float16, device=dev)
+                self.ind = torch.empty((fp_features_num,), dtype=torch.int32, device=dev)
         self.bias = torch.empty((out_features,), dtype=torch.float16, device=dev) if bias else None
         self.cnt = 0
         self.add_outliers = True
@@ -109,15 +128,30 @@ class MixLinear_GEMM:
             self.sigma[0] = cache.sigma[0]
 
     @classmethod
-    def from_linear(cls, weight, bias=None, bit=8, weight_only=False, cache=None, dev="cuda"):
-        """linear.py:88-149 (``linear.weight`` fp16 [N,K], optional bias)."""
+    def from_linear(cls, weight, bias=None, bit=8, weight_only=False, cache=None, dev="cuda", layer_scales=None,
+                    fp_features_num=256):
+        """linear.py:88-149 (``linear.weight`` fp16 [N,K], optional bias; ``layer_scales`` = per-input-channel
+        activation scales, needed for bit = 4 to pick the static outlier columns)."""
         n, k = weight.shape
-        q = cls(k, n, bias is not None, dev, bit=bit, weight_only=weight_only, cache=cache)
+        q = cls(k, n, bias is not None, dev, bit=bit, weight_only=weight_only, cache=cache,
+                fp_features_num=fp_features_num)
         if weight_only:  # :102-106 EETQ quant_weights of W^T
             from . import pack
             qweight, scales, _ = pack.eetq_quant_weights(weight.t().contiguous())
             q.q_weight.copy_(qweight.to(dev))
             q.scale_col.copy_(scales.to(dev))
+        elif bit == 4:   # :121-143: top-k activation-scale columns stay fp16; scale = fp16(max|w_rest| / 10), clamp [-8, 7]
+            assert layer_scales is not None
+            ind = torch.sort(layer_scales.float().cpu(), stable=True)[1][-fp_features_num:]  # (stable: see pack.py)
+            w = weight.to(dev).clone()
+            q.weight_cache.copy_(w[:, ind.to(dev)])
+            w[:, ind.to(dev)] = 0
+            scale = (torch.max(torch.abs(w), dim=1)[0].unsqueeze(1) / 10).to(torch.float16).reshape((1, n))
+            q.scale_col.copy_(scale)
+            w /= q.scale_col.T
+            w = torch.clamp(w.round(), -8, 7)
+            q.q_weight.copy_(pack_to_i4(w.to(torch.int8).cpu()).to(dev))
+            q.ind.copy_(ind.to(torch.int32).to(dev))
         else:            # :113-120: scale = fp16(max|w| / 127) per row; q = round(w / scale) (no clamp)
             w = weight.to(dev)
             scale = (torch.max(torch.abs(w), dim=1)[0].unsqueeze(1) / 127).to(torch.float16).reshape((1, n))
@@ -159,7 +193,10 @@ class MixLinear_GEMM:
                 ind = self.FindOutliers(inputs)
                 cache.new_ind = ind
                 activation_outliers = mixlib.ExtractOutliersAndSetToZeros(ind, inputs)
-                weight_cache = dequant_weight_columns(self.q_weight, self.scale_col, ind)
+                if self.bit == 8:
+                    weight_cache = dequant_weight_columns(self.q_weight, self.scale_col, ind)
+                else:  # :210-212 (fp16 x fp16 product, like the reference's tensor expression)
+                    weight_cache = mixlib.unpack_int4_to_fp16(self.q_weight, ind) * self.scale_col.T
                 if self.ind.shape[0] == 0:
                     cache.activation_outliers = activation_outliers
                     self.weight_cache = weight_cache
@@ -174,8 +211,12 @@ class MixLinear_GEMM:
                 self.add_outliers = False
 
         y = outlier_product(cache.activation_outliers, self.weight_cache) if self.ind.shape[0] else None
-        y1 = mixlib.int8FusedDequantize(cache.q_xcache, self.q_weight, cache.x_scale, self.scale_col, y, M,
-                                        self.out_features, self.in_features)
+        if self.bit == 8:
+            y1 = mixlib.int8FusedDequantize(cache.q_xcache, self.q_weight, cache.x_scale, self.scale_col, y, M,
+                                            self.out_features, self.in_features)
+        else:
+            y1 = mixlib.int4FusedDequantize(cache.q_xcache, self.q_weight, cache.x_scale, self.scale_col, y, M,
+                                            self.out_features, self.in_features // 2)
         if self.bias is not None:
             y1 += self.bias
         return y1.reshape(cache.shape)

@@ -17,7 +17,8 @@ __all__ = [
     "dequant_epilogue", "dequantization", "linear_prefill", "weight_scales", "quantize_weight",
     "select_outliers", "pack_linear_weights", "eetq_symmetric_quantize", "eetq_preprocess", "w8a16_gemv",
     "int_to_half", "int8_matrix_to_half", "rmsnorm_extract_quant", "find_outliers", "dequant_weight_columns",
-    "MixLinearState", "mixlinear_forward",
+    "MixLinearState", "mixlinear_forward", "quant4_rows", "unpack_i4", "pack_i4", "mixlinear4_from_linear",
+    "mixlinear4_forward",
 ]
 
 
@@ -317,3 +318,59 @@ def mixlinear_forward(st, x):
     if st.bias is not None:
         out = (out + st.bias[None, :]).astype(np.float16)
     return out
+
+
+# ---- 4-bit (W4A4) flavour, numpy restatement (cult.cu:2515-2567, linear.py:11-17, 121-143) ----
+def quant4_rows(A):
+    """FindRowScaleKernel4bit: s = fp16(amax / 7) (NaN dropped from the max like __hmax), q = low 4 bits of
+    half2int_rn(hdiv(x, s)); returns (packed uint8 [M, K/2] with element 2i in the low nibble, s fp16 [M])."""
+    A = _h(A)
+    M, K = A.shape
+    with np.errstate(all="ignore"):
+        absA = np.abs(A)
+        amax = np.where(np.isnan(absA).all(axis=1), np.float16(np.nan),
+                        np.nanmax(np.where(np.isnan(absA), np.float16(-1), absA), axis=1)).astype(np.float16)
+        s = (amax / np.float16(7)).astype(np.float16)
+        qh = (A / s[:, None]).astype(np.float16)                    # __hdiv: correctly rounded fp16 quotient
+        r = np.rint(qh.astype(np.float64))                           # __half2int_rn: RNE
+        r = np.where(np.isnan(r), 0, np.clip(r, -2147483648, 2147483647))   # NaN -> 0, +-inf saturate
+    q = (r.astype(np.int64) & 0xF).astype(np.uint8)
+    return (q[:, 0::2] | (q[:, 1::2] << 4)).astype(np.uint8), s
+
+
+def unpack_i4(packed):
+    """packed uint8 [R, C/2] -> int8 [R, C] (sign-extended; low nibble = even column)."""
+    p = np.asarray(packed, np.uint8)
+    out = np.empty((p.shape[0], p.shape[1] * 2), np.int8)
+    out[:, 0::2] = ((p & 0xF).astype(np.int16) ^ 8) - 8
+    out[:, 1::2] = ((p >> 4).astype(np.int16) ^ 8) - 8
+    return out
+
+
+def pack_i4(x):
+    """linear.py:11-17 pack_to_i4."""
+    x = np.asarray(x, np.int8).astype(np.int16)
+    u = np.where(x < 0, 16 + x, x).astype(np.uint8)
+    return (u[:, 0::2] | (u[:, 1::2] << 4)).astype(np.uint8)
+
+
+def mixlinear4_from_linear(W, layer_scales, fp_features_num=256):
+    """linear.py:121-143 -> (q_weight packed, scale_col fp16 [N], ind int32, weight_cache fp16 [N, fp])."""
+    W = _h(W).copy()
+    ind = np.argsort(np.asarray(layer_scales, np.float32), kind="stable")[-fp_features_num:].astype(np.int32)
+    wc = W[:, ind].copy()
+    W[:, ind] = 0
+    sc = (np.abs(W).max(axis=1) / np.float16(10)).astype(np.float16)
+    q = np.clip(np.rint((W / sc[:, None]).astype(np.float16).astype(np.float64)), -8, 7).astype(np.int8)
+    return pack_i4(q), sc, ind, wc
+
+
+def mixlinear4_forward(q_weight_packed, scale_col, ind, weight_cache, x):
+    """bit = 4 forward with a frozen outlier set (linear.py:183-193, 259-267): zero + extract the outlier columns,
+    4-bit row quantisation, s4 x s4 -> s32 GEMM, fp16 outlier product as the addend of the dequant epilogue."""
+    assert x.dtype == np.float16 and x.flags.c_contiguous
+    act_out = extract_outliers(x, ind, set_zero=True)
+    qx, xs = quant4_rows(x)
+    acc = gemm_s8s8s32(unpack_i4(qx), unpack_i4(q_weight_packed))
+    y = gemm_fp16(np.ascontiguousarray(act_out), np.ascontiguousarray(weight_cache))
+    return dequant_epilogue(acc, xs, scale_col, C=y)

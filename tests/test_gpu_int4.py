@@ -1,0 +1,105 @@
+"""GPU (-m gpu): the 4-bit (W4A4) flavour -- FindRowScale(bit=4), int4FusedDequantize, unpack_int4_to_fp16 and the
+bit = 4 branch of MixLinear_GEMM (MixQ/src/mixquant/modules/linear.py, quantkernel/mix_cuda/cult.cu) through the C ABI,
+against the oracle's numpy restatement.  Integer results bit-exact; fp16 output bit-exact given its addend."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint16)
+
+
+@pytest.mark.parametrize("M,K", [(1, 256), (33, 4096), (7, 11008), (5, 64)])
+def test_find_row_scale_4bit_bit_exact(oracle, M, K):
+    from mixq_tensorrt_llm_amd import mixlib
+    rng = np.random.default_rng(M + K)
+    A = (rng.standard_normal((M, K)) * rng.uniform(0.05, 20)).astype(np.float16)
+    if M > 4:
+        A[1] = 0                        # zero row: scale 0, 0/0 = NaN -> 0
+        A[2, 3] = np.nan                # NaN element dropped from the max, quantised to 0
+        A[3, :] = np.float16(6e-8)      # scale underflows to 0: x/0 = inf -> INT_MAX & 0xF = -1
+        A[4, 7] = np.inf                # inf amax -> inf scale -> finite/inf = 0, inf/inf = NaN -> 0
+    s = torch.empty(M, dtype=torch.float16, device="cuda:0")
+    q = mixlib.FindRowScale(dev(A), s, M, K, 4)
+    qo, so = oracle.quant4_rows(A)
+    assert q.dtype == torch.uint8 and tuple(q.shape) == (M, K // 2)
+    assert np.array_equal(bits(s.cpu().numpy()), bits(so))
+    assert np.array_equal(q.cpu().numpy(), qo)
+
+
+def test_unpack_int4_to_int8_and_columns(oracle):
+    from mixq_tensorrt_llm_amd import _lib, mixlib
+    rng = np.random.default_rng(9)
+    R, C = 96, 4096
+    packed = rng.integers(0, 256, (R, C // 2), dtype=np.uint8)
+    src = dev(packed)
+    dst = torch.empty((R, C), dtype=torch.int8, device="cuda:0")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(_lib.load().mixq_unpack_int4_to_int8(ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(dst.data_ptr()),
+                                                    packed.size, st), "unpack")
+    want = oracle.unpack_i4(packed)
+    assert np.array_equal(dst.cpu().numpy(), want)
+    ind = np.array([0, 1, 4095, 4094, 77, 78, 2048], np.int32)
+    got = mixlib.unpack_int4_to_fp16(src, dev(ind)).cpu().numpy()
+    assert np.array_equal(got, want[:, ind].astype(np.float16))
+
+
+@pytest.mark.parametrize("M,N,K,silu", [(40, 512, 1024, False), (300, 1024, 4096, False), (64, 256, 512, True),
+                                        (2048, 4096, 4096, False)])
+def test_int4_fused_dequantize_bit_exact(oracle, M, N, K, silu):
+    """s4 x s4 -> s32 (exact) + the dequant epilogue with an fp16 addend: identical bits to the oracle."""
+    from mixq_tensorrt_llm_amd import mixlib
+    rng = np.random.default_rng(M + N + K)
+    a = rng.integers(-8, 8, (M, K), dtype=np.int8)
+    b = rng.integers(-8, 8, (N, K), dtype=np.int8)
+    sa = (rng.random(M) * 0.5 + 0.01).astype(np.float16)
+    sb = (rng.random(N) * 1e-2 + 1e-4).astype(np.float16)
+    y = (rng.standard_normal((M, N)) * 0.3).astype(np.float16)
+    ap, bp = oracle.pack_i4(a), oracle.pack_i4(b)
+    assert np.array_equal(oracle.unpack_i4(ap), a)
+    fn = mixlib.int4FusedDequantizeSilu if silu else mixlib.int4FusedDequantize
+    got = fn(dev(ap), dev(bp), dev(sa.reshape(M, 1)), dev(sb.reshape(1, N)), dev(y), M, N, K // 2).cpu().numpy()
+    want = oracle.dequant_epilogue(oracle.gemm_s8s8s32(a, b), sa, sb, C=y, silu=silu)
+    if silu:
+        g, w = got.astype(np.float64), want.astype(np.float64)
+        assert np.abs(g - w).max() / np.abs(w).max() < 1e-3      # __expf vs expf: not bit-pinned (as for int8)
+    else:
+        assert np.array_equal(bits(got), bits(want))
+
+
+def test_mixlinear_4bit_from_linear_and_forward(oracle):
+    from mixq_tensorrt_llm_amd import mixlinear
+    rng = np.random.default_rng(17)
+    N, K, M, FP = 768, 2048, 96, 256
+    W = (rng.standard_normal((N, K)) * 0.02).astype(np.float16)
+    scales = np.abs(rng.standard_normal(K)).astype(np.float32)
+    cache = mixlinear.MixLibCache(inputdim=256, sigma=6, bit=4, device="cuda:0")
+    layer = mixlinear.MixLinear_GEMM.from_linear(torch.from_numpy(W), bit=4, cache=cache, dev="cuda:0",
+                                                 layer_scales=torch.from_numpy(scales), fp_features_num=FP)
+    qp, sc, ind, wc = oracle.mixlinear4_from_linear(W, scales, FP)
+    assert np.array_equal(layer.ind.cpu().numpy(), ind)
+    assert np.array_equal(bits(layer.scale_col.cpu().numpy().reshape(-1)), bits(sc))
+    assert np.array_equal(layer.q_weight.cpu().numpy(), qp)
+    assert np.array_equal(bits(layer.weight_cache.cpu().numpy()), bits(wc))
+    x = (rng.standard_normal((M, K)) * 0.8).astype(np.float16)
+    x[:, ind] *= 12.0                       # the calibrated outlier columns carry the large activations
+    x_ref = x.copy()
+    xt = dev(x)
+    got = layer.forward(xt, cache).cpu().numpy()
+    want = oracle.mixlinear4_forward(qp, sc, ind, wc, x_ref)
+    assert layer.ind.numel() == FP, "no dynamic growth expected: the remaining activations stay below sigma"
+    assert np.array_equal(bits(xt.cpu().numpy()), bits(x_ref))
+    g, w = got.astype(np.float64), want.astype(np.float64)
+    assert np.abs(g - w).max() / np.abs(w).max() < 1e-3
+    # 4-bit weights + 4-bit activations are coarse, but the result must still track the fp product
+    ref = x.astype(np.float64) @ W.astype(np.float64).T
+    assert np.abs(g - ref).max() / np.abs(ref).max() < 0.35

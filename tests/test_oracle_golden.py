@@ -156,3 +156,31 @@ def test_dynamic_outlier_helpers_against_the_reference_torch_expressions(oracle)
     want_wc = (q[:, ind].to(torch.float16) * scale_col.T).numpy()
     got_wc = oracle.dequant_weight_columns(q.numpy(), scale_col.numpy(), want[:17])
     assert np.array_equal(got_wc.view(np.uint16), want_wc.view(np.uint16))
+
+
+def test_int4_packing_and_weight_quant_against_torch_expressions(oracle):
+    """linear.py:11-17 (pack_to_i4) and :121-143 (bit = 4 `from_linear`) are torch expressions: evaluate them with CPU
+    torch and compare the oracle's numpy restatement."""
+    torch = pytest.importorskip("torch")
+    from mixq_tensorrt_llm_amd import mixlinear
+    rng = np.random.default_rng(8)
+    q = rng.integers(-8, 8, (16, 64), dtype=np.int8)
+    assert np.array_equal(mixlinear.pack_to_i4(torch.from_numpy(q)).numpy(), oracle.pack_i4(q))
+    assert np.array_equal(oracle.unpack_i4(oracle.pack_i4(q)), q)
+    W = (rng.standard_normal((32, 128)) * 0.02).astype(np.float16)
+    scales = np.abs(rng.standard_normal(128)).astype(np.float32)
+    fp = 16
+    # the reference's expressions, verbatim
+    ind = torch.sort(torch.from_numpy(scales))[1][-fp:]
+    tmp = torch.from_numpy(W.copy())
+    weight_cache = tmp[:, ind].clone()
+    tmp[:, ind] = 0
+    scale = (torch.max(torch.abs(tmp), dim=1)[0].unsqueeze(1) / (10)).to(torch.float16).reshape((1, 32))
+    tmp /= scale.T
+    tmp = torch.clamp(tmp.round(), -8, 7)
+    packed = mixlinear.pack_to_i4(tmp.to(torch.int8))
+    qp, sc, oind, wc = oracle.mixlinear4_from_linear(W, scales, fp)
+    assert np.array_equal(oind, ind.numpy().astype(np.int32))
+    assert np.array_equal(sc.view(np.uint16), scale.numpy().reshape(-1).view(np.uint16))
+    assert np.array_equal(qp, packed.numpy())
+    assert np.array_equal(wc.view(np.uint16), weight_cache.numpy().view(np.uint16))
