@@ -33,7 +33,7 @@ constexpr int KSLICE = 128;  // bytes of K per LDS row (int8 elements)
 constexpr int OSLICE = 256;  // bytes per LDS row in the outlier phase (128 fp16)
 constexpr int GROUP_M = 4;
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int NSTAGE = 2>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_w8a8o16_kernel(const GemmParams p)
 {
     constexpr int NWAVES = WAVES_M * WAVES_N;
@@ -45,7 +45,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_w8a8o16_kernel(con
     constexpr int XL = BN * 8 / T, YL = BM * 8 / T;       // 16-B loads per thread per K slice
     static_assert(BN * 8 % T == 0 && BM * 8 % T == 0, "tile rows must split evenly over the block");
     static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA");
-    static_assert((BM + BN) * OSLICE <= 2 * STAGE_BYTES, "outlier tiles must fit the main-loop LDS");
+    static_assert((BM + BN) * OSLICE <= NSTAGE * STAGE_BYTES, "outlier tiles must fit the main-loop LDS");
+    static_assert(NSTAGE >= 2 && NSTAGE <= 8, "2..8 LDS stages");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -139,12 +140,18 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_w8a8o16_kernel(con
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
 
     // ---- main loop -------------------------------------------------------------------------------------
-    stage(0, 0);
+    // NSTAGE LDS buffers, slices kt+1 .. kt+NSTAGE-1 in flight while slice kt is multiplied.  Small tiles are bound by
+    // the HBM round trip of each slice, not by MFMA work: the deeper the prefetch, the more bytes in flight per CU.
+#pragma unroll
+    for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
+        if (s0 < nk) stage(s0, s0);
     for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads(); // slice kt has landed for every wave; everyone is done reading the other buffer
-        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-        const char* base = smem + (kt & 1) * STAGE_BYTES;
+        // copies complete in order: at most the (NSTAGE-2) younger slices may still be in flight once slice kt landed
+        if (NSTAGE > 2 && kt + NSTAGE - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * (XL + YL)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads(); // slice kt has landed for every wave; everyone is done reading slice kt-1's buffer
+        if (kt + NSTAGE - 1 < nk) stage((kt + NSTAGE - 1) % NSTAGE, kt + NSTAGE - 1);
+        const char* base = smem + (kt % NSTAGE) * STAGE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             v4i xf[TN], yf[TM];
@@ -261,12 +268,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_w8a8o16_kernel(con
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int NSTAGE = 2>
 static hipError_t launch_cfg(const GemmParams& p, hipStream_t st)
 {
     constexpr int T = WAVES_M * WAVES_N * 64;
-    constexpr size_t lds = 2 * (size_t)(BM + BN) * KSLICE;
-    auto kern = gemm_w8a8o16_kernel<BM, BN, WAVES_M, WAVES_N, EPI>;
+    constexpr size_t lds = NSTAGE * (size_t)(BM + BN) * KSLICE;
+    auto kern = gemm_w8a8o16_kernel<BM, BN, WAVES_M, WAVES_N, EPI, NSTAGE>;
     static bool attr_done = false; // benign race: idempotent
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -279,12 +286,35 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t st)
     return hipGetLastError();
 }
 
+static std::atomic<int> g_force_cfg{-1}; // measurement knob (variant 10 + i): force tile configuration i
+
 template <int EPI>
 static hipError_t launch_epi(const GemmParams& p, hipStream_t st)
 {
-    if (p.M <= 64) return launch_cfg<32, 128, 1, 4, EPI>(p, st);
-    if (p.M <= 128 || (int64_t)p.M * p.N <= (int64_t)256 * 256 * 128) return launch_cfg<128, 128, 2, 2, EPI>(p, st);
-    return launch_cfg<256, 256, 2, 4, EPI>(p, st);
+    switch (g_force_cfg.load()) {
+    case 0: return launch_cfg<32, 128, 1, 4, EPI>(p, st);
+    case 1: return launch_cfg<128, 128, 2, 2, EPI>(p, st);
+    case 2: return launch_cfg<256, 256, 2, 4, EPI>(p, st);
+    case 3: return launch_cfg<64, 128, 2, 4, EPI>(p, st);
+    case 4: return launch_cfg<128, 128, 2, 4, EPI>(p, st);
+    case 5: return launch_cfg<128, 64, 4, 2, EPI>(p, st);
+    case 6: return launch_cfg<256, 128, 2, 4, EPI>(p, st);
+    case 7: return launch_cfg<64, 64, 2, 2, EPI>(p, st);
+    case 8: return launch_cfg<64, 256, 2, 4, EPI>(p, st);
+    case 9: return launch_cfg<64, 64, 2, 2, EPI, 4>(p, st);
+    case 10: return launch_cfg<64, 64, 2, 2, EPI, 8>(p, st);
+    case 11: return launch_cfg<64, 128, 2, 4, EPI, 4>(p, st);
+    case 12: return launch_cfg<128, 64, 4, 2, EPI, 4>(p, st);
+    case 13: return launch_cfg<64, 32, 2, 1, EPI, 8>(p, st);
+    case 14: return launch_cfg<128, 128, 2, 4, EPI, 4>(p, st);
+    case 15: return launch_cfg<32, 128, 1, 4, EPI, 4>(p, st);
+    default: break;
+    }
+    // Measured choice (tools/cfg_sweep.sh, M = 32..1024 on 12288x4096, 4096x11008, 4096x4096): small problems are
+    // bound by how many workgroups stream operands concurrently, so the 64x64 tile wins until ~3 workgroups per CU.
+    const int64_t wg64 = (int64_t)((p.M + 63) / 64) * ((p.N + 63) / 64);
+    if (wg64 <= 768) return launch_cfg<64, 64, 2, 2, EPI>(p, st);
+    return launch_cfg<128, 128, 2, 4, EPI>(p, st);
 }
 
 // Schedule selection.  0 = auto (ping-pong 256x256 kernel when the problem fills the chip with 256x256 tiles, else the
@@ -293,7 +323,23 @@ static hipError_t launch_epi(const GemmParams& p, hipStream_t st)
 // Set through mixq_debug_set_gemm_variant() (tests, A/B measurements) or MIXQ_GEMM_VARIANT=v1|pp in the environment.
 static std::atomic<int> g_variant{-1};
 
-void set_gemm_variant(int v) { g_variant.store(v); }
+void set_gemm_variant(int v)
+{
+    if (v >= 40 && v < 100) { // 40 + kw: skinny kernel with kw K-split waves (measurements)
+        set_skinny_kw(v - 40);
+        g_force_cfg.store(-1);
+        g_variant.store(0);
+        return;
+    }
+    set_skinny_kw(0);
+    if (v >= 10 && v < 100) { // 10 + i: the 2-barrier kernel in tile configuration i (measurements)
+        g_force_cfg.store(v - 10);
+        g_variant.store(1);
+        return;
+    }
+    g_force_cfg.store(-1);
+    g_variant.store(v);
+}
 
 static int gemm_variant()
 {
@@ -310,11 +356,13 @@ hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st)
 {
     if (p.M <= 0 || p.N <= 0) return hipSuccess;
     const int variant = gemm_variant();
-    if (variant != 1 && gemm_skinny_supported(p)) return launch_gemm_skinny(p, epi, st); // M <= 64
+    // M <= 32, or M <= 64 with too few 64x64 tiles to fill the chip: weight-streaming GEMV-like kernel
+    if (variant != 1 && gemm_skinny_supported(p) && (p.M <= 32 || p.N < 8192)) return launch_gemm_skinny(p, epi, st);
     const int64_t tiles256 = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256);
     if (variant >= 100) return launch_gemm_pp_ablate(p, variant - 100, st); // measurement-only ablations
     if (variant == 3 && gemm_pp2_supported(p, epi)) return launch_gemm_pp2(p, epi, st);
-    if (variant == 2 || (variant == 0 && p.M > 128 && tiles256 >= 96)) return launch_gemm_pp(p, epi, st);
+    const int64_t wg64 = (int64_t)((p.M + 63) / 64) * ((p.N + 63) / 64);
+    if (variant == 2 || (variant == 0 && p.M > 128 && tiles256 >= 96 && wg64 > 768)) return launch_gemm_pp(p, epi, st);
     switch (epi) {
     case EPI_DEQUANT: return launch_epi<EPI_DEQUANT>(p, st);
     case EPI_DEQUANT_SILU: return launch_epi<EPI_DEQUANT_SILU>(p, st);

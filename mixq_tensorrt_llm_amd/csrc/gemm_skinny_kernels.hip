@@ -1,25 +1,27 @@
 // Skinny-M form of the fused W8A8O16 GEMM (5 <= M <= 64: small prefill chunks, BASELINE config 0 = bs 32): the
 // operator is HBM-bound on the N x K int8 weight here (AI ~ 2M op/B), so the kernel is built like a GEMV:
 //
-//   * one 256-thread workgroup per 16 output features: N/16 workgroups (256 for N = 4096: one per CU), 4 waves each;
-//     the waves split K into quarters, so 4 x N/16 wavefronts stream W concurrently with 16-byte loads straight into
+//   * one workgroup per 16 output features: N/16 workgroups (256 for N = 4096: one per CU) of KW = 4, 8 or 16 waves
+//     (chosen so that the chip holds >= ~12 wavefronts per CU); the waves split K evenly, so KW x N/16 wavefronts stream
+//     W concurrently with 16-byte loads straight into
 //     MFMA A-fragments (v_mfma_i32_16x16x64_i8: lane l = W row l%16, K bytes (l/16)*16.. of each 64-byte step): every
 //     weight byte is read from HBM exactly once, no LDS staging, 16 steps (1 KiB/lane-group) of loads in flight per wave;
 //   * qA (M x K int8, <= 64 rows) is the MFMA B operand, read through L2 (it is shared by every workgroup);
-//   * the four K-quarter accumulators meet in LDS; wave t then owns m-tile t: fp16 outlier side GEMM on
+//   * the KW partial accumulators meet in LDS; wave t then owns m-tile t: fp16 outlier side GEMM on
 //     v_mfma_f32_16x16x32_f16 (operands straight from L2), dequant FMA, 8-byte fp16 stores (4 consecutive n per lane).
 //
 // Same arithmetic and same results as the large-M kernels (integer accumulation is order-independent).
 // Reference lines replaced: see gemm_kernels.hip.
 #include "mixq_device.h"
 #include "mixq_launch.h"
+#include <atomic>
 
 namespace mixq {
 
-template <int MT, int EPI>
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmParams p)
+template <int MT, int EPI, int KW>
+__global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p)
 {
-    __shared__ v4i part[4][MT][64]; // [K quarter][m tile][lane]
+    __shared__ v4i part[KW][MT][64]; // [K part][m tile][lane]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n0 = blockIdx.x * 16;
@@ -28,7 +30,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmParams p)
 
     // this wave's K range, in 64-byte MFMA steps
     const int nsteps = (p.K + 63) >> 6;
-    const int per = (nsteps + 3) >> 2;
+    const int per = (nsteps + KW - 1) / KW;
     const int s_begin = min(wave * per, nsteps), s_end = min(s_begin + per, nsteps);
 
     const int8_t* wrow = p.B + (int64_t)min(n0 + lr, p.N - 1) * K + lq * 16;
@@ -74,10 +76,10 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmParams p)
     __syncthreads();
 
     // wave t finishes m-tile t : C/D layout of the 16x16 MFMA: m = lane & 15, n = 4 * (lane >> 4) + r
-    for (int t = wave; t < MT; t += 4) {
+    for (int t = wave; t < MT; t += KW) {
         v4i a = part[0][t][lane];
 #pragma unroll
-        for (int w2 = 1; w2 < 4; ++w2) {
+        for (int w2 = 1; w2 < KW; ++w2) {
             const v4i b = part[w2][t][lane];
             a = v4i{a[0] + b[0], a[1] + b[1], a[2] + b[2], a[3] + b[3]};
         }
@@ -132,18 +134,33 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmParams p)
     }
 }
 
+static std::atomic<int> g_skinny_kw{0}; // measurement knob: force the K-split width (0 = auto)
+void set_skinny_kw(int kw) { g_skinny_kw.store(kw); }
+
+template <int EPI, int KW>
+static hipError_t launch_skinny_kw(const GemmParams& p, hipStream_t st)
+{
+    const dim3 grid((unsigned)((p.N + 15) / 16)), block(KW * 64);
+    const int mt = (p.M + 15) / 16;
+    switch (mt) {
+    case 1: hipLaunchKernelGGL((gemm_skinny_kernel<1, EPI, KW>), grid, block, 0, st, p); break;
+    case 2: hipLaunchKernelGGL((gemm_skinny_kernel<2, EPI, KW>), grid, block, 0, st, p); break;
+    case 3: hipLaunchKernelGGL((gemm_skinny_kernel<3, EPI, KW>), grid, block, 0, st, p); break;
+    default: hipLaunchKernelGGL((gemm_skinny_kernel<4, EPI, KW>), grid, block, 0, st, p); break;
+    }
+    return hipGetLastError();
+}
+
 template <int EPI>
 static hipError_t launch_skinny_epi(const GemmParams& p, hipStream_t st)
 {
-    const dim3 grid((unsigned)((p.N + 15) / 16)), block(256);
-    const int mt = (p.M + 15) / 16;
-    switch (mt) {
-    case 1: hipLaunchKernelGGL((gemm_skinny_kernel<1, EPI>), grid, block, 0, st, p); break;
-    case 2: hipLaunchKernelGGL((gemm_skinny_kernel<2, EPI>), grid, block, 0, st, p); break;
-    case 3: hipLaunchKernelGGL((gemm_skinny_kernel<3, EPI>), grid, block, 0, st, p); break;
-    default: hipLaunchKernelGGL((gemm_skinny_kernel<4, EPI>), grid, block, 0, st, p); break;
-    }
-    return hipGetLastError();
+    // KW = 4 everywhere: measured (tools/skinny_sweep.sh) 8 / 16 K-split waves are never faster, even for N = 4096
+    // where KW = 4 leaves one wave per SIMD -- the kernel is bound by the qA re-reads through L1, not by occupancy.
+    int kw = g_skinny_kw.load();
+    if (kw == 0) kw = 4;
+    if (kw >= 16) return launch_skinny_kw<EPI, 16>(p, st);
+    if (kw >= 8) return launch_skinny_kw<EPI, 8>(p, st);
+    return launch_skinny_kw<EPI, 4>(p, st);
 }
 
 bool gemm_skinny_supported(const GemmParams& p) { return p.M <= 64 && p.O <= 256; }

@@ -29,6 +29,7 @@ bool gemm_pp2_supported(const GemmParams& p, int epi);
 hipError_t launch_gemm_pp2(const GemmParams& p, int epi, hipStream_t st); // persistent ping-pong schedule
 hipError_t launch_gemm_pp_ablate(const GemmParams& p, int abl, hipStream_t st);  // timing experiments only
 void set_gemm_variant(int v);
+void set_skinny_kw(int kw); // measurement knob: K-split width of the skinny kernel (0 = auto)
 hipError_t launch_gemm_fp16(const void* fpA, const void* fpW, void* Out, int M, int N, int O, hipStream_t st);
 hipError_t launch_dequantization(void* out, const int32_t* x, const void* sRow, const void* sCol, int M, int N,
                                  hipStream_t st);

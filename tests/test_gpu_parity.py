@@ -191,6 +191,25 @@ def test_every_schedule_gives_identical_int32(oracle, variant, which, M, N, K):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("cfg", range(16))
+def test_every_tile_configuration_of_the_two_barrier_kernel(oracle, variant, cfg):
+    """variant 10 + cfg forces one tile / pipeline-depth configuration of gemm_w8a8o16_kernel (2..8 LDS stages): raw
+    int32 on ragged shapes (K shorter than the prefetch depth, K tail, odd slice counts) + the fused operator."""
+    from mixq_tensorrt_llm_amd import mixlib
+    variant(10 + cfg)
+    for (M, N, K) in [(70, 144, 48), (129, 272, 400), (200, 336, 1040), (515, 528, 2064)]:
+        rng = np.random.default_rng(M + N + K + cfg)
+        a = rng.integers(-128, 128, size=(M, K), dtype=np.int8)
+        b = rng.integers(-128, 128, size=(N, K), dtype=np.int8)
+        got = mixlib.gemm(to_dev(a), to_dev(b), M, N, K).cpu().numpy()
+        assert np.array_equal(got, a.astype(np.int32) @ b.astype(np.int32).T), (M, N, K)
+    A, W, act = make_layer(150, 272, 704, seed=cfg)
+    p = oracle.pack_linear_weights(W, act)
+    got = run_enqueue(A, p)
+    want = oracle.linear_prefill(A, p["weight"], p["weights_scaling_factor"], p["fp_weight"], p["fp_ind"])
+    assert rel_err(got, want) < REL_TOL
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 768, 1280), (700, 528, 2112), (520, 1024, 512), (257, 272, 704)])
 @pytest.mark.parametrize("which", [1, 2, 3])
 def test_every_schedule_full_operator(oracle, variant, which, M, N, K):
