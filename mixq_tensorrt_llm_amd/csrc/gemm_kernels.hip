@@ -33,11 +33,16 @@ constexpr int KSLICE = 128;  // bytes of K per LDS row (int8 elements)
 constexpr int OSLICE = 256;  // bytes per LDS row in the outlier phase (128 fp16)
 constexpr int GROUP_M = 4;
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int NSTAGE = 2>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_w8a8o16_kernel(const GemmParams p)
+// KG > 1: in-workgroup split-K.  KG groups of WAVES_M x WAVES_N waves work on the same output tile, group g on the K
+// slices g, g + KG, ... with its own LDS stages; the partial accumulators meet in LDS and group 0 runs the epilogue.
+// (Small-N problems have too few tiles for the chip, and an LDS-DMA instruction costs the issuing wave 100-200 cycles:
+// more waves per tile is what raises the operand stream, and no global scratch is needed.)
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int NSTAGE = 2, int KG = 1>
+__global__ __launch_bounds__(WAVES_M* WAVES_N* KG * 64) void gemm_w8a8o16_kernel(const GemmParams p)
 {
     constexpr int NWAVES = WAVES_M * WAVES_N;
-    constexpr int T = NWAVES * 64;
+    constexpr int T = NWAVES * 64;      // threads of one K group
+    constexpr int TT = T * KG;          // threads of the workgroup
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int X_BYTES = BN * KSLICE, Y_BYTES = BM * KSLICE;
@@ -45,15 +50,21 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_w8a8o16_kernel(con
     constexpr int XL = BN * 8 / T, YL = BM * 8 / T;       // 16-B loads per thread per K slice
     static_assert(BN * 8 % T == 0 && BM * 8 % T == 0, "tile rows must split evenly over the block");
     static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA");
-    static_assert((BM + BN) * OSLICE <= NSTAGE * STAGE_BYTES, "outlier tiles must fit the main-loop LDS");
+    static_assert((BM + BN) * OSLICE <= KG * NSTAGE * STAGE_BYTES, "outlier tiles must fit the main-loop LDS");
+    static_assert((KG - 1) * NWAVES * TN * TM * 4096 <= KG * NSTAGE * STAGE_BYTES, "partial accumulators must fit");
+    static_assert(BN * 16 % TT == 0 && BM * 16 % TT == 0, "outlier tile rows must split evenly over the block");
     static_assert(NSTAGE >= 2 && NSTAGE <= 8, "2..8 LDS stages");
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];
 
-    const int tid = threadIdx.x;
+    const int tid_all = threadIdx.x;
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid_all >> 6);
+    const int group = KG > 1 ? wave_all / NWAVES : 0;
+    const int tid = KG > 1 ? tid_all - group * T : tid_all;   // thread inside its K group
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = KG > 1 ? wave_all - group * NWAVES : wave_all;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    char* const smem = smem_all + group * (NSTAGE * STAGE_BYTES); // this group's stages
 
     // ---- block -> tile mapping (XCD-aware, grouped) ------------------------------------------------
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
@@ -142,16 +153,22 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_w8a8o16_kernel(con
     // ---- main loop -------------------------------------------------------------------------------------
     // NSTAGE LDS buffers, slices kt+1 .. kt+NSTAGE-1 in flight while slice kt is multiplied.  Small tiles are bound by
     // the HBM round trip of each slice, not by MFMA work: the deeper the prefetch, the more bytes in flight per CU.
+    // (group g owns slices g, g + KG, ...: its it-th slice is kt = it * KG + g; every group runs the same number of
+    //  iterations because the barrier is workgroup-wide)
 #pragma unroll
     for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
-        if (s0 < nk) stage(s0, s0);
-    for (int kt = 0; kt < nk; ++kt) {
+        if (s0 * KG + group < nk) stage(s0, s0 * KG + group);
+    const int nit = (nk + KG - 1) / KG;
+    for (int it = 0; it < nit; ++it) {
+        const int kt = it * KG + group;
         // copies complete in order: at most the (NSTAGE-2) younger slices may still be in flight once slice kt landed
-        if (NSTAGE > 2 && kt + NSTAGE - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * (XL + YL)) : "memory");
+        if (NSTAGE > 2 && (it + NSTAGE - 2) * KG + group < nk)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * (XL + YL)) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads(); // slice kt has landed for every wave; everyone is done reading slice kt-1's buffer
-        if (kt + NSTAGE - 1 < nk) stage((kt + NSTAGE - 1) % NSTAGE, kt + NSTAGE - 1);
-        const char* base = smem + (kt % NSTAGE) * STAGE_BYTES;
+        __syncthreads(); // slice kt has landed for every wave; everyone is done reading the previous slice's buffer
+        if ((it + NSTAGE - 1) * KG + group < nk) stage((it + NSTAGE - 1) % NSTAGE, (it + NSTAGE - 1) * KG + group);
+        if (KG > 1 && kt >= nk) continue; // (K groups past the end only keep the barrier count)
+        const char* base = smem + (it % NSTAGE) * STAGE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             v4i xf[TN], yf[TM];
@@ -169,34 +186,69 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_w8a8o16_kernel(con
         }
     }
 
-    // ---- outlier side GEMM: stage fpW / fpA tiles (256-B rows, slot = chunk ^ (row & 15)) ------------
+    // ---- in-workgroup split-K: partial accumulators of groups 1.. -> LDS -> added by group 0 ----------
+    if (KG > 1) {
+        __syncthreads(); // main-loop LDS is dead
+        if (group > 0) {
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) {
+                    char* r = smem_all + (((group - 1) * NWAVES + wave) * (TN * TM) + i * TM + j) * 4096 + lane * 16;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<v4i*>(r + q * 1024) =
+                            v4i{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                }
+        }
+        __syncthreads();
+        if (group == 0) {
+#pragma unroll
+            for (int g2 = 1; g2 < KG; ++g2)
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) {
+                        const char* r = smem_all + (((g2 - 1) * NWAVES + wave) * (TN * TM) + i * TM + j) * 4096 + lane * 16;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const v4i t4 = *reinterpret_cast<const v4i*>(r + q * 1024);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] += t4[e];
+                        }
+                    }
+        }
+    }
+
+    // ---- outlier side GEMM: stage fpW / fpA tiles (256-B rows, slot = chunk ^ (row & 15)); all threads help ----
     const bool has_outliers = (EPI != EPI_INT32) && p.O > 0;
     if (has_outliers) {
-        __syncthreads(); // main-loop LDS is dead
-        constexpr int OXL = BN * 16 / T, OYL = BM * 16 / T;
+        __syncthreads(); // main-loop LDS (and the partial accumulators) are dead
+        constexpr int OXL = BN * 16 / TT, OYL = BM * 16 / TT;
         const int obytes = p.O * 2; // valid bytes per row (O % 8 == 0)
-        const int slot = tid & 15;
+        const int slot = tid_all & 15;
 #pragma unroll
         for (int i = 0; i < OXL; ++i) {
-            const int row = (i * T + tid) >> 4;
+            const int row = (i * TT + tid_all) >> 4;
             const int c = (slot ^ (row & 15)) << 4;
             const int grow = min(n0 + row, p.N - 1);
             const char* s = reinterpret_cast<const char*>(p.fpW) + (int64_t)grow * obytes + c;
             if (c >= obytes) s = static_cast<const char*>(p.zeros);
-            glds16(s, smem + (i * T + wave * 64) * 16);
+            glds16(s, smem_all + (i * TT + wave_all * 64) * 16);
         }
 #pragma unroll
         for (int i = 0; i < OYL; ++i) {
-            const int row = (i * T + tid) >> 4;
+            const int row = (i * TT + tid_all) >> 4;
             const int c = (slot ^ (row & 15)) << 4;
             const int grow = min(m0 + row, p.M - 1);
             const char* s = reinterpret_cast<const char*>(p.fpA) + (int64_t)grow * obytes + c;
             if (c >= obytes) s = static_cast<const char*>(p.zeros);
-            glds16(s, smem + BN * OSLICE + (i * T + wave * 64) * 16);
+            glds16(s, smem_all + BN * OSLICE + (i * TT + wave_all * 64) * 16);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    if (KG > 1 && group > 0) return; // (no barrier below this point)
 
     // ---- epilogue, one 32x32 tile at a time -----------------------------------------------------------
     const int osteps = has_outliers ? (p.O + 15) / 16 : 0;
@@ -223,8 +275,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_w8a8o16_kernel(con
 #pragma unroll
             for (int e = 0; e < 16; ++e) P[e] = 0.f;
             if (has_outliers) {
-                const char* xo = smem + (wn * WN + i * 32 + lr) * OSLICE;
-                const char* yo = smem + BN * OSLICE + (wm * WM + j * 32 + lr) * OSLICE;
+                const char* xo = smem_all + (wn * WN + i * 32 + lr) * OSLICE;
+                const char* yo = smem_all + BN * OSLICE + (wm * WM + j * 32 + lr) * OSLICE;
                 const int sw16 = lr & 15;
                 for (int ks = 0; ks < osteps; ++ks) {
                     const int off = ((ks * 2 + lh) ^ sw16) << 4;
@@ -268,12 +320,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_w8a8o16_kernel(con
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int NSTAGE = 2>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int NSTAGE = 2, int KG = 1>
 static hipError_t launch_cfg(const GemmParams& p, hipStream_t st)
 {
-    constexpr int T = WAVES_M * WAVES_N * 64;
-    constexpr size_t lds = NSTAGE * (size_t)(BM + BN) * KSLICE;
-    auto kern = gemm_w8a8o16_kernel<BM, BN, WAVES_M, WAVES_N, EPI, NSTAGE>;
+    constexpr int T = WAVES_M * WAVES_N * KG * 64;
+    constexpr size_t lds = (size_t)KG * NSTAGE * (size_t)(BM + BN) * KSLICE;
+    auto kern = gemm_w8a8o16_kernel<BM, BN, WAVES_M, WAVES_N, EPI, NSTAGE, KG>;
     static bool attr_done = false; // benign race: idempotent
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -308,11 +360,23 @@ static hipError_t launch_epi(const GemmParams& p, hipStream_t st)
     case 13: return launch_cfg<64, 32, 2, 1, EPI, 8>(p, st);
     case 14: return launch_cfg<128, 128, 2, 4, EPI, 4>(p, st);
     case 15: return launch_cfg<32, 128, 1, 4, EPI, 4>(p, st);
+    case 16: return launch_cfg<64, 64, 2, 2, EPI, 2, 4>(p, st);
+    case 17: return launch_cfg<64, 64, 2, 2, EPI, 2, 2>(p, st);
+    case 18: return launch_cfg<32, 64, 1, 2, EPI, 2, 4>(p, st);
+    case 19: return launch_cfg<128, 64, 4, 2, EPI, 2, 2>(p, st);
+    case 20: return launch_cfg<64, 32, 2, 1, EPI, 2, 4>(p, st);
+    case 21: return launch_cfg<64, 128, 2, 4, EPI, 2, 2>(p, st);
     default: break;
     }
     // Measured choice (tools/cfg_sweep.sh, M = 32..1024 on 12288x4096, 4096x11008, 4096x4096): small problems are
     // bound by how many workgroups stream operands concurrently, so the 64x64 tile wins until ~3 workgroups per CU.
-    const int64_t wg64 = (int64_t)((p.M + 63) / 64) * ((p.N + 63) / 64);
+    // Rule distilled from the sweep: keep ~16 wavefronts on every CU.  With few tiles, several groups of waves share one
+    // tile and split K among themselves (KG = 4, then 2); with ~3 tiles per CU plain 64x64 tiles; beyond that 128x128.
+    const int64_t n64 = (p.N + 63) / 64;
+    const int64_t wg32 = (int64_t)((p.M + 31) / 32) * n64, wg64 = (int64_t)((p.M + 63) / 64) * n64;
+    if (wg32 <= 256) return launch_cfg<32, 64, 1, 2, EPI, 2, 4>(p, st);
+    if (wg64 <= 256) return launch_cfg<64, 64, 2, 2, EPI, 2, 4>(p, st);
+    if (wg64 <= 512) return launch_cfg<64, 64, 2, 2, EPI, 2, 2>(p, st);
     if (wg64 <= 768) return launch_cfg<64, 64, 2, 2, EPI>(p, st);
     return launch_cfg<128, 128, 2, 4, EPI>(p, st);
 }
@@ -356,8 +420,9 @@ hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st)
 {
     if (p.M <= 0 || p.N <= 0) return hipSuccess;
     const int variant = gemm_variant();
-    // M <= 32, or M <= 64 with too few 64x64 tiles to fill the chip: weight-streaming GEMV-like kernel
-    if (variant != 1 && gemm_skinny_supported(p) && (p.M <= 32 || p.N < 8192)) return launch_gemm_skinny(p, epi, st);
+    // M <= 16, and M <= 32 on narrow outputs: the weight-streaming GEMV-like kernel (measured against the split-K tiles)
+    if (variant != 1 && gemm_skinny_supported(p) && (p.M <= 16 || (p.M <= 32 && p.N < 8192)))
+        return launch_gemm_skinny(p, epi, st);
     const int64_t tiles256 = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256);
     if (variant >= 100) return launch_gemm_pp_ablate(p, variant - 100, st); // measurement-only ablations
     if (variant == 3 && gemm_pp2_supported(p, epi)) return launch_gemm_pp2(p, epi, st);
