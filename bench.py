@@ -78,6 +78,40 @@ def synth_activation(M, K, ind, dev, gen):
     return A.to(torch.float16)
 
 
+def small_m_points(lib, TensorDesc, dev, gen, st_ptr, iters=300):
+    """Informational (never part of `value`): the HBM-bound end of the same operator, SURVEY §8d -- BASELINE config 0
+    (one 4096 x 4096 MixQ linear, bs = 32) and a decode step (bs = 1, W8A16 GEMV on `qweight`) through mixq_enqueue,
+    as weight bytes / time against the HBM peak."""
+    out = {}
+    N = K = 4096
+    t = synth_layer(N, K, dev, gen)
+    for name, M in (("config0_bs32_4096x4096", 32), ("decode_bs1_4096x4096", 1)):
+        A = synth_activation(M, K, t["ind_i32"], dev, gen)
+        o = torch.empty((M, N), dtype=torch.float16, device=dev)
+        ins = [A, t["weight"], t["weights_scaling_factor"], t["fp_weight"], t["fp_ind"], t["qweight"],
+               t["weights_scaling_factor"]]
+        in_desc = (TensorDesc * 7)(*[TensorDesc.make(x.shape) for x in ins])
+        out_desc = TensorDesc.make(o.shape)
+        in_ptrs = (ctypes.c_void_p * 7)(*[x.data_ptr() for x in ins])
+        out_ptrs = (ctypes.c_void_p * 1)(o.data_ptr())
+        h = ctypes.c_void_p(lib.mixq_create(M, N, K))
+        ws = torch.empty(max(lib.mixq_workspace_size(h, M, N, K), 16), dtype=torch.uint8, device=dev)
+        run = lambda: lib.mixq_enqueue(h, in_desc, ctypes.byref(out_desc), in_ptrs, out_ptrs,  # noqa: E731
+                                       ctypes.c_void_p(ws.data_ptr()), st_ptr)
+        for _ in range(20):
+            assert run() == 0
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            run()
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / iters
+        lib.mixq_destroy(h)
+        out[name] = {"us_per_call": dt * 1e6, "weight_GBps": N * K / dt / 1e9, "hbm_frac": N * K / dt / 8e12,
+                     "launches_per_call": 2 if M > 4 else 1}
+    return out
+
+
 def cpu_baseline(seconds_target=15.0):
     """The oracle (CPU restatement of the reference arithmetic, OpenMP) on a bounded sample: ONE Llama-2-7B layer
     (its three MixQ linears), M tokens chosen so the run takes ~seconds_target; tokens/s for the full model = M /
@@ -298,6 +332,10 @@ def main():
                          "ops_per_launch": ops_per_launch,
                          "gemm_share_of_wall": gemm_ms / 1e3 / elapsed},
         }
+        try:  # informational small-M points (HBM-bound end of the operator); never part of `value`
+            res["small_m"] = small_m_points(lib, TensorDesc, dev, gen, st_ptr)
+        except Exception as e:  # noqa: BLE001
+            res["small_m"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline()
