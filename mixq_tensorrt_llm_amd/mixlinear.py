@@ -121,6 +121,7 @@ class MixLinear_GEMM:
                 self.ind = torch.empty((fp_features_num,), dtype=torch.int32, device=dev)
         self.bias = torch.empty((out_features,), dtype=torch.float16, device=dev) if bias else None
         self.cnt = 0
+        self.forward_without_precondition_len = fp_features_num if (bit == 4 and not weight_only) else -1  # :68-71
         self.add_outliers = True
         self.sigma = None
         if cache is not None:
@@ -168,9 +169,10 @@ class MixLinear_GEMM:
         return find_outliers(activation, float(self.sigma[0, 0]))
 
     @torch.no_grad()
-    def forward(self, x, cache=None, unfused=True):
-        """linear.py:163-286.  ``unfused=True`` quantises ``x`` here (the fused variant gets q_xcache / x_scale /
-        activation_outliers from the preceding norm layer through the cache, exactly like the reference)."""
+    def forward(self, x, cache=None, unfused=False):
+        """linear.py:163-286.  ``unfused=True`` quantises ``x`` here; with the default (``False``, as in the reference)
+        q_xcache / x_scale / activation_outliers come through the cache from the preceding fused norm layer
+        (`FasterTransformerRMSNorm` with ``next_layer`` set)."""
         cache = self.cache if cache is None else cache
         cache.shape = x.shape[:-1] + (self.out_features,)
         inputs = x.reshape(-1, x.shape[-1])
@@ -220,5 +222,83 @@ class MixLinear_GEMM:
         if self.bias is not None:
             y1 += self.bias
         return y1.reshape(cache.shape)
+
+    __call__ = forward
+
+    @torch.no_grad()
+    def forward_without_preconditionFusedSilu(self, x, cache):
+        """linear.py:288-375: the gate projection of an MLP.  Re-uses the activation that the up projection has just
+        quantised (cache.q_xcache / x_scale / activation_outliers / ind) -- no second quantisation pass -- adopts the
+        outlier columns the up projection may have added, and applies SiLU in the GEMM epilogue."""
+        inputs = x.reshape(-1, x.shape[-1])
+        M = inputs.shape[0]
+        if self.forward_without_precondition_len != cache.ind.shape[0]:
+            if cache.ind.shape[0]:
+                ind = cache.new_ind
+                if self.bit == 8:
+                    weight_cache = dequant_weight_columns(self.q_weight, self.scale_col, ind)
+                else:
+                    weight_cache = mixlib.unpack_int4_to_fp16(self.q_weight, ind) * self.scale_col.T
+                if self.ind.shape[0] == 0:
+                    self.weight_cache = weight_cache
+                else:
+                    self.weight_cache = torch.hstack((self.weight_cache, weight_cache))
+            self.ind = cache.ind
+            self.forward_without_precondition_len = self.ind.shape[0]
+        y = outlier_product(cache.activation_outliers, self.weight_cache) if self.ind.shape[0] else None
+        if self.bit == 8:
+            y1 = mixlib.int8FusedDequantizeSilu(cache.q_xcache, self.q_weight, cache.x_scale, self.scale_col, y, M,
+                                                self.out_features, self.in_features)
+        else:
+            if y is None:
+                raise RuntimeError("int4 mod should have outliers !")  # :364
+            y1 = mixlib.int4FusedDequantizeSilu(cache.q_xcache, self.q_weight, cache.x_scale, self.scale_col, y, M,
+                                                self.out_features, self.in_features // 2)
+        if self.bias is not None:
+            y1 += self.bias
+        return y1.reshape(cache.shape)
+
+
+class FasterTransformerRMSNorm:
+    """MixQ/src/mixquant/modules/fused/norm.py:6-40: RMSNorm that, when ``next_layer`` is a MixLinear_GEMM, also
+    extracts (+zeroes) that layer's outlier columns and quantises the rows in the same pass over the hidden state
+    (`mixq_rmsnorm_extract_quant`), leaving q_xcache / x_scale / activation_outliers in the cache."""
+
+    def __init__(self, weight, eps=1e-6, cache=None):
+        self.weight = weight.to(torch.float16)
+        self.variance_epsilon = eps
+        self.cache = cache
+        self.next_layer = None
+
+    @torch.no_grad()
+    def forward(self, x):
+        output = torch.empty_like(x)
+        if self.next_layer is None:
+            mixlib.layernorm_forward_cuda(x, self.weight, output, self.variance_epsilon)
+        elif self.next_layer.bit == 8:
+            self.cache.activation_outliers, self.cache.q_xcache = mixlib.layernorm_forward_cuda_extract_outliers(
+                x, self.weight, output, self.variance_epsilon, self.next_layer.ind, self.cache.x_scale)
+        else:
+            raise NotImplementedError("the fused 4-bit norm producer is not built")
+        return output
+
+    __call__ = forward
+
+
+class MixLlamaMLP:
+    """MixQ/src/mixquant/modules/fused/mlp.py:37-68: down(silu(gate(x)) * up(x)) where the gate projection re-uses the
+    up projection's quantised activation and has SiLU fused into its GEMM epilogue."""
+
+    def __init__(self, gate_proj, down_proj, up_proj, MixGemmCache=None):
+        self.down_proj_, self.gate_proj_, self.up_proj_ = down_proj, gate_proj, up_proj
+        self.out_features = down_proj.out_features
+        self.MLPCache = MixGemmCache
+
+    @torch.no_grad()
+    def forward(self, x):
+        up_output = self.up_proj_(x, self.MLPCache)            # fused producer: the norm in front filled the cache
+        gate_output = self.gate_proj_.forward_without_preconditionFusedSilu(x, self.MLPCache)
+        gate_output *= up_output
+        return self.down_proj_(gate_output, None, True)
 
     __call__ = forward

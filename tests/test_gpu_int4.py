@@ -94,7 +94,7 @@ def test_mixlinear_4bit_from_linear_and_forward(oracle):
     x[:, ind] *= 12.0                       # the calibrated outlier columns carry the large activations
     x_ref = x.copy()
     xt = dev(x)
-    got = layer.forward(xt, cache).cpu().numpy()
+    got = layer.forward(xt, cache, True).cpu().numpy()
     want = oracle.mixlinear4_forward(qp, sc, ind, wc, x_ref)
     assert layer.ind.numel() == FP, "no dynamic growth expected: the remaining activations stay below sigma"
     assert np.array_equal(bits(xt.cpu().numpy()), bits(x_ref))

@@ -94,7 +94,7 @@ def test_mixlinear_dynamic_outliers_state_machine(oracle, bias):
         x[rng.integers(0, M, len(hot)), hot] = np.float16(20.0)
         x_ref = x.copy()
         xt = dev(x)
-        got = layer.forward(xt, cache).cpu().numpy()
+        got = layer.forward(xt, cache, True).cpu().numpy()
         want = oracle.mixlinear_forward(st, x_ref)
         assert np.array_equal(layer.ind.cpu().numpy(), st.ind), f"step {step}: outlier index set"
         assert layer.add_outliers == st.add_outliers and layer.cnt == st.cnt
@@ -115,7 +115,7 @@ def test_mixlinear_no_outliers_and_3d_input(oracle):
     layer = mixlinear.MixLinear_GEMM.from_linear(torch.from_numpy(W), cache=cache, dev="cuda:0")
     st = oracle.MixLinearState(layer.q_weight.cpu().numpy(), layer.scale_col.cpu().numpy(), sigma=6.0)
     x = (rng.standard_normal((2, 9, K)) * 0.5).astype(np.float16)       # nothing above sigma
-    got = layer.forward(dev(x), cache).cpu().numpy()
+    got = layer.forward(dev(x), cache, True).cpu().numpy()
     assert got.shape == (2, 9, N)
     want = oracle.mixlinear_forward(st, x.reshape(-1, K).copy())
     assert layer.ind.numel() == 0 and rel_err(got.reshape(-1, N), want) < REL_TOL
@@ -132,3 +132,71 @@ def test_mixlinear_weight_only_mode(oracle):
     got = layer.forward(dev(x)).cpu().numpy()
     q_un, scales = oracle.eetq_symmetric_quantize(W.T.copy())
     assert rel_err(got, oracle.w8a16_gemv(x, q_un, scales)) < 5e-3
+
+
+def test_fused_norm_and_llama_mlp_block(oracle):
+    """norm.py:6-40 + mlp.py:37-68: FasterTransformerRMSNorm (next_layer = up_proj) fills the cache in one pass,
+    up_proj consumes it (and discovers outlier columns dynamically), gate_proj re-uses the SAME quantised activation with
+    SiLU fused into its epilogue and adopts the new columns, gate *= up, down_proj quantises its own input.
+    Followed step by step against the oracle; then the packaged MixLlamaMLP must give the same bits as the steps."""
+    from mixq_tensorrt_llm_amd import mixlinear
+    rng = np.random.default_rng(23)
+    H, F, M = 512, 1024, 40
+    Wu, _ = make_layer(rng, F, H, False)
+    Wg, _ = make_layer(rng, F, H, False)
+    Wd, _ = make_layer(rng, H, F, False)
+    gamma = (1.0 + 0.1 * rng.standard_normal(H)).astype(np.float16)
+    eps = 1e-6
+    hidden = rng.standard_normal((M, H)).astype(np.float16)
+    hidden[3, 17] = np.float16(60.0)        # survives the norm as |x| > sigma -> dynamic outlier column 17
+    hidden[9, 300] = np.float16(-45.0)
+
+    def build():
+        cache = mixlinear.MixLibCache(inputdim=64, sigma=6, device="cuda:0")
+        mk = lambda W: mixlinear.MixLinear_GEMM.from_linear(torch.from_numpy(W), cache=cache, dev="cuda:0")  # noqa: E731
+        up, gate, down = mk(Wu), mk(Wg), mk(Wd)
+        norm = mixlinear.FasterTransformerRMSNorm(dev(gamma), eps, cache)
+        norm.next_layer = up
+        return cache, norm, up, gate, down
+
+    # ---- oracle, step by step -------------------------------------------------------------------------
+    cache, norm, up, gate, down = build()
+    st = {n: oracle.MixLinearState(l.q_weight.cpu().numpy(), l.scale_col.cpu().numpy(), sigma=6.0)
+          for n, l in (("up", up), ("gate", gate), ("down", down))}
+    x_ref, outl, qx, xs = oracle.rmsnorm_extract_quant(hidden, gamma, eps, np.zeros(0, np.int32))
+    x_ref = np.ascontiguousarray(x_ref)
+    assert np.abs(x_ref.astype(np.float32)).max() > 6.0, "the test needs a dynamic outlier"
+    new_ind = oracle.find_outliers(x_ref, 6.0)
+    act_out = oracle.extract_outliers(x_ref, new_ind, set_zero=True)
+    st["up"].weight_cache = oracle.dequant_weight_columns(st["up"].q_weight, st["up"].scale_col, new_ind)
+    st["up"].ind = new_ind
+    qx, xs = oracle.quant_rows(x_ref)
+    up_want = oracle.dequant_epilogue(oracle.gemm_s8s8s32(qx, st["up"].q_weight), xs, st["up"].scale_col,
+                                      C=oracle.gemm_fp16(act_out, st["up"].weight_cache))
+    wc_gate = oracle.dequant_weight_columns(st["gate"].q_weight, st["gate"].scale_col, new_ind)
+    gate_want = oracle.dequant_epilogue(oracle.gemm_s8s8s32(qx, st["gate"].q_weight), xs, st["gate"].scale_col,
+                                        C=oracle.gemm_fp16(act_out, wc_gate), silu=True)
+
+    # ---- GPU, step by step ----------------------------------------------------------------------------
+    x = norm(dev(hidden))
+    assert np.array_equal(cache.q_xcache.cpu().numpy(), oracle.rmsnorm_extract_quant(
+        hidden, gamma, eps, np.zeros(0, np.int32))[2]), "fused norm -> int8 rows"
+    up_got = up(x, cache)
+    assert np.array_equal(up.ind.cpu().numpy(), new_ind) and 17 in new_ind and 300 in new_ind
+    assert np.array_equal(cache.q_xcache.cpu().numpy(), qx), "rows re-quantised after the outlier columns were zeroed"
+    assert rel_err(up_got.cpu().numpy(), up_want) < REL_TOL
+    gate_got = gate.forward_without_preconditionFusedSilu(x, cache)
+    assert np.array_equal(gate.ind.cpu().numpy(), new_ind)
+    assert np.array_equal(gate.weight_cache.cpu().numpy().view(np.uint16), wc_gate.view(np.uint16))
+    assert rel_err(gate_got.cpu().numpy(), gate_want) < REL_TOL
+    gate_got *= up_got
+    h = gate_got.cpu().numpy().copy()
+    y_got = down(gate_got, None, True).cpu().numpy()
+    y_want = oracle.mixlinear_forward(st["down"], h)          # same input bits: isolates the down projection
+    assert rel_err(y_got, y_want) < REL_TOL
+
+    # ---- the packaged block gives the same bits ------------------------------------------------------------
+    cache2, norm2, up2, gate2, down2 = build()
+    mlp = mixlinear.MixLlamaMLP(gate2, down2, up2, cache2)
+    y2 = mlp(norm2(dev(hidden))).cpu().numpy()
+    assert np.array_equal(y2.view(np.uint16), y_got.view(np.uint16))
