@@ -171,6 +171,13 @@ MIXQ_API int mixq_dequantization(void* out_f16, const int32_t* x, const void* sc
 MIXQ_API int mixq_w8a16_gemm_forward(const void* input_f16, const uint8_t* weight, const void* scale_f16,
                                      void* output_f16, int m, int n, int k, void* stream);
 
+/* MLP fusion beyond the reference (MixQ/src/mixquant/modules/fused/mlp.py:57-64 runs int8FusedDequantizeSilu and then
+ * `gate_output *= up_output` as a separate pass over [M,N]): D = fp16( fp16(silu(float(A.B^T)*(sc*sr) + y)) * mul ),
+ * bit-identical to the two-step sequence, one pass.  mul = fp16 [M,N] (the up projection's output), 8-byte aligned. */
+MIXQ_API int mixq_int8_fused_dequantize_silu_mul(const int8_t* A, const int8_t* B, const void* scale_row,
+                                                 const void* scale_col, const void* y, const void* mul, void* D, int M,
+                                                 int N, int K, char* workspace, void* stream);
+
 /* ---- dynamic outliers of the P-flavour forward (MixQ/src/mixquant/modules/linear.py) ------------- */
 /* FindOutliers (linear.py:155-161): torch.unique(torch.where(A.abs() > sigma)[1]) -> ascending int32 column indices of
  * fp16 A [M,K] that hold at least one |a| > sigma (NaN compares false).  `mask_ws` = device scratch of

@@ -306,8 +306,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KG * 64) void gemm_w8a8o16_kernel
                             // addend: the fp16-rounded outlier product (cuBLAS writes fp16) or the caller's y
                             const float c = has_outliers ? h2f(f2h_bits_of_f32_result(P[4 * g + e])) : h2f(yh[e]);
                             float v = __builtin_fmaf((float)acc[i][j][4 * g + e], h2f(swh[e]) * sa, c);
-                            if (EPI == EPI_DEQUANT_SILU) v = v / (1.f + __expf(-v));
+                            if (epi_has_silu(EPI)) v = v / (1.f + __expf(-v));
                             oh[e] = f2h_bits_of_f32_result(v);
+                        }
+                        if (EPI == EPI_DEQUANT_SILU_MUL) { // gate * up: one fp16 multiply of the rounded result
+                            const uint2 mb = *reinterpret_cast<const uint2*>(p.Mul + (int64_t)m * p.N + nb);
+                            const uint16_t mh[4] = {(uint16_t)(mb.x & 0xffffu), (uint16_t)(mb.x >> 16),
+                                                    (uint16_t)(mb.y & 0xffffu), (uint16_t)(mb.y >> 16)};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) oh[e] = f2h_bits(h2f(oh[e]) * h2f(mh[e]));
                         }
                         uint2 o;
                         o.x = (unsigned)oh[0] | ((unsigned)oh[1] << 16);
@@ -431,6 +438,7 @@ hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st)
     switch (epi) {
     case EPI_DEQUANT: return launch_epi<EPI_DEQUANT>(p, st);
     case EPI_DEQUANT_SILU: return launch_epi<EPI_DEQUANT_SILU>(p, st);
+    case EPI_DEQUANT_SILU_MUL: return launch_epi<EPI_DEQUANT_SILU_MUL>(p, st);
     default: return launch_epi<EPI_INT32>(p, st);
     }
 }

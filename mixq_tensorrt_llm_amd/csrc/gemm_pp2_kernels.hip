@@ -493,7 +493,7 @@ static hipError_t launch_pp2_epi(const GemmParams& p, hipStream_t st)
 // Persistent ping-pong GEMM.  Requires at least 4 K slices (K > 384) and an fp16 epilogue.
 bool gemm_pp2_supported(const GemmParams& p, int epi)
 {
-    return epi != EPI_INT32 && p.K > 3 * pp2::KS;
+    return (epi == EPI_DEQUANT || epi == EPI_DEQUANT_SILU) && p.K > 3 * pp2::KS;
 }
 
 hipError_t launch_gemm_pp2(const GemmParams& p, int epi, hipStream_t st)

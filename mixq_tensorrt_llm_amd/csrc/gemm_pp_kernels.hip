@@ -365,6 +365,43 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             swq[i][g] = *reinterpret_cast<const uint2*>(p.sW + min(n0 + wn * 64 + i * 32 + 4 * lh + 8 * g, p.N - 4));
+    // [M,N] fp16 operands of the epilogue (the caller's addend y, the gate*up multiplicand) take the store path in
+    // reverse: coalesced 16-byte loads of 128-byte row segments (8 rows per instruction), one block ahead, then through
+    // the wave's window into the accumulator layout (8 bytes = 4 consecutive n of row lane & 31).  Reading them in the
+    // accumulator layout directly costs 32 cache lines of 16 useful bytes per load instruction.
+    constexpr bool HAS_MUL = EPI == EPI_DEQUANT_SILU_MUL;
+    uint2 yq[2][4], mq[2][4];
+    uint4 ypre[4], mpre[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ypre[q] = mpre[q] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) yq[i][g] = mq[i][g] = make_uint2(0u, 0u);
+    const int64_t src_wave = ((int64_t)(m0 + wm * 128) * p.N + n0 + wn * 64) * 2; // byte offset of the wave tile
+    const unsigned src_lane = ((unsigned)(lane >> 3) * (unsigned)p.N + (lane & 7) * 8) * 2;
+    const bool src_n_ok = n0 + wn * 64 + (lane & 7) * 8 < p.N;
+    const int win_rd = (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4);
+    auto fetch = [&](const uint16_t* src, int j, uint4 (&v)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = j * 32 + q * 8; // wave-uniform
+            const char* a = reinterpret_cast<const char*>(src) + src_wave + (int64_t)row * p.N * 2 + src_lane;
+            const bool ok = src_n_ok && m0 + wm * 128 + row + (lane >> 3) < p.M;
+            v[q] = ok ? *reinterpret_cast<const uint4*>(a) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto spread = [&](const uint4 (&v)[4], uint2 (&out)[2][4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<uint4*>(wstg + q * 1024 + win_rd) = v[q];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                out[i][g] = *reinterpret_cast<const uint2*>(wstg + lr * 128 + (((i * 4 + g) ^ (lr & 7)) << 4) + lh * 8);
+    };
+    if (HAS_Y) fetch(p.Y, 0, ypre);
+    if (HAS_MUL) fetch(p.Mul, 0, mpre);
     // dequant of tile (i, j) with its side product P -> 4 quads (4 consecutive n of row m each) -> window
     auto dequant = [&](int i, int j, const v16f& P) __attribute__((always_inline)) {
 #pragma unroll
@@ -374,12 +411,11 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
                                   h2f((uint16_t)(swb.y & 0xffffu)), h2f((uint16_t)(swb.y >> 16))};
             uint16_t yh[4] = {0, 0, 0, 0};
             if (HAS_Y) {
-                const int m = min(m0 + wm * 128 + j * 32 + lr, p.M - 1);
-                const int nb = min(n0 + wn * 64 + i * 32 + 4 * lh + 8 * g, p.N - 4);
-                const uint2 yb = *reinterpret_cast<const uint2*>(p.Y + (int64_t)m * p.N + nb);
+                const uint2 yb = yq[i][g];
                 yh[0] = (uint16_t)(yb.x & 0xffffu), yh[1] = (uint16_t)(yb.x >> 16);
                 yh[2] = (uint16_t)(yb.y & 0xffffu), yh[3] = (uint16_t)(yb.y >> 16);
             }
+            const uint2 mulq = mq[i][g];
             unsigned ow[2];
 #pragma unroll
             for (int e2 = 0; e2 < 4; e2 += 2) {
@@ -394,11 +430,12 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
                 }
                 float v0 = __builtin_fmaf((float)acc[i][j][4 * g + e2], s2[0], c2[0]);
                 float v1 = __builtin_fmaf((float)acc[i][j][4 * g + e2 + 1], s2[1], c2[1]);
-                if (EPI == EPI_DEQUANT_SILU) {
+                if (epi_has_silu(EPI)) {
                     v0 = v0 / (1.f + __expf(-v0));
                     v1 = v1 / (1.f + __expf(-v1));
                 }
-                const v2h o16 = f2h2_of_f32_results(v0, v1);
+                v2h o16 = f2h2_of_f32_results(v0, v1);
+                if (EPI == EPI_DEQUANT_SILU_MUL) o16 = o16 * __builtin_bit_cast(v2h, e2 ? mulq.y : mulq.x); // gate * up
                 __builtin_memcpy(&ow[e2 >> 1], &o16, 4);
             }
             const int c = i * 4 + g; // 16-byte chunk of the 128-byte row
@@ -435,6 +472,14 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
         for (int t = 0; t < 8; ++t) {
             v16f Pnext = Pcur;
             if (t + 1 < 8) Pnext = side((t + 1) & 1, (t + 1) >> 1);
+            if ((HAS_Y || HAS_MUL) && (t & 1) == 0) { // block j = t >> 1 starts: operands of this block -> registers
+                if (HAS_Y) spread(ypre, yq);
+                if (HAS_MUL) spread(mpre, mq);
+                if (t + 2 < 8) {
+                    if (HAS_Y) fetch(p.Y, (t >> 1) + 1, ypre);
+                    if (HAS_MUL) fetch(p.Mul, (t >> 1) + 1, mpre);
+                }
+            }
             dequant(t & 1, t >> 1, Pcur);
             if (t & 1) flush(t >> 1);
             Pcur = Pnext;
@@ -497,6 +542,7 @@ hipError_t launch_gemm_pp(const GemmParams& p, int epi, hipStream_t st)
     switch (epi) {
     case EPI_DEQUANT: return launch_pp_epi<EPI_DEQUANT>(p, st);
     case EPI_DEQUANT_SILU: return launch_pp_epi<EPI_DEQUANT_SILU>(p, st);
+    case EPI_DEQUANT_SILU_MUL: return launch_pp_epi<EPI_DEQUANT_SILU_MUL>(p, st);
     default: return launch_pp_cfg<EPI_INT32, false, false>(p, st);
     }
 }

@@ -123,8 +123,15 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
             for (int e = 0; e < 4; ++e) {
                 const float c = p.O > 0 ? h2f(f2h_bits_of_f32_result(P[e])) : h2f(yh[e]);
                 float v = __builtin_fmaf((float)a[e], h2f(swh[e]) * sa, c);
-                if (EPI == EPI_DEQUANT_SILU) v = v / (1.f + __expf(-v));
+                if (epi_has_silu(EPI)) v = v / (1.f + __expf(-v));
                 oh[e] = f2h_bits_of_f32_result(v);
+            }
+            if (EPI == EPI_DEQUANT_SILU_MUL) { // gate * up
+                const uint2 mb = *reinterpret_cast<const uint2*>(p.Mul + (int64_t)m * p.N + nb);
+                const uint16_t mh[4] = {(uint16_t)(mb.x & 0xffffu), (uint16_t)(mb.x >> 16), (uint16_t)(mb.y & 0xffffu),
+                                        (uint16_t)(mb.y >> 16)};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) oh[e] = f2h_bits(h2f(oh[e]) * h2f(mh[e]));
             }
             uint2 o;
             o.x = (unsigned)oh[0] | ((unsigned)oh[1] << 16);
@@ -170,6 +177,7 @@ hipError_t launch_gemm_skinny(const GemmParams& p, int epi, hipStream_t st)
     switch (epi) {
     case EPI_DEQUANT: return launch_skinny_epi<EPI_DEQUANT>(p, st);
     case EPI_DEQUANT_SILU: return launch_skinny_epi<EPI_DEQUANT_SILU>(p, st);
+    case EPI_DEQUANT_SILU_MUL: return launch_skinny_epi<EPI_DEQUANT_SILU_MUL>(p, st);
     default: return launch_skinny_epi<EPI_INT32>(p, st);
     }
 }

@@ -335,7 +335,8 @@ int mixq_rmsnorm_extract_quant(int M, int K, const void* x, const void* gamma, v
 }
 
 static int fused_dequant_impl(const int8_t* A, const int8_t* B, const void* scale_row, const void* scale_col,
-                              const void* y, void* D, int M, int N, int K, int epi, void* stream)
+                              const void* y, void* D, int M, int N, int K, int epi, void* stream,
+                              const void* mul = nullptr)
 {
     if (M < 0 || N < 0 || K <= 0) return MIXQ_E_BADARG;
     if (M == 0 || N == 0) return MIXQ_OK;
@@ -347,6 +348,8 @@ static int fused_dequant_impl(const int8_t* A, const int8_t* B, const void* scal
     p.A = A, p.B = B;
     p.sA = static_cast<const uint16_t*>(scale_row), p.sW = static_cast<const uint16_t*>(scale_col);
     p.Y = static_cast<const uint16_t*>(y), p.D = D;
+    p.Mul = static_cast<const uint16_t*>(mul);
+    if (epi == mixq::EPI_DEQUANT_SILU_MUL && (!mul || (reinterpret_cast<uintptr_t>(mul) & 7u))) return MIXQ_E_BADARG;
     p.zeros = mixq::zero_page();
     p.M = M, p.N = N, p.K = K, p.O = 0;
     if (!p.zeros) return MIXQ_E_HIP;
@@ -425,6 +428,13 @@ int mixq_unpack_int4_to_int8(const uint8_t* src, int8_t* dst, size_t packed_byte
     if (packed_bytes % 16) return MIXQ_E_SHAPE;
     if (!aligned16(src) || !aligned16(dst)) return MIXQ_E_ALIGN;
     return hip_rc(mixq::launch_unpack_s4(src, dst, packed_bytes, static_cast<hipStream_t>(stream)));
+}
+
+int mixq_int8_fused_dequantize_silu_mul(const int8_t* A, const int8_t* B, const void* scale_row, const void* scale_col,
+                                        const void* y, const void* mul, void* D, int M, int N, int K,
+                                        char* /*workspace*/, void* stream)
+{
+    return fused_dequant_impl(A, B, scale_row, scale_col, y, D, M, N, K, mixq::EPI_DEQUANT_SILU_MUL, stream, mul);
 }
 
 int mixq_gemm_mixed(const int8_t* qA, const int8_t* W, const void* sA, const void* sW, const void* fpA,

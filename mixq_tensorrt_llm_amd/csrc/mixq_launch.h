@@ -5,7 +5,8 @@
 
 namespace mixq {
 
-enum { EPI_DEQUANT = 0, EPI_DEQUANT_SILU = 1, EPI_INT32 = 2 };
+enum { EPI_DEQUANT = 0, EPI_DEQUANT_SILU = 1, EPI_INT32 = 2, EPI_DEQUANT_SILU_MUL = 3 };
+constexpr bool epi_has_silu(int epi) { return epi == EPI_DEQUANT_SILU || epi == EPI_DEQUANT_SILU_MUL; }
 
 struct GemmParams {
     const int8_t* A;      // qA [M,K]
@@ -15,6 +16,7 @@ struct GemmParams {
     const uint16_t* fpA;  // [M,O] or null
     const uint16_t* fpW;  // [N,O] or null
     const uint16_t* Y;    // fp16 [M,N] addend or null (int8FusedDequantize API)
+    const uint16_t* Mul;  // fp16 [M,N] multiplicand of EPI_DEQUANT_SILU_MUL: D = fp16(fp16(silu(..)) * Mul), else null
     void* D;              // fp16 [M,N] (EPI_DEQUANT*) or int32 [M,N] (EPI_INT32)
     const void* zeros;    // >= 16 B of device zeros (K / O tails)
     int M, N, K, O;

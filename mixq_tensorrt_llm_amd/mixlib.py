@@ -14,7 +14,7 @@ __all__ = ["FindRowScale", "ExtractOutliersAndSetToZeros", "int8FusedDequantize"
            "dequantizeInt8", "Int8quantize", "FindRowScaleFusedExtracOutliers", "layernorm_forward_cuda",
            "layernorm_forward_cuda_extract_outliers", "int_to_half", "int_matrix_to_half",
            "int8_matrix_to_half", "w8_a16_gemm", "preprocess_weights", "mixq_linear", "int4FusedDequantize",
-           "int4FusedDequantizeSilu", "unpack_int4_to_fp16"]
+           "int4FusedDequantizeSilu", "unpack_int4_to_fp16", "int8FusedDequantizeSiluMul"]
 
 
 def _st(t):
@@ -107,6 +107,16 @@ def unpack_int4_to_fp16(weight, ind):
     _lib.check(_lib.load().mixq_unpack_int4_to_fp16(_p(weight), _p(ind), rows, colsp, n, _p(out), _st(weight)),
                "unpack_int4_to_fp16")
     return out
+
+
+def int8FusedDequantizeSiluMul(A, B, scale_row, scale_col, y, mul, M, N, K):
+    """MI355X extension (no reference op): int8FusedDequantizeSilu followed by ``*= mul`` (fused/mlp.py:61-63) in ONE
+    kernel: D = fp16(fp16(silu(...)) * mul), the same bits as the two-step sequence."""
+    _dev(*(t for t in (A, B, scale_row, scale_col, y, mul) if t is not None))
+    D = torch.empty((M, N), dtype=torch.float16, device=A.device)
+    _lib.check(_lib.load().mixq_int8_fused_dequantize_silu_mul(_p(A), _p(B), _p(scale_row), _p(scale_col), _p(y), _p(mul),
+                                                              _p(D), M, N, K, None, _st(A)), "int8FusedDequantizeSiluMul")
+    return D
 
 
 def gemm(mat1, mat2, m, n, k):

@@ -226,10 +226,12 @@ class MixLinear_GEMM:
     __call__ = forward
 
     @torch.no_grad()
-    def forward_without_preconditionFusedSilu(self, x, cache):
+    def forward_without_preconditionFusedSilu(self, x, cache, mul=None):
         """linear.py:288-375: the gate projection of an MLP.  Re-uses the activation that the up projection has just
         quantised (cache.q_xcache / x_scale / activation_outliers / ind) -- no second quantisation pass -- adopts the
-        outlier columns the up projection may have added, and applies SiLU in the GEMM epilogue."""
+        outlier columns the up projection may have added, and applies SiLU in the GEMM epilogue.  ``mul`` (MI355X
+        extension, bit = 8): a [.., N] fp16 tensor multiplied into the rounded result inside the same epilogue --
+        `gate *= up` without another pass over [M, N]."""
         inputs = x.reshape(-1, x.shape[-1])
         M = inputs.shape[0]
         if self.forward_without_precondition_len != cache.ind.shape[0]:
@@ -246,7 +248,12 @@ class MixLinear_GEMM:
             self.ind = cache.ind
             self.forward_without_precondition_len = self.ind.shape[0]
         y = outlier_product(cache.activation_outliers, self.weight_cache) if self.ind.shape[0] else None
-        if self.bit == 8:
+        fused_mul = mul is not None and self.bit == 8 and self.bias is None
+        if fused_mul:
+            y1 = mixlib.int8FusedDequantizeSiluMul(cache.q_xcache, self.q_weight, cache.x_scale, self.scale_col, y,
+                                                   mul.reshape(M, self.out_features), M, self.out_features,
+                                                   self.in_features)
+        elif self.bit == 8:
             y1 = mixlib.int8FusedDequantizeSilu(cache.q_xcache, self.q_weight, cache.x_scale, self.scale_col, y, M,
                                                 self.out_features, self.in_features)
         else:
@@ -256,6 +263,9 @@ class MixLinear_GEMM:
                                                 self.out_features, self.in_features // 2)
         if self.bias is not None:
             y1 += self.bias
+        if mul is not None and not fused_mul:
+            y1 = y1.reshape(cache.shape)
+            y1 *= mul
         return y1.reshape(cache.shape)
 
 
@@ -297,8 +307,8 @@ class MixLlamaMLP:
     @torch.no_grad()
     def forward(self, x):
         up_output = self.up_proj_(x, self.MLPCache)            # fused producer: the norm in front filled the cache
-        gate_output = self.gate_proj_.forward_without_preconditionFusedSilu(x, self.MLPCache)
-        gate_output *= up_output
+        # `gate_output *= up_output` (mlp.py:63) rides in the gate GEMM's epilogue: same bits, one pass less over [M, N]
+        gate_output = self.gate_proj_.forward_without_preconditionFusedSilu(x, self.MLPCache, mul=up_output)
         return self.down_proj_(gate_output, None, True)
 
     __call__ = forward

@@ -200,3 +200,25 @@ def test_fused_norm_and_llama_mlp_block(oracle):
     mlp = mixlinear.MixLlamaMLP(gate2, down2, up2, cache2)
     y2 = mlp(norm2(dev(hidden))).cpu().numpy()
     assert np.array_equal(y2.view(np.uint16), y_got.view(np.uint16))
+
+
+@pytest.mark.parametrize("M,N,K", [(16, 512, 1024), (200, 768, 640), (300, 4096, 512), (2048, 3072, 512)])
+def test_fused_silu_mul_epilogue_is_the_two_step_sequence(M, N, K):
+    """int8FusedDequantizeSiluMul == int8FusedDequantizeSilu followed by `*= up` (fused/mlp.py:61-63), bit for bit, on
+    every GEMM kernel (skinny, two-barrier incl. split-K, ping-pong)."""
+    from mixq_tensorrt_llm_amd import mixlib
+    g = torch.Generator(device="cpu").manual_seed(M + N)
+    a = torch.randint(-127, 128, (M, K), dtype=torch.int8, generator=g).to("cuda:0")
+    b = torch.randint(-127, 128, (N, K), dtype=torch.int8, generator=g).to("cuda:0")
+    sa = (torch.rand(M, 1, generator=g) * 1e-2 + 1e-3).to(torch.float16).to("cuda:0")
+    sb = (torch.rand(1, N, generator=g) * 1e-3 + 1e-4).to(torch.float16).to("cuda:0")
+    y = (torch.randn(M, N, generator=g) * 0.5).to(torch.float16).to("cuda:0")
+    up = torch.randn(M, N, generator=g).to(torch.float16).to("cuda:0")
+    two_step = mixlib.int8FusedDequantizeSilu(a, b, sa, sb, y, M, N, K)
+    two_step *= up
+    fused = mixlib.int8FusedDequantizeSiluMul(a, b, sa, sb, y, up, M, N, K)
+    assert torch.equal(fused, two_step)
+    fused0 = mixlib.int8FusedDequantizeSiluMul(a, b, sa, sb, None, up, M, N, K)     # no addend
+    ref0 = mixlib.int8FusedDequantizeSilu(a, b, sa, sb, None, M, N, K)
+    ref0 *= up
+    assert torch.equal(fused0, ref0)
