@@ -438,3 +438,32 @@ def test_full_size_linearity_and_row_independence():
     out_p = mixlib.mixq_linear(A[perm].contiguous(), w1, sW, fpw, ind)
     assert torch.equal(out[perm], out_p)
     assert torch.isfinite(out).all()
+
+
+@pytest.mark.parametrize("M", [3, 48, 700])
+def test_enqueue_is_capturable_in_a_hip_graph(oracle, M):
+    """The operator is a fixed sequence of launches on the caller's stream (no allocation, no host sync): after one warm
+    call it can be captured into a HIP graph and replayed on new data in the same buffers -- decode (M <= 4), the
+    split-K tile kernel and the ping-pong kernel."""
+    from mixq_tensorrt_llm_amd import plugin
+    N, K = 1024, 2048
+    A, W, act = make_layer(M, N, K, seed=77 + M)
+    p = oracle.pack_linear_weights(W, act)
+    layer = plugin.MixQLinear(K, N, device=dev()).load(p)
+    x = to_dev(np.zeros_like(A))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        out = layer(x)                           # warm-up: one-time function attributes, workspace allocation
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            out = layer(x)
+    torch.cuda.current_stream().wait_stream(side)
+    for trial in range(2):
+        A2 = np.ascontiguousarray(np.roll(A, trial * 3, axis=0))
+        x.copy_(to_dev(A2))
+        graph.replay()
+        torch.cuda.synchronize()
+        eager = run_enqueue(A2, p)
+        assert np.array_equal(bits(out.cpu().numpy().reshape(M, N)), bits(eager)), "graph replay == eager launch"
