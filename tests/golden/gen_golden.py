@@ -80,7 +80,76 @@ def main():
         weights_scaling_factor=wsf.numpy(), fp_ind=fp_ind.to(torch.int32).numpy(),
         fp_weight=fp_weight.numpy(), weight_int8=q.numpy(),
     )
+    pflavour_fixture()
     print("wrote", os.listdir(OUT))
+
+
+def pflavour_fixture():
+    """pflavour_small.npz: outputs of the REFERENCE's own Python code for the PyTorch flavour
+    (MixQ/src/mixquant/modules/linear.py), executed from the reference file on CPU tensors:
+      * ``pack_to_i4`` (:13-17) on seeded int8 values;
+      * ``MixLinear_GEMM.from_linear`` for bit = 8 (:113-120) and bit = 4 (:121-143): q_weight, scale_col, ind,
+        weight_cache;
+      * ``MixLinear_GEMM.FindOutliers`` (:155-161) on a seeded activation with inf / NaN / == sigma entries.
+    The file imports the CUDA extension modules ``mixlib`` and ``EETQ`` at the top and calls ``.cuda()`` on tensors; for
+    the import they are satisfied by empty placeholder modules and, while the functions run, ``Tensor.cuda`` /
+    ``torch.cuda.get_device_capability`` are pointed at CPU no-ops -- none of the captured functions calls into either
+    extension, every captured value is produced by the reference's own lines."""
+    for name, attrs in (("mixlib", ()), ("EETQ", ("quant_weights", "preprocess_weights", "w8_a16_gemm"))):
+        m = types.ModuleType(name)
+        for a in attrs:
+            setattr(m, a, None)
+        sys.modules[name] = m
+    spec = importlib.util.spec_from_file_location("ref_mixquant_linear", f"{REF}/MixQ/src/mixquant/modules/linear.py")
+    lin = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lin)
+
+    keep_cuda, keep_cap = torch.Tensor.cuda, torch.cuda.get_device_capability
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.cuda.get_device_capability = lambda *a, **k: (8, 0)
+    try:
+        g = torch.Generator().manual_seed(4321)
+        blob = {}
+        q = torch.randint(-8, 8, (12, 64), generator=g, dtype=torch.int8)
+        blob["i4_in"] = q.numpy()
+        blob["i4_packed"] = lin.pack_to_i4(q).numpy()
+
+        class Linear:  # the attributes from_linear reads from an nn.Linear
+            pass
+
+        class Cache:
+            sigma = 6
+            stop = 2
+
+        N, K = 48, 512   # bit = 4 keeps the reference's default of 256 fp16 outlier columns
+        W = (torch.randn(N, K, generator=g) * 0.02).to(torch.float16)
+        W[2, 9] = 0.4
+        layer_scales = torch.rand(K, generator=g)
+        blob["W"], blob["layer_scales"] = W.numpy(), layer_scales.numpy()
+        for bit in (8, 4):
+            fake = Linear()
+            fake.in_features, fake.out_features, fake.bias = K, N, None
+            fake.weight = types.SimpleNamespace(data=W.clone())
+            cache = Cache()
+            cache.sigma = torch.tensor(6.0)
+            ql = lin.MixLinear_GEMM.from_linear(fake, bit, cache=cache, layer_scales=layer_scales, dev="cpu")
+            blob[f"w{bit}_q_weight"] = ql.q_weight.numpy()
+            blob[f"w{bit}_scale_col"] = ql.scale_col.numpy().reshape(-1)
+            if bit == 4:
+                blob["w4_ind"] = ql.ind.numpy()
+                blob["w4_weight_cache"] = ql.weight_cache.numpy()
+        A = torch.randn(40, 256, generator=g).clamp_(-5, 5).to(torch.float16)
+        A[torch.randint(0, 40, (25,), generator=g), torch.randint(0, 256, (25,), generator=g)] = 8.25
+        A[3, 10], A[4, 11], A[5, 12] = float("nan"), float("inf"), 6.0
+        finder = lin.MixLinear_GEMM.__new__(lin.MixLinear_GEMM)
+        torch.nn.Module.__init__(finder)
+        finder.sigma = torch.zeros((1, 1), dtype=torch.float16)
+        finder.sigma[0] = 6
+        blob["fo_A"] = A.numpy()
+        blob["fo_ind"] = lin.MixLinear_GEMM.FindOutliers(finder, A).numpy()
+    finally:
+        torch.Tensor.cuda, torch.cuda.get_device_capability = keep_cuda, keep_cap
+    np.savez_compressed(os.path.join(OUT, "pflavour_small.npz"), **blob)
 
 
 if __name__ == "__main__":

@@ -222,3 +222,24 @@ def test_fused_silu_mul_epilogue_is_the_two_step_sequence(M, N, K):
     ref0 = mixlib.int8FusedDequantizeSilu(a, b, sa, sb, None, M, N, K)
     ref0 *= up
     assert torch.equal(fused0, ref0)
+
+
+def test_product_reproduces_the_reference_generated_fixture():
+    """pflavour_small.npz = outputs of the reference's own linear.py (see tests/golden/gen_golden.py): the product's
+    from_linear (bit 8 and 4, on the GPU) and the find_outliers kernel reproduce them bit for bit."""
+    import os
+    from conftest import GOLDEN
+    from mixq_tensorrt_llm_amd import mixlinear
+    g = np.load(os.path.join(GOLDEN, "pflavour_small.npz"))
+    W = torch.from_numpy(g["W"])
+    cache = mixlinear.MixLibCache(inputdim=64, sigma=6, device="cuda:0")
+    l8 = mixlinear.MixLinear_GEMM.from_linear(W, bit=8, cache=cache, dev="cuda:0")
+    assert np.array_equal(l8.q_weight.cpu().numpy(), g["w8_q_weight"])
+    assert np.array_equal(l8.scale_col.cpu().numpy().reshape(-1).view(np.uint16), g["w8_scale_col"].view(np.uint16))
+    l4 = mixlinear.MixLinear_GEMM.from_linear(W, bit=4, cache=cache, dev="cuda:0",
+                                              layer_scales=torch.from_numpy(g["layer_scales"]), fp_features_num=256)
+    assert np.array_equal(l4.ind.cpu().numpy(), g["w4_ind"])
+    assert np.array_equal(l4.q_weight.cpu().numpy(), g["w4_q_weight"])
+    assert np.array_equal(l4.scale_col.cpu().numpy().reshape(-1).view(np.uint16), g["w4_scale_col"].view(np.uint16))
+    assert np.array_equal(l4.weight_cache.cpu().numpy().view(np.uint16), g["w4_weight_cache"].view(np.uint16))
+    assert np.array_equal(mixlinear.find_outliers(dev(g["fo_A"]), 6.0).cpu().numpy(), g["fo_ind"])

@@ -184,3 +184,31 @@ def test_int4_packing_and_weight_quant_against_torch_expressions(oracle):
     assert np.array_equal(sc.view(np.uint16), scale.numpy().reshape(-1).view(np.uint16))
     assert np.array_equal(qp, packed.numpy())
     assert np.array_equal(wc.view(np.uint16), weight_cache.numpy().view(np.uint16))
+
+
+def test_pflavour_fixture_from_the_reference_linear_py(oracle):
+    """tests/golden/pflavour_small.npz holds outputs of the reference's own MixQ/src/mixquant/modules/linear.py
+    (pack_to_i4, MixLinear_GEMM.from_linear for bit 8 and 4, FindOutliers), captured by gen_golden.py.  The oracle's
+    restatements and the product's host-side `from_linear` / `pack_to_i4` must reproduce them exactly."""
+    torch = pytest.importorskip("torch")
+    from mixq_tensorrt_llm_amd import mixlinear
+    g = np.load(os.path.join(GOLDEN, "pflavour_small.npz"))
+    # pack_to_i4
+    assert np.array_equal(oracle.pack_i4(g["i4_in"]), g["i4_packed"])
+    assert np.array_equal(mixlinear.pack_to_i4(torch.from_numpy(g["i4_in"])).numpy(), g["i4_packed"])
+    assert np.array_equal(oracle.unpack_i4(g["i4_packed"]), g["i4_in"])
+    # FindOutliers
+    assert np.array_equal(oracle.find_outliers(g["fo_A"], 6.0), g["fo_ind"])
+    # from_linear, bit = 4 (oracle restatement)
+    qp, sc, ind, wc = oracle.mixlinear4_from_linear(g["W"], g["layer_scales"], 256)
+    assert np.array_equal(np.sort(ind), np.sort(g["w4_ind"]))      # (tie order of torch.sort is unspecified)
+    assert np.array_equal(sc.view(np.uint16), g["w4_scale_col"].view(np.uint16))
+    assert np.array_equal(qp, g["w4_q_weight"])
+    order = {c: i for i, c in enumerate(g["w4_ind"])}
+    assert np.array_equal(wc[:, [list(ind).index(c) for c in g["w4_ind"]]].view(np.uint16),
+                          g["w4_weight_cache"].view(np.uint16)) and len(order) == 256
+    # from_linear, bit = 8: scale = fp16(max|w| / 127), q = round(w / scale), no clamp
+    W = g["W"]
+    sc8 = (np.abs(W).max(axis=1) / np.float16(127)).astype(np.float16)
+    assert np.array_equal(sc8.view(np.uint16), g["w8_scale_col"].view(np.uint16))
+    assert np.array_equal(np.rint((W / sc8[:, None]).astype(np.float16).astype(np.float64)).astype(np.int8), g["w8_q_weight"])
