@@ -84,7 +84,7 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp2_kernel(const GemmParams 
     const int group = wave >> 2;          // 0: waves 0-3, 1: waves 4-7 (one of each per SIMD)
     const int wm = wave & 1;              // 2 wave rows along m (128 each)
     const int wn = wave >> 1;             // 4 wave columns along n (64 each)
-    const int lr = lane & 31, lh = lane >> 5;
+    (void)lane; // (fragment offsets are recomputed per tile from an opaque thread id: setup_frag_offsets)
 
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     const int nwg = tiles_m * tiles_n;
