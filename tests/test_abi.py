@@ -132,3 +132,40 @@ def test_qweight_layout_importer_matches_oracle(lib, oracle):
     assert lib.mixq_unprocess_weights_int8(back.ctypes.data, got.ctypes.data, K, N) == 0
     assert np.array_equal(back, q)
     assert lib.mixq_preprocess_weights_int8(got.ctypes.data, q.ctypes.data, 100, N) == 2
+
+
+def test_argument_validation_returns_codes_and_never_touches_the_device():
+    """Bad arguments are rejected before any HIP call (return codes, no exceptions across the C boundary), so these run
+    without a GPU: null pointers, negative sizes, K / N not multiples of 16, misaligned pointers."""
+    import ctypes
+    from mixq_tensorrt_llm_amd import _lib
+    lib = _lib.load()
+    OK, BADARG, SHAPE, ALIGN = 0, 1, 2, 3
+    buf = (ctypes.c_char * 4096)()
+    p = ctypes.addressof(buf)
+    p16 = ctypes.c_void_p((p + 15) & ~15)
+    odd = ctypes.c_void_p(((p + 15) & ~15) + 2)
+    # quantiser: null pointers, K % 8, misaligned A
+    assert lib.mixq_quant_extract(4, 64, None, p16, p16, None, None, 0, 0, None) == BADARG
+    assert lib.mixq_quant_extract(4, 60, p16, p16, p16, None, None, 0, 0, None) == SHAPE
+    assert lib.mixq_quant_extract(4, 64, odd, p16, p16, None, None, 0, 0, None) == ALIGN
+    assert lib.mixq_quant_extract(-1, 64, p16, p16, p16, None, None, 0, 0, None) == BADARG
+    assert lib.mixq_quant_extract(0, 64, None, None, None, None, None, 0, 0, None) == OK      # empty input is fine
+    # fused GEMM: K / N multiples of 16, alignment, nulls
+    assert lib.mixq_gemm_mixed(p16, p16, p16, p16, None, None, p16, 8, 64, 40, 0, None) == SHAPE
+    assert lib.mixq_gemm_mixed(p16, p16, p16, p16, None, None, p16, 8, 60, 64, 0, None) == SHAPE
+    assert lib.mixq_gemm_mixed(odd, p16, p16, p16, None, None, p16, 8, 64, 64, 0, None) == ALIGN
+    assert lib.mixq_gemm_mixed(None, p16, p16, p16, None, None, p16, 8, 64, 64, 0, None) == BADARG
+    assert lib.mixq_gemm_mixed(p16, p16, p16, p16, None, None, p16, 8, 64, 64, 128, None) == BADARG  # O > 0 without operands
+    assert lib.mixq_gemm_mixed(p16, p16, p16, p16, None, None, p16, 0, 64, 64, 0, None) == OK
+    assert lib.mixq_int8_fused_dequantize(p16, p16, p16, p16, None, p16, 8, 64, 24, None, None) == SHAPE
+    assert lib.mixq_int8_fused_dequantize_silu_mul(p16, p16, p16, p16, None, None, p16, 8, 64, 64, None, None) == BADARG
+    # 4-bit flavour and outlier helpers
+    assert lib.mixq_int4quant(4, 60, p16, p16, p16, None) == SHAPE
+    assert lib.mixq_int4_fused_dequantize(p16, p16, p16, p16, None, p16, 8, 64, 24, p16, None) == SHAPE
+    assert lib.mixq_int4_fused_dequantize(p16, p16, p16, p16, None, p16, 8, 64, 32, None, None) == BADARG  # no workspace
+    assert lib.mixq_find_outliers(p16, 4, 60, ctypes.c_float(6.0), p16, p16, p16, 8, None) == SHAPE
+    assert lib.mixq_find_outliers(p16, 4, 64, ctypes.c_float(6.0), None, p16, p16, 8, None) == BADARG
+    assert lib.mixq_find_outliers_workspace_size(4096) == 512 and lib.mixq_int4_fused_workspace_size(32, 64, 16) == 32 * 32 + 64 * 32
+    for code in (1, 2, 3, 4, 5):
+        assert lib.mixq_error_string(code)
