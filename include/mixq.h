@@ -208,6 +208,12 @@ MIXQ_API int mixq_int4_fused_dequantize(const uint8_t* A, const uint8_t* B, cons
 MIXQ_API int mixq_int4_fused_dequantize_silu(const uint8_t* A, const uint8_t* B, const void* scale_row,
                                              const void* scale_col, const void* y, void* D, int M, int N, int k_packed,
                                              char* workspace, void* stream);
+/* layernorm_forward_cuda_extract_outliers_int4 (layernorm/layernorm.cu:201-290, 379-414): the fused RMSNorm producer
+ * with 4-bit rows: out fp16 [M,K] (normalised, outlier columns zeroed), outliers fp16 [M,len], q_packed uint8 [M,K/2]
+ * (scale = fp16(amax/7)), scale fp16 [M].  Same constraints as mixq_rmsnorm_extract_quant. */
+MIXQ_API int mixq_rmsnorm_extract_quant4(int M, int K, const void* x_f16, const void* gamma_f16, void* out_f16, float eps,
+                                         const int32_t* ind, int len, void* outliers_f16, uint8_t* q_packed,
+                                         void* scale_f16, void* stream);
 /* unpack_int4_to_fp16 (cult.cu:3020-3043, 3088-3118): out[r, c] = fp16(int4 value of weight[r, ind[c]]),
  * weight uint8 [rows, cols_packed], out fp16 [rows, n]. */
 MIXQ_API int mixq_unpack_int4_to_fp16(const uint8_t* weight, const int32_t* ind, int rows, int cols_packed, int n,

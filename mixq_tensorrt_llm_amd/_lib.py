@@ -84,6 +84,7 @@ SIGNATURES = {
     "mixq_extract_outliers_set_zero": (_i, [_i, _i, _vp, _vp, _vp, _i, _vp]),
     "mixq_quant_extract": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "mixq_int4quant": (_i, [_i, _i, _vp, _vp, _vp, _vp]),
+    "mixq_rmsnorm_extract_quant4": (_i, [_i, _i, _vp, _vp, _vp, ctypes.c_float, _vp, _i, _vp, _vp, _vp, _vp]),
     "mixq_int4_fused_workspace_size": (ctypes.c_size_t, [_i, _i, _i]),
     "mixq_int4_fused_dequantize": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "mixq_int4_fused_dequantize_silu": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),

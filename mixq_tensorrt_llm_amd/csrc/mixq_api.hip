@@ -330,8 +330,20 @@ int mixq_rmsnorm_extract_quant(int M, int K, const void* x, const void* gamma, v
     if (len > 0 && (!ind || !outliers)) return MIXQ_E_BADARG;
     if (K % 8 || K > 32768) return MIXQ_E_SHAPE;
     if (!aligned16(x) || !aligned16(gamma) || !aligned16(out) || (reinterpret_cast<uintptr_t>(q) & 7u)) return MIXQ_E_ALIGN;
-    return hip_rc(mixq::launch_rmsnorm_quant(x, gamma, out, outliers, ind, q, scale, eps, M, K, len, true,
+    return hip_rc(mixq::launch_rmsnorm_quant(x, gamma, out, outliers, ind, q, scale, eps, M, K, len, 8,
                                              static_cast<hipStream_t>(stream)));
+}
+
+int mixq_rmsnorm_extract_quant4(int M, int K, const void* x, const void* gamma, void* out, float eps, const int32_t* ind,
+                                int len, void* outliers, uint8_t* q_packed, void* scale, void* stream)
+{
+    if (M < 0 || K <= 0 || len < 0 || (M > 0 && (!x || !gamma || !out || !q_packed || !scale))) return MIXQ_E_BADARG;
+    if (len > 0 && (!ind || !outliers)) return MIXQ_E_BADARG;
+    if (K % 8 || K > 32768) return MIXQ_E_SHAPE;
+    if (!aligned16(x) || !aligned16(gamma) || !aligned16(out) || (reinterpret_cast<uintptr_t>(q_packed) & 3u))
+        return MIXQ_E_ALIGN;
+    return hip_rc(mixq::launch_rmsnorm_quant(x, gamma, out, outliers, ind, reinterpret_cast<int8_t*>(q_packed), scale, eps,
+                                             M, K, len, 4, static_cast<hipStream_t>(stream)));
 }
 
 static int fused_dequant_impl(const int8_t* A, const int8_t* B, const void* scale_row, const void* scale_col,

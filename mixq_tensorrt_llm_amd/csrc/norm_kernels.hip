@@ -18,7 +18,8 @@ namespace mixq {
 
 constexpr int NBLOCK = 256;
 
-template <int TPR, int MAXV, bool QUANT>
+// QUANT: 0 = plain RMSNorm, 8 = int8 rows (scale amax/127), 4 = packed int4 rows (scale amax/7, layernorm.cu:201-290)
+template <int TPR, int MAXV, int QUANT>
 __global__ __launch_bounds__(NBLOCK) void rmsnorm_quant_kernel(const uint16_t* __restrict__ X,
                                                                const uint16_t* __restrict__ gamma,
                                                                uint16_t* __restrict__ out, uint16_t* __restrict__ outl,
@@ -160,10 +161,28 @@ __global__ __launch_bounds__(NBLOCK) void rmsnorm_quant_kernel(const uint16_t* _
         amax = row_max(amax);
     }
     const uint16_t amax_bits = amax < 0 ? (uint16_t)0x7fffu : (uint16_t)amax;
-    const uint16_t s_bits = f2h_bits(h2f(amax_bits) / 127.0f);
+    const uint16_t s_bits = f2h_bits(h2f(amax_bits) / (QUANT == 4 ? 7.0f : 127.0f));
     const float s = h2f(s_bits);
     const float rs = 1.0f / s;
     if (row_ok && t == 0) scale[row] = s_bits;
+    if (QUANT == 4) { // packed int4 pairs: element 2i in the low nibble (cutlass::int4b_t), low 4 bits of half2int_rn
+        unsigned* __restrict__ dst4 = reinterpret_cast<unsigned*>(q + (row_ok ? row : 0) * (int64_t)(K >> 1));
+        for (int v = 0; v < MAXV; ++v) {
+            const int idx = v * TPR + t;
+            if (row_ok && idx < nvec) {
+                const unsigned w[4] = {x[v].x, x[v].y, x[v].z, x[v].w};
+                unsigned o = 0u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned q0 = (unsigned)quant_one(h2f((uint16_t)(w[e] & 0xffffu)), s) & 0xfu;
+                    const unsigned q1 = (unsigned)quant_one(h2f((uint16_t)(w[e] >> 16)), s) & 0xfu;
+                    o |= (q0 | (q1 << 4)) << (8 * e);
+                }
+                dst4[idx] = o;
+            }
+        }
+        return;
+    }
     uint2* __restrict__ dstq = reinterpret_cast<uint2*>(q + (row_ok ? row : 0) * (int64_t)K);
     if (amax_all < 0x7c00 && s_bits != 0) { // every element finite, scale finite and non-zero (row-uniform)
 #pragma unroll
@@ -192,7 +211,7 @@ __global__ __launch_bounds__(NBLOCK) void rmsnorm_quant_kernel(const uint16_t* _
 template <int TPR, int MAXV>
 static hipError_t launch_norm(const uint16_t* X, const uint16_t* gamma, uint16_t* out, uint16_t* outl,
                               const int32_t* ind, int8_t* q, uint16_t* scale, float eps, int M, int K, int O,
-                              bool quant, hipStream_t st)
+                              int quant, hipStream_t st)
 {
     constexpr int RPB = NBLOCK / TPR;
     const dim3 grid((unsigned)((M + RPB - 1) / RPB)), block(NBLOCK);
@@ -200,23 +219,30 @@ static hipError_t launch_norm(const uint16_t* X, const uint16_t* gamma, uint16_t
         const size_t lds = (size_t)((K + 127) / 128) * 16 + (size_t)RPB * K * 2;
         static bool attr_done = false; // rows of 8192 x 4 waves need more than the default 64 KiB of dynamic LDS
         if (!attr_done) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rmsnorm_quant_kernel<TPR, MAXV, true>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rmsnorm_quant_kernel<TPR, MAXV, 8>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(rmsnorm_quant_kernel<TPR, MAXV, 4>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
             if (e != hipSuccess) return e;
             attr_done = true;
         }
-        hipLaunchKernelGGL((rmsnorm_quant_kernel<TPR, MAXV, true>), grid, block, lds, st, X, gamma, out, outl, ind, q,
-                           scale, eps, M, K, O);
+        if (quant == 4)
+            hipLaunchKernelGGL((rmsnorm_quant_kernel<TPR, MAXV, 4>), grid, block, lds, st, X, gamma, out, outl, ind, q,
+                               scale, eps, M, K, O);
+        else
+            hipLaunchKernelGGL((rmsnorm_quant_kernel<TPR, MAXV, 8>), grid, block, lds, st, X, gamma, out, outl, ind, q,
+                               scale, eps, M, K, O);
     } else {
-        hipLaunchKernelGGL((rmsnorm_quant_kernel<TPR, MAXV, false>), grid, block, 0, st, X, gamma, out, outl, ind, q,
+        hipLaunchKernelGGL((rmsnorm_quant_kernel<TPR, MAXV, 0>), grid, block, 0, st, X, gamma, out, outl, ind, q,
                            scale, eps, M, K, O);
     }
     return hipGetLastError();
 }
 
-// quant = false: plain RMSNorm (only `out`).  Returns hipErrorInvalidValue for rows longer than 32768 elements.
+// quant = 0: plain RMSNorm (only `out`), 8 / 4: fused producer.  hipErrorInvalidValue for rows longer than 32768.
 hipError_t launch_rmsnorm_quant(const void* X, const void* gamma, void* out, void* outl, const int32_t* ind, int8_t* q,
-                                void* scale, float eps, int M, int K, int O, bool quant, hipStream_t st)
+                                void* scale, float eps, int M, int K, int O, int quant, hipStream_t st)
 {
     if (M <= 0) return hipSuccess;
     const uint16_t* x = static_cast<const uint16_t*>(X);

@@ -14,7 +14,8 @@ __all__ = ["FindRowScale", "ExtractOutliersAndSetToZeros", "int8FusedDequantize"
            "dequantizeInt8", "Int8quantize", "FindRowScaleFusedExtracOutliers", "layernorm_forward_cuda",
            "layernorm_forward_cuda_extract_outliers", "int_to_half", "int_matrix_to_half",
            "int8_matrix_to_half", "w8_a16_gemm", "preprocess_weights", "mixq_linear", "int4FusedDequantize",
-           "int4FusedDequantizeSilu", "unpack_int4_to_fp16", "int8FusedDequantizeSiluMul"]
+           "int4FusedDequantizeSilu", "unpack_int4_to_fp16", "int8FusedDequantizeSiluMul",
+           "layernorm_forward_cuda_extract_outliers_int4", "ExtractOutliers"]
 
 
 def _st(t):
@@ -179,6 +180,31 @@ def layernorm_forward_cuda_extract_outliers(_input, _gamma, _out, eps, _ind, sca
                                                       _p(_ind), n, _p(outl), _p(q), _p(scaleRow), _st(_input)),
                "layernorm_forward_cuda_extract_outliers")
     return [outl, q]
+
+
+def layernorm_forward_cuda_extract_outliers_int4(_input, _gamma, _out, eps, _ind, scaleRow):
+    """layernorm.cu:379-414: the same fused producer with packed 4-bit rows (scale = amax / 7).
+    Returns [outliers fp16 [m,len], quant uint8 [m, c/2]]."""
+    _dev(_input, _gamma, _out, _ind, scaleRow)
+    c = _input.shape[-1]
+    m = _input.numel() // c
+    n = _ind.shape[0]
+    outl = torch.zeros((m, n), dtype=torch.float16, device=_input.device)
+    q = torch.empty((m, c // 2), dtype=torch.uint8, device=_input.device)
+    _lib.check(_lib.load().mixq_rmsnorm_extract_quant4(m, c, _p(_input), _p(_gamma), _p(_out), ctypes.c_float(eps),
+                                                       _p(_ind), n, _p(outl), _p(q), _p(scaleRow), _st(_input)),
+               "layernorm_forward_cuda_extract_outliers_int4")
+    return [outl, q]
+
+
+def ExtractOutliers(ind, input):
+    """cult.cu ExtractOutliers: input[:, ind] as fp16 [M, len]; `input` is left untouched (T-flavour gather)."""
+    _dev(ind, input)
+    m, k = input.shape
+    n = ind.shape[0]
+    out = torch.zeros((m, n), dtype=torch.float16, device=input.device)
+    _lib.check(_lib.load().mixq_extract_outliers(m, k, _p(input), _p(out), _p(ind), n, _st(input)), "ExtractOutliers")
+    return out
 
 
 def int_to_half(int_ind):

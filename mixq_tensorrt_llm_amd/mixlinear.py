@@ -288,8 +288,11 @@ class FasterTransformerRMSNorm:
         elif self.next_layer.bit == 8:
             self.cache.activation_outliers, self.cache.q_xcache = mixlib.layernorm_forward_cuda_extract_outliers(
                 x, self.weight, output, self.variance_epsilon, self.next_layer.ind, self.cache.x_scale)
+        elif self.next_layer.bit == 4:
+            self.cache.activation_outliers, self.cache.q_xcache = mixlib.layernorm_forward_cuda_extract_outliers_int4(
+                x, self.weight, output, self.variance_epsilon, self.next_layer.ind, self.cache.x_scale)
         else:
-            raise NotImplementedError("the fused 4-bit norm producer is not built")
+            raise NotImplementedError
         return output
 
     __call__ = forward

@@ -103,3 +103,33 @@ def test_mixlinear_4bit_from_linear_and_forward(oracle):
     # 4-bit weights + 4-bit activations are coarse, but the result must still track the fp product
     ref = x.astype(np.float64) @ W.astype(np.float64).T
     assert np.abs(g - ref).max() / np.abs(ref).max() < 0.35
+
+
+def test_fused_norm_4bit_producer(oracle):
+    """layernorm_forward_cuda_extract_outliers_int4 == RMSNorm -> extract + zero -> FindRowScale(bit = 4), one pass."""
+    from mixq_tensorrt_llm_amd import mixlib
+    rng = np.random.default_rng(31)
+    M, K = 37, 4096
+    x = (rng.standard_normal((M, K)) * 3).astype(np.float16)
+    gamma = (1.0 + 0.1 * rng.standard_normal(K)).astype(np.float16)
+    ind = np.sort(rng.choice(K, 64, replace=False)).astype(np.int32)
+    x[:, ind] *= 10
+    out = torch.empty((M, K), dtype=torch.float16, device="cuda:0")
+    sc = torch.empty((M, 1), dtype=torch.float16, device="cuda:0")
+    outl, q4 = mixlib.layernorm_forward_cuda_extract_outliers_int4(dev(x), dev(gamma), out, 1e-6, dev(ind), sc)
+    o_ref, outl_ref, _, _ = oracle.rmsnorm_extract_quant(x, gamma, 1e-6, ind)
+    out_np = out.cpu().numpy()
+    # the normalised row is within one fp16 ulp of the oracle's (the sum of squares is reduced in another order) ...
+    denom = np.maximum(np.abs(o_ref.astype(np.float64)), 1e-3)
+    assert (np.abs(out_np.astype(np.float64) - o_ref.astype(np.float64)) / denom).max() < 1.1e-3
+    assert np.all(out_np[:, ind] == 0)
+    assert (np.abs(outl.cpu().numpy().astype(np.float64) - outl_ref.astype(np.float64))
+            / np.maximum(np.abs(outl_ref.astype(np.float64)), 1e-3)).max() < 1.1e-3
+    # ... and given the GPU's normalised row, scale and packed 4-bit rows are bit-exact
+    q_ref, s_ref = oracle.quant4_rows(np.ascontiguousarray(out_np))
+    assert np.array_equal(bits(sc.cpu().numpy().reshape(-1)), bits(s_ref))
+    assert np.array_equal(q4.cpu().numpy(), q_ref)
+    # ExtractOutliers (non-zeroing gather)
+    xa = dev(x)
+    got = mixlib.ExtractOutliers(dev(ind), xa).cpu().numpy()
+    assert np.array_equal(bits(got), bits(x[:, ind])) and np.array_equal(bits(xa.cpu().numpy()), bits(x))
