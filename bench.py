@@ -346,6 +346,13 @@ def main():
                          "avg_launch_ms": avg_launch_s * 1e3, "launches": n_launch,
                          "ops_per_launch": ops_per_launch,
                          "gemm_share_of_wall": gemm_ms / 1e3 / elapsed},
+            # the other launch of every call (fused quantise + outlier extract, HBM-bound): algorithmic bytes of SURVEY §8d
+            # row a4 over the wall time NOT spent in the GEMM (so launch gaps count against it)
+            "quantizer": (lambda qb, qt: {"bound": "hbm", "achieved": qb / qt / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                          "frac": qb / qt / 8e12, "avg_launch_ms": qt * 1e3,
+                                          "bytes_per_launch": qb, "timing": "step wall time minus GEMM event time"})(
+                sum(chunk * (3 * k + 2 + 2 * NUM_OUTLIERS) for _, _, k in LLAMA2_7B["linears"]) / 3.0,
+                max(elapsed - gemm_ms / 1e3, 1e-9) / n_launch),
         }
         try:  # informational small-M points (HBM-bound end of the operator); never part of `value`
             res["small_m"] = small_m_points(lib, TensorDesc, dev, gen, st_ptr)
