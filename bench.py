@@ -3,8 +3,8 @@
 
 One "step" = one prefill pass of `--tokens` synthetic tokens (default 512 x 2048 = 1,048,576, BASELINE.json's quoted
 config) through every MixQ'd linear of Llama-2-7B (attention.qkv 12288x4096, mlp.gate 11008x4096, mlp.proj 4096x11008;
-32 layers = 96 operator calls per token chunk), executed in M-chunks of `--chunk` tokens (tokens/s is chunk-invariant,
-SURVEY.md §8).  Every call goes through the drop-in C ABI (`mixq_enqueue_profiled` == `mixq_enqueue` + two event
+32 layers = 96 operator calls per token chunk), executed in M-chunks of `--chunk` tokens (default 65536 = 32 sequences;
+the work per token does not depend on the chunk).  Every call goes through the drop-in C ABI (`mixq_enqueue_profiled` == `mixq_enqueue` + two event
 records around the GEMM launch).  Inputs (activations, packed weights) are resident in HBM before the timed region.
 
   python bench.py --gpus N --steps K --warmup W           (N>1: launched by torch.distributed.run, one rank per GPU)
@@ -154,7 +154,9 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--tokens", type=int, default=512 * 2048, help="tokens per step per DP replica")
-    ap.add_argument("--chunk", type=int, default=16384, help="M of each operator call (SURVEY §8: 8192-16384)")
+    ap.add_argument("--chunk", type=int, default=65536,
+                    help="M of each operator call.  65536 tokens = 32 sequences: 256 tile rows, so that the 256x256 tiles "
+                         "of all three shapes (48 / 43 / 16 tile columns) fill the 256 CUs in whole rounds")
     ap.add_argument("--tp", type=int, default=1, help="rows-of-W sharding degree (1 = pure DP, no collective)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--order", choices=["layer", "chunk"], default="layer",
