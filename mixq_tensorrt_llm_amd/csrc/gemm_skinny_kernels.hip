@@ -42,6 +42,34 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[t] = v4i{0, 0, 0, 0};
 
+    // Epilogue operands of the m-tile this wave will finish (tile `wave`; KW >= MT, so at most one per wave) are requested
+    // NOW -- the first 128 outlier columns of the side GEMM, the row scale, the weight scales -- so that their L2 round
+    // trip runs under the weight stream instead of after it (the kernel is a chain of latencies at this size).
+    constexpr int PRE = 4; // pre-loaded side-GEMM steps (32 outlier columns each)
+    v8h pxf[PRE], pyf[PRE];
+    uint16_t psa = 0;
+    uint2 psw = {0u, 0u};
+    const bool fin = EPI != EPI_INT32 && wave < MT; // this wave runs an fp16 epilogue
+    const int fm = wave * 16 + lr, fnb = n0 + 4 * lq;
+    if (fin) {
+        const int obytes = p.O * 2;
+        const char* xw = reinterpret_cast<const char*>(p.fpW) + (int64_t)min(n0 + lr, p.N - 1) * obytes;
+        const char* ya = reinterpret_cast<const char*>(p.fpA) + (int64_t)min(fm, p.M - 1) * obytes;
+#pragma unroll
+        for (int u = 0; u < PRE; ++u) {
+            const int kb = u * 64 + lq * 16;
+            if (kb < obytes) {
+                pxf[u] = *reinterpret_cast<const v8h*>(xw + kb);
+                pyf[u] = *reinterpret_cast<const v8h*>(ya + kb);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pxf[u][e] = (_Float16)0.f, pyf[u][e] = (_Float16)0.f;
+            }
+        }
+        psa = p.sA[min(fm, p.M - 1)];
+        psw = *reinterpret_cast<const uint2*>(p.sW + min(fnb, p.N - 4));
+    }
+
     const v4i zero4 = {0, 0, 0, 0};
     // Weight loads are issued 16 steps (1 KiB per lane-row quarter) ahead: the kernel is latency-bound (each wave only
     // streams K/4 bytes of 16 rows), so as much of W as the registers hold is put in flight before the first MFMA.
@@ -94,7 +122,12 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
             const int obytes = p.O * 2;
             const char* xw = reinterpret_cast<const char*>(p.fpW) + (int64_t)min(n0 + lr, p.N - 1) * obytes;
             const char* ya = reinterpret_cast<const char*>(p.fpA) + (int64_t)min(m, p.M - 1) * obytes;
-            for (int k0 = 0; k0 < obytes; k0 += 64) { // 32 outlier columns per step, 8 per lane
+            if (t == wave) { // (always true for KW >= MT) the first PRE steps were requested before the main loop
+#pragma unroll
+                for (int u = 0; u < PRE; ++u)
+                    if (u * 64 < obytes) P = __builtin_amdgcn_mfma_f32_16x16x32_f16(pxf[u], pyf[u], P, 0, 0, 0);
+            }
+            for (int k0 = (t == wave ? PRE * 64 : 0); k0 < obytes; k0 += 64) { // 32 outlier columns per step, 8 per lane
                 const int kb = k0 + lq * 16;
                 v8h xf, yf;
                 if (kb < obytes) {
@@ -108,8 +141,8 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
             }
         }
         if (m < p.M && nb < p.N) {
-            const float sa = h2f(p.sA[m]);
-            const uint2 swb = *reinterpret_cast<const uint2*>(p.sW + nb);
+            const float sa = h2f(t == wave ? psa : p.sA[m]);
+            const uint2 swb = t == wave ? psw : *reinterpret_cast<const uint2*>(p.sW + nb);
             const uint16_t swh[4] = {(uint16_t)(swb.x & 0xffffu), (uint16_t)(swb.x >> 16), (uint16_t)(swb.y & 0xffffu),
                                      (uint16_t)(swb.y >> 16)};
             uint16_t yh[4] = {0, 0, 0, 0};
