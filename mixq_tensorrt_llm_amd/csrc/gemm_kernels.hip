@@ -37,7 +37,10 @@ constexpr int GROUP_M = 4;
 // slices g, g + KG, ... with its own LDS stages; the partial accumulators meet in LDS and group 0 runs the epilogue.
 // (Small-N problems have too few tiles for the chip, and an LDS-DMA instruction costs the issuing wave 100-200 cycles:
 // more waves per tile is what raises the operand stream, and no global scratch is needed.)
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int NSTAGE = 2, int KG = 1>
+// PREO: the outlier operands of the epilogue get their own LDS region behind the stages and are copied there at kernel
+// start, under the main loop, instead of after it (used by the one-workgroup-per-CU split-K configurations, where the
+// extra (BM + BN) x 256 bytes of LDS cost no occupancy and the kernel is a chain of latencies).
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int NSTAGE = 2, int KG = 1, bool PREO = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N* KG * 64) void gemm_w8a8o16_kernel(const GemmParams p)
 {
     constexpr int NWAVES = WAVES_M * WAVES_N;
@@ -112,6 +115,34 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KG * 64) void gemm_w8a8o16_kernel
 
     const int nk = (p.K + KSLICE - 1) / KSLICE;
     const bool ktail = (p.K % KSLICE) != 0;
+
+    // fpW / fpA tiles -> LDS (256-B rows, slot = chunk ^ (row & 15)); all threads of the workgroup take part
+    const bool has_outliers = (EPI != EPI_INT32) && p.O > 0;
+    char* const osmem = smem_all + (PREO ? KG * NSTAGE * STAGE_BYTES : 0);
+    auto stage_outliers = [&]() __attribute__((always_inline)) {
+        constexpr int OXL = BN * 16 / TT, OYL = BM * 16 / TT;
+        const int obytes = p.O * 2; // valid bytes per row (O % 8 == 0)
+        const int slot = tid_all & 15;
+#pragma unroll
+        for (int i = 0; i < OXL; ++i) {
+            const int row = (i * TT + tid_all) >> 4;
+            const int c = (slot ^ (row & 15)) << 4;
+            const int grow = min(n0 + row, p.N - 1);
+            const char* s2 = reinterpret_cast<const char*>(p.fpW) + (int64_t)grow * obytes + c;
+            if (c >= obytes) s2 = static_cast<const char*>(p.zeros);
+            glds16(s2, osmem + (i * TT + wave_all * 64) * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < OYL; ++i) {
+            const int row = (i * TT + tid_all) >> 4;
+            const int c = (slot ^ (row & 15)) << 4;
+            const int grow = min(m0 + row, p.M - 1);
+            const char* s2 = reinterpret_cast<const char*>(p.fpA) + (int64_t)grow * obytes + c;
+            if (c >= obytes) s2 = static_cast<const char*>(p.zeros);
+            glds16(s2, osmem + BN * OSLICE + (i * TT + wave_all * 64) * 16);
+        }
+    };
+    if (PREO && has_outliers) stage_outliers(); // older than every slice copy: retired by the loop's first wait
 
     auto stage = [&](int buf, int kt) {
         char* xb = smem + buf * STAGE_BYTES;
@@ -220,34 +251,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KG * 64) void gemm_w8a8o16_kernel
         }
     }
 
-    // ---- outlier side GEMM: stage fpW / fpA tiles (256-B rows, slot = chunk ^ (row & 15)); all threads help ----
-    const bool has_outliers = (EPI != EPI_INT32) && p.O > 0;
-    if (has_outliers) {
+    // ---- outlier side GEMM operands (unless they were copied at kernel start) ----------------------------------------
+    if (has_outliers && !PREO) {
         __syncthreads(); // main-loop LDS (and the partial accumulators) are dead
-        constexpr int OXL = BN * 16 / TT, OYL = BM * 16 / TT;
-        const int obytes = p.O * 2; // valid bytes per row (O % 8 == 0)
-        const int slot = tid_all & 15;
-#pragma unroll
-        for (int i = 0; i < OXL; ++i) {
-            const int row = (i * TT + tid_all) >> 4;
-            const int c = (slot ^ (row & 15)) << 4;
-            const int grow = min(n0 + row, p.N - 1);
-            const char* s = reinterpret_cast<const char*>(p.fpW) + (int64_t)grow * obytes + c;
-            if (c >= obytes) s = static_cast<const char*>(p.zeros);
-            glds16(s, smem_all + (i * TT + wave_all * 64) * 16);
-        }
-#pragma unroll
-        for (int i = 0; i < OYL; ++i) {
-            const int row = (i * TT + tid_all) >> 4;
-            const int c = (slot ^ (row & 15)) << 4;
-            const int grow = min(m0 + row, p.M - 1);
-            const char* s = reinterpret_cast<const char*>(p.fpA) + (int64_t)grow * obytes + c;
-            if (c >= obytes) s = static_cast<const char*>(p.zeros);
-            glds16(s, smem_all + BN * OSLICE + (i * TT + wave_all * 64) * 16);
-        }
+        stage_outliers();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    if (has_outliers && PREO && KG == 1) __syncthreads(); // (KG > 1: the split-K hand-over above already synchronised)
     if (KG > 1 && group > 0) return; // (no barrier below this point)
 
     // ---- epilogue, one 32x32 tile at a time -----------------------------------------------------------
@@ -275,8 +286,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KG * 64) void gemm_w8a8o16_kernel
 #pragma unroll
             for (int e = 0; e < 16; ++e) P[e] = 0.f;
             if (has_outliers) {
-                const char* xo = smem_all + (wn * WN + i * 32 + lr) * OSLICE;
-                const char* yo = smem_all + BN * OSLICE + (wm * WM + j * 32 + lr) * OSLICE;
+                const char* xo = osmem + (wn * WN + i * 32 + lr) * OSLICE;
+                const char* yo = osmem + BN * OSLICE + (wm * WM + j * 32 + lr) * OSLICE;
                 const int sw16 = lr & 15;
                 for (int ks = 0; ks < osteps; ++ks) {
                     const int off = ((ks * 2 + lh) ^ sw16) << 4;
@@ -327,12 +338,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KG * 64) void gemm_w8a8o16_kernel
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int NSTAGE = 2, int KG = 1>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int NSTAGE = 2, int KG = 1, bool PREO = false>
 static hipError_t launch_cfg(const GemmParams& p, hipStream_t st)
 {
     constexpr int T = WAVES_M * WAVES_N * KG * 64;
-    constexpr size_t lds = (size_t)KG * NSTAGE * (size_t)(BM + BN) * KSLICE;
-    auto kern = gemm_w8a8o16_kernel<BM, BN, WAVES_M, WAVES_N, EPI, NSTAGE, KG>;
+    constexpr size_t lds = (size_t)KG * NSTAGE * (size_t)(BM + BN) * KSLICE + (PREO ? (size_t)(BM + BN) * OSLICE : 0);
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = gemm_w8a8o16_kernel<BM, BN, WAVES_M, WAVES_N, EPI, NSTAGE, KG, PREO>;
     static bool attr_done = false; // benign race: idempotent
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -373,6 +385,8 @@ static hipError_t launch_epi(const GemmParams& p, hipStream_t st)
     case 19: return launch_cfg<128, 64, 4, 2, EPI, 2, 2>(p, st);
     case 20: return launch_cfg<64, 32, 2, 1, EPI, 2, 4>(p, st);
     case 21: return launch_cfg<64, 128, 2, 4, EPI, 2, 2>(p, st);
+    case 22: return launch_cfg<32, 64, 1, 2, EPI, 2, 4, true>(p, st);
+    case 23: return launch_cfg<64, 64, 2, 2, EPI, 2, 4, true>(p, st);
     default: break;
     }
     // Measured choice (tools/cfg_sweep.sh, M = 32..1024 on 12288x4096, 4096x11008, 4096x4096): small problems are
@@ -381,8 +395,8 @@ static hipError_t launch_epi(const GemmParams& p, hipStream_t st)
     // tile and split K among themselves (KG = 4, then 2); with ~3 tiles per CU plain 64x64 tiles; beyond that 128x128.
     const int64_t n64 = (p.N + 63) / 64;
     const int64_t wg32 = (int64_t)((p.M + 31) / 32) * n64, wg64 = (int64_t)((p.M + 63) / 64) * n64;
-    if (wg32 <= 256) return launch_cfg<32, 64, 1, 2, EPI, 2, 4>(p, st);
-    if (wg64 <= 256) return launch_cfg<64, 64, 2, 2, EPI, 2, 4>(p, st);
+    if (wg32 <= 256) return launch_cfg<32, 64, 1, 2, EPI, 2, 4, true>(p, st);
+    if (wg64 <= 256) return launch_cfg<64, 64, 2, 2, EPI, 2, 4, true>(p, st);
     if (wg64 <= 512) return launch_cfg<64, 64, 2, 2, EPI, 2, 2>(p, st);
     if (wg64 <= 768) return launch_cfg<64, 64, 2, 2, EPI>(p, st);
     return launch_cfg<128, 128, 2, 4, EPI>(p, st);

@@ -191,7 +191,7 @@ def test_every_schedule_gives_identical_int32(oracle, variant, which, M, N, K):
     assert np.array_equal(got, want)
 
 
-@pytest.mark.parametrize("cfg", range(22))
+@pytest.mark.parametrize("cfg", range(24))
 def test_every_tile_configuration_of_the_two_barrier_kernel(oracle, variant, cfg):
     """variant 10 + cfg forces one tile / pipeline-depth configuration of gemm_w8a8o16_kernel (2..8 LDS stages): raw
     int32 on ragged shapes (K shorter than the prefetch depth, K tail, odd slice counts) + the fused operator."""
