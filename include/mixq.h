@@ -148,7 +148,9 @@ MIXQ_API int mixq_rmsnorm_extract_quant(int M, int K, const void* x_f16, const v
                                         void* stream);
 /* int8FusedDequantizeCUDA (kernel/i8gemm.cu:151-194): D = fp16(float(A.B^T) * (scale_col[n]*scale_row[m]) + y).
  * A int8 [M,K], B int8 [N,K], scale_row fp16 [M], scale_col fp16 [N], y/D fp16 [M,N] (y may alias D, may be NULL = 0).
- * `workspace` is unused (kept for signature parity). */
+ * `workspace` (the reference hands CUTLASS its scratch here): NULL, or device scratch for the K split over workgroups --
+ * at least mixq_gemm_scratch_size(M,N,K) bytes, ZERO-FILLED before its first use, one per stream (see
+ * mixq_gemm_mixed_scratch below).  NULL always selects the one-workgroup-per-tile kernels. */
 MIXQ_API int mixq_int8_fused_dequantize(const int8_t* A, const int8_t* B, const void* scale_row, const void* scale_col,
                                         const void* y, void* D, int M, int N, int K, char* workspace, void* stream);
 /* Same with the SiLU epilogue (mixlib int8FusedDequantizeSilu, linear_combination_dequant.h:176-270). */
@@ -159,6 +161,19 @@ MIXQ_API int mixq_int8_fused_dequantize_silu(const int8_t* A, const int8_t* B, c
  * fp32 accumulate, rounded to fp16 like the reference's separate cuBLAS call) + dequant epilogue, Out written once. */
 MIXQ_API int mixq_gemm_mixed(const int8_t* qA, const int8_t* W, const void* sA, const void* sW, const void* fpA,
                              const void* fpW, void* Out, int M, int N, int K, int O, void* stream);
+/* The fused GEMM with caller-owned device scratch (MI355X extension).  Mid-size problems whose 256x256 tiles cover at
+ * most half / a quarter of the CUs split K over 2 / 4 workgroups per tile, which exchange their int32 partial sums
+ * through `scratch` and each finish a share of the tile: bit-identical results, 10-35 % less time on the shapes it is
+ * chosen for (csrc/gemm_pp_kernels.hip).  mixq_gemm_scratch_size(M,N,K) = bytes needed (0: the split
+ * form is not used for this shape; never more than ~48 MiB).  The scratch must be ZERO-FILLED before its first use (the
+ * kernel leaves its arrival words zero again) and must not be shared by launches that can run concurrently (one scratch
+ * per stream).  A null / too small scratch selects the one-workgroup-per-tile kernels (= mixq_gemm_mixed).
+ * mixq_enqueue carves this scratch from the plugin workspace itself (and zeroes the arrival words on every call).
+ * mixq_debug_set_gemm_variant(70) switches the split form off, 72 / 74 force a factor, 79 = automatic (default). */
+MIXQ_API size_t mixq_gemm_scratch_size(int M, int N, int K);
+MIXQ_API int mixq_gemm_mixed_scratch(const int8_t* qA, const int8_t* W, const void* sA, const void* sW, const void* fpA,
+                                     const void* fpW, void* Out, int M, int N, int K, int O, void* scratch,
+                                     size_t scratch_bytes, void* stream);
 /* gemm (TsinghuaMixQPlugin.cpp:36-77, cuBLAS s8 x s8 -> s32): raw int32 accumulators, for bit-exact checks. */
 MIXQ_API int mixq_gemm_s8s8s32(const int8_t* A, const int8_t* B, int32_t* C, int M, int N, int K, void* stream);
 /* gemmfp16 (TsinghuaMixQPlugin.cpp:122-161): Out = fpA . fpW^T, fp32 accumulate, fp16 out. */

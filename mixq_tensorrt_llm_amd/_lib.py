@@ -98,6 +98,8 @@ SIGNATURES = {
     "mixq_rmsnorm_extract_quant": (_i, [_i, _i, _vp, _vp, _vp, ctypes.c_float, _vp, _i, _vp, _vp, _vp, _vp]),
     "mixq_int8_fused_dequantize": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "mixq_int8_fused_dequantize_silu": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "mixq_gemm_scratch_size": (ctypes.c_size_t, [_i, _i, _i]),
+    "mixq_gemm_mixed_scratch": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, ctypes.c_size_t, _vp]),
     "mixq_int8_fused_dequantize_silu_mul": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "mixq_gemm_mixed": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mixq_gemm_s8s8s32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),

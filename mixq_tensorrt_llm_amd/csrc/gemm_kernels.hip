@@ -410,6 +410,10 @@ static std::atomic<int> g_variant{-1};
 
 void set_gemm_variant(int v)
 {
+    if (v >= 70 && v <= 79) { // K split over workgroups (ping-pong kernel): 70 off, 72 / 74 forced factor, 79 automatic
+        set_splitk_force(v == 79 ? -1 : v - 70);
+        return;
+    }
     if (v >= 40 && v < 100) { // 40 + kw: skinny kernel with kw K-split waves (measurements)
         set_skinny_kw(v - 40);
         g_force_cfg.store(-1);
@@ -448,6 +452,8 @@ hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st)
     if (variant >= 100) return launch_gemm_pp_ablate(p, variant - 100, st); // measurement-only ablations
     if (variant == 3 && gemm_pp2_supported(p, epi)) return launch_gemm_pp2(p, epi, st);
     const int64_t wg64 = (int64_t)((p.M + 63) / 64) * ((p.N + 63) / 64);
+    if (variant == 0 && epi != EPI_INT32 && p.splitk_ws != nullptr && gemm_splitk_factor(p.M, p.N, p.K) != 0)
+        return launch_gemm_pp_splitk(p, epi, st); // 2 / 4 workgroups per tile
     if (variant == 2 || (variant == 0 && p.M > 128 && tiles256 >= 96 && wg64 > 768)) return launch_gemm_pp(p, epi, st);
     switch (epi) {
     case EPI_DEQUANT: return launch_epi<EPI_DEQUANT>(p, st);

@@ -29,6 +29,7 @@
 // dequant FMA, results packed to fp16 and transposed through a wave-private LDS window into 128-byte row segments.
 #include "mixq_device.h"
 #include "mixq_launch.h"
+#include <atomic>
 #include <type_traits>
 
 namespace mixq {
@@ -80,9 +81,31 @@ __device__ __forceinline__ void glds16_sbase(const char* sbase, unsigned voff, u
 // ABL: measurement-only ablations (wrong results): 1 = no global_load_lds in the loop, 2 = no vmcnt waits,
 // 4 = no ds_reads in the loop, 8 = every tile loads tile (0,0)'s operands (all L2 hits), 16 = no epilogue.
 // ABL = 0 is the product kernel.
-template <int EPI, bool HAS_O, bool HAS_Y, int ABL = 0>
+// SPLITK = 2 / 4: K split over S workgroups per output tile, for mid-size problems whose tiles alone cover at most
+// 1/S of the CUs.  The S workgroups of a tile are S consecutive blocks (dispatched together, resident together); each
+//   1. multiplies its quarter / half of the K slices into the usual 256x256 int32 accumulators, with the 32-row m tiles
+//      of its wave tile PERMUTED (accumulator tile jj holds m tile jj ^ (r * PJ), r = rank in the group, PJ = 4 / S:
+//      a change of the staging offsets only), so that the share it will finish always sits in acc[.][0 .. PJ-1];
+//   2. parks the other S-1 shares in p.splitk_ws (its own slot), waits for the write-through acknowledgements,
+//      publishes its arrival word, and stages its outlier operands while the others do the same;
+//   3. waits for the other arrival words, adds the S-1 foreign partial sums of its own share (64 / 96 loads per lane,
+//      all in flight together, landing in the registers step 2 freed) and runs the usual epilogue on that share.
+// Same int32 sums (integer addition commutes), same epilogue, same bits as the one-workgroup form.
+// Hand-over accesses are relaxed AGENT-scope atomics: `global_store sc1` writes through to memory and
+// `global_load sc1` is served coherently, per access, for any pair of XCDs -- no bulk L2 write-back / invalidate (a
+// release / acquire fence pair costs ~70k cycles per tile here), and the compiler tracks the loads (an asm load
+// consumed after a later s_waitcnt gets copied / spilled before its data has arrived).
+// The last workgroup of a group to finish its reads re-arms the group's arrival words for the next launch.
+// Progress: blocks are dispatched in id order, so at most one group is ever partially resident and every other group
+// completes and frees its CUs; the kernel needs S free CUs in total.  The wait is bounded and traps (a loud launch
+// failure, never a hang or a wrong result).
+template <int EPI, bool HAS_O, bool HAS_Y, int ABL = 0, int SPLITK = 0>
 __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p)
 {
+    constexpr int S = SPLITK ? SPLITK : 1; // workgroups per tile
+    constexpr int PJ = 4 / S;              // 32-row m tiles (per wave) this workgroup finishes
+    constexpr int NT = 2 * PJ;             // 32x32 accumulator tiles it finishes
+    static_assert(SPLITK == 0 || SPLITK == 2 || SPLITK == 4, "");
     using namespace pp;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -97,11 +120,21 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
     // ---- block -> tile mapping (XCD-aware, grouped; identical to gemm_kernels.hip) -------------------
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     const int nwg = tiles_m * tiles_n;
-    int t_lin;
-    {
+    int t_lin, rank = 0;
+    if (SPLITK) { // block = idx * 8 + grp * S + rank: the S workgroups of a tile are consecutive blocks; each of the
+                  // 8 / S groups of XCDs takes a contiguous range of tiles (neighbouring tiles share operand rows in L2)
+        constexpr int G = 8 / S;
+        const int bid = blockIdx.x, xcd = bid & 7, grp = xcd / S, idx = bid >> 3;
+        rank = xcd % S;
+        const int q = nwg / G, rem = nwg % G;
+        if (idx >= q + (grp < rem ? 1 : 0)) return; // (all S blocks of the group leave together)
+        t_lin = (grp < rem ? grp * (q + 1) : rem * (q + 1) + (grp - rem) * q) + idx;
+    } else {
         const int bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         t_lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
+    const int jperm = rank * PJ;                                   // accumulator m tile jj <-> m tile jj ^ jperm
+    auto jmap = [&](int jj) __attribute__((always_inline)) { return SPLITK ? (jj ^ jperm) : jj; };
     int tile_m, tile_n;
     {
         constexpr int GROUP_M = 4;
@@ -132,7 +165,8 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
                 const int q = i * 64 + (tid >> 3);
                 const int sw = (q >> 1) & 7;
                 const int nl = (q >> 5) * 64 + h * 32 + (q & 31);
-                const int ml = (q >> 6) * 128 + h * 64 + (q & 63);
+                const int ml = SPLITK ? (q >> 6) * 128 + (h ^ (jperm >> 1)) * 64 + ((q & 63) ^ ((jperm & 1) << 5))
+                                      : (q >> 6) * 128 + h * 64 + (q & 63);
                 const int rn = min(n0 + nl, p.N - 1) - n0, rm = min(m0 + ml, p.M - 1) - m0; // clamped rows, >= 0
                 off[h][i] = (unsigned)rn * (unsigned)p.K + ((slot ^ sw) << 4);
                 off[2 + h][i] = (unsigned)rm * (unsigned)p.K + ((slot ^ sw) << 4);
@@ -141,6 +175,9 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
     }
     const int nk = (p.K + KS - 1) / KS;
     const bool ktail = (p.K % KS) != 0;
+    // K range of this workgroup in slices
+    const int k_begin = SPLITK && rank > 0 ? ((nk * rank / S) + 1) & ~1 : 0;
+    const int k_end = SPLITK && rank + 1 < S ? ((nk * (rank + 1) / S) + 1) & ~1 : nk;
     const unsigned lds0 = (unsigned)(size_t)(MIXQ_LDS_PTR(smem)) + wave * 1024; // this wave's 1-KiB DMA window
 
     // 2 x LDS-DMA: region `region` of slice kt.  TAILCHK: slice kt may be partial in K (chunks past K <- zero page).
@@ -206,7 +243,7 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
     // One K slice.  Xcur holds X half 0 of this slice on entry; Xoth receives X half 1, then X half 0 of slice kt+1.
     auto slice = [&](v4i (&Xcur)[4], v4i (&Xoth)[4], int kt, auto steady_tag) __attribute__((always_inline)) {
         constexpr bool steady = decltype(steady_tag)::value;   // compile-time: a full next slice exists, no checks
-        const bool more = steady || (kt + 1 < nk);             // wave-uniform
+        const bool more = steady || (kt + 1 < k_end);          // wave-uniform
         // phase 1: (Y0, X0)
         read_y(kt, 0);
         if (more) issue(0, kt + 1, !steady);
@@ -245,30 +282,54 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
             static_cast<unsigned long long*>(p.dbg)[(size_t)blockIdx.x * 8 + idx] = __builtin_readcyclecounter();
     };
     stamp(0);
+    // SPLITK bookkeeping words of this tile (behind all slots): [0..3] arrival, [4] workgroups done reading
+    constexpr int SLOT = (S - 1) * PJ * 2 * 16 * T; // dwords per (tile, rank) slot
+    int* const ws = static_cast<int*>(p.splitk_ws);
+    unsigned* const words = SPLITK ? reinterpret_cast<unsigned*>(ws + (size_t)nwg * S * SLOT) + t_lin * 8 : nullptr;
     // ---- prologue: slice 0 completely, then stagger the groups ----------------------------------------------
-    issue(0, 0, true);
-    issue(2, 0, true);
-    issue(1, 0, true);
-    issue(3, 0, true);
+    issue(0, k_begin, true);
+    issue(2, k_begin, true);
+    issue(1, k_begin, true);
+    issue(3, k_begin, true);
     wait_vmcnt<4>(); // X0 and Y0 have landed; X1 / Y1 are retired by the vmcnt(4) of phases 1 / 2 like in steady state
     MIXQ_SEG_END();
-    read_x(XA, 0, 0);
+    read_x(XA, k_begin, 0);
     stamp(1);
     if (group == 1) MIXQ_SEG_END(); // group 1 now runs one segment behind group 0
 
     {
-        int kt = 0;
-        for (; kt + 3 < nk; kt += 2) { // both slices of the pair have a full successor: branch-free body
+        int kt = k_begin;
+        for (; kt + 3 < k_end; kt += 2) { // both slices of the pair have a full successor: branch-free body
             slice(XA, XB, kt, steady_t{});
             slice(XB, XA, kt + 1, steady_t{});
         }
-        for (; kt < nk; kt += 2) { // last 1-3 slices: the next slice may be partial in K or absent (runtime checks)
+        for (; kt < k_end; kt += 2) { // last 1-3 slices: the next slice may be partial in K or absent (runtime checks)
             slice(XA, XB, kt, tail_t{});
-            if (kt + 1 < nk) slice(XB, XA, kt + 1, tail_t{});
+            if (kt + 1 < k_end) slice(XB, XA, kt + 1, tail_t{});
         }
     }
     if (group == 0) MIXQ_SEG_END(); // re-align the groups
     stamp(2);
+
+    // ---- SPLITK: park the shares the other workgroups of the group finish, publish the arrival word
+    // slot of (tile, rank): [(S-1) shares][2 n tiles][PJ m tiles][16][512 lanes] dwords (one instruction = a 2-KiB run)
+    if (SPLITK) {
+        int* const mine = ws + ((size_t)t_lin * S + rank) * SLOT + tid;
+#pragma unroll
+        for (int sh = 1; sh < S; ++sh)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int x = 0; x < PJ; ++x)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        __hip_atomic_store(mine + ((((sh - 1) * 2 + i) * PJ + x) * 16 + e) * T, acc[i][sh * PJ + x][e],
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every write-through acknowledged
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(words + rank, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        stamp(3);
+    }
 
     if ((ABL & 16) && p.M != -1) return; // (p.M is never -1: keeps the accumulators live)
     if (EPI == EPI_INT32 || (ABL & 16)) { // debug / unfused API: raw accumulators, 16-byte stores straight from the MFMA layout
@@ -319,7 +380,50 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    stamp(3);
+    if (SPLITK) { // ---- add the other workgroups' partial sums of this workgroup's share
+        stamp(4);
+        if (tid < S && tid != rank) {
+            int spins = 0;
+            while (__hip_atomic_load(words + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1 << 26)) __builtin_trap();
+            }
+        }
+        __syncthreads();
+        stamp(5);
+        int pk[S > 1 ? S - 1 : 1][2][PJ][16];
+#pragma unroll
+        for (int sh = 1; sh < S; ++sh) { // share sh of workgroup rank ^ sh is this workgroup's own share
+            const int* const theirs = ws + ((size_t)t_lin * S + (rank ^ sh)) * SLOT + tid;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int x = 0; x < PJ; ++x)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        pk[sh - 1][i][x][e] = __hip_atomic_load(theirs + ((((sh - 1) * 2 + i) * PJ + x) * 16 + e) * T,
+                                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int sh = 1; sh < S; ++sh)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int x = 0; x < PJ; ++x)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][x][e] += pk[sh - 1][i][x][e];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads(); // every wave of this workgroup has its data
+        if (tid == 0) {
+            const unsigned before = __hip_atomic_fetch_add(words + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (before == (unsigned)(S - 1)) { // the whole group is done reading: re-arm for the next launch
+#pragma unroll
+                for (int w = 0; w < 5; ++w) __hip_atomic_store(words + w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        stamp(6);
+    }
+    if (!SPLITK) stamp(3);
 
     // ---- dequant math + stores, one 32 (m) x 64 (n) block of the wave tile at a time.  Results are packed to fp16 and
     // transposed through a wave-private 4-KiB LDS window (32 rows x 128 B; the 32 KiB above the slice buffers), then
@@ -333,7 +437,8 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
     const int obase = (lh ^ (lr & 15)) << 4; // 16-B slot of k-step ks = obase ^ (ks << 5)
     float sa[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) sa[j] = h2f(p.sA[min(m0 + wm * 128 + j * 32 + lr, p.M - 1)]); // clamped rows never stored
+    for (int j = 0; j < 4; ++j) // (clamped rows are never stored)
+        sa[j] = j < PJ ? h2f(p.sA[min(m0 + wm * 128 + jmap(j) * 32 + lr, p.M - 1)]) : 0.f;
 
     // side GEMM of tile (i, j): 8 k-steps of 16 outlier columns
     auto side = [&](int i, int j) __attribute__((always_inline)) {
@@ -342,7 +447,7 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
         for (int e = 0; e < 16; ++e) P[e] = 0.f;
         if (HAS_O) {
             const char* xo = smem + (wn * 64 + i * 32 + lr) * OSLICE;
-            const char* yo = smem + BN * OSLICE + (wm * 128 + j * 32 + lr) * OSLICE;
+            const char* yo = smem + BN * OSLICE + (wm * 128 + jmap(j) * 32 + lr) * OSLICE;
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh) { // two batches of 4 k-steps keep the fragment registers at 32
                 v8h xf[4], yf[4];
@@ -385,7 +490,7 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
     auto fetch = [&](const uint16_t* src, int j, uint4 (&v)[4]) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int row = j * 32 + q * 8; // wave-uniform
+            const int row = jmap(j) * 32 + q * 8; // wave-uniform
             const char* a = reinterpret_cast<const char*>(src) + src_wave + (int64_t)row * p.N * 2 + src_lane;
             const bool ok = src_n_ok && m0 + wm * 128 + row + (lane >> 3) < p.M;
             v[q] = ok ? *reinterpret_cast<const uint4*>(a) : make_uint4(0u, 0u, 0u, 0u);
@@ -459,7 +564,7 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (q & 1) v[q] = uint4{v[q].z, v[q].w, v[q].x, v[q].y}; // rows with bit 3 set hold their 8-B halves swapped
-            const int row = j * 32 + q * 8;            // wave-uniform
+            const int row = jmap(j) * 32 + q * 8;     // wave-uniform
             char* dst = dwave + (int64_t)row * p.N * 2 + dlane;
             if (interior) *reinterpret_cast<uint4*>(dst) = v[q];
             else if (n_ok && m0 + wm * 128 + row + (lane >> 3) < p.M) *reinterpret_cast<uint4*>(dst) = v[q];
@@ -469,13 +574,13 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
     {
         v16f Pcur = side(0, 0);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
+        for (int t = 0; t < NT; ++t) {
             v16f Pnext = Pcur;
-            if (t + 1 < 8) Pnext = side((t + 1) & 1, (t + 1) >> 1);
+            if (t + 1 < NT) Pnext = side((t + 1) & 1, (t + 1) >> 1);
             if ((HAS_Y || HAS_MUL) && (t & 1) == 0) { // block j = t >> 1 starts: operands of this block -> registers
                 if (HAS_Y) spread(ypre, yq);
                 if (HAS_MUL) spread(mpre, mq);
-                if (t + 2 < 8) {
+                if (t + 2 < NT) {
                     if (HAS_Y) fetch(p.Y, (t >> 1) + 1, ypre);
                     if (HAS_MUL) fetch(p.Mul, (t >> 1) + 1, mpre);
                 }
@@ -486,9 +591,11 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    stamp(4);
-    stamp(5);
-    stamp(6);
+    if (!SPLITK) {
+        stamp(4);
+        stamp(5);
+        stamp(6);
+    }
     if (p.dbg != nullptr) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp(7);
@@ -519,6 +626,104 @@ static hipError_t launch_pp_epi(const GemmParams& p, hipStream_t st)
     if (has_o) return launch_pp_cfg<EPI, true, false>(p, st); // the API never passes both an addend and outliers
     if (has_y) return launch_pp_cfg<EPI, false, true>(p, st);
     return launch_pp_cfg<EPI, false, false>(p, st);
+}
+
+// ---- K split over 2 / 4 workgroups per tile (see the kernel header) ---------------------------------------------------
+static int num_cus()
+{
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+             prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return n;
+}
+
+static std::atomic<int> g_splitk_force{-1}; // -1 automatic, 0 off, 2 / 4: that factor wherever the shape allows it
+void set_splitk_force(int v) { g_splitk_force.store(v); }
+
+// Automatic choice, from tools/splitk_select_sweep.py on MI355X: with the tiles on (1/4, 1/2] of the CUs
+// two workgroups per tile always pay; on at most 1/4 of the CUs four pay once K is long enough to amortise the
+// exchange (3 x 64 KiB per workgroup each way) and there are enough tiles for the small-tile kernels to be L2-bound;
+// rows that fill less than one 256-row tile are better served by the small-tile kernels.
+int gemm_splitk_factor(int M, int N, int K)
+{
+    const int force = g_splitk_force.load();
+    if (force == 0 || M <= 128) return 0;
+    const int64_t tiles = (int64_t)((M + pp::BM - 1) / pp::BM) * ((N + pp::BN - 1) / pp::BN);
+    const int nk = (K + pp::KS - 1) / pp::KS;
+    const int cus = num_cus();
+    if (force == 4) return 4 * tiles <= cus && nk >= 16 ? 4 : 0;
+    if (force == 2) return 2 * tiles <= cus && nk >= 8 ? 2 : 0;
+    if (M < 256 || 2 * tiles > cus) return 0;
+    if (4 * tiles > cus) return nk >= 16 ? 2 : 0;
+    if (nk >= 64 && 8 * tiles >= cus) return 4;
+    if (nk >= 40 && 16 * tiles >= 3 * cus) return 2;
+    return 0;
+}
+
+static size_t splitk_slot_bytes(int s) { return (size_t)(s - 1) * (4 / s) * 2 * 16 * pp::T * 4; }
+
+size_t gemm_splitk_workspace_size(int M, int N, int K)
+{
+    const int s = gemm_splitk_factor(M, N, K);
+    if (s == 0) return 0;
+    const size_t tiles = (size_t)((M + pp::BM - 1) / pp::BM) * ((N + pp::BN - 1) / pp::BN);
+    return tiles * s * splitk_slot_bytes(s) + tiles * 32;
+}
+
+void gemm_splitk_words(int M, int N, int K, size_t* offset, size_t* bytes)
+{
+    const size_t total = gemm_splitk_workspace_size(M, N, K);
+    const size_t tiles = (size_t)((M + pp::BM - 1) / pp::BM) * ((N + pp::BN - 1) / pp::BN);
+    *bytes = total ? tiles * 32 : 0;
+    *offset = total ? total - tiles * 32 : 0;
+}
+
+size_t gemm_splitk_workspace_bound() { return (size_t)num_cus() * splitk_slot_bytes(4) + (size_t)num_cus() * 32; }
+
+template <int EPI, bool HAS_O, bool HAS_Y, int SPLITK>
+static hipError_t launch_pp_splitk_cfg(const GemmParams& p, hipStream_t st)
+{
+    constexpr size_t lds = 2 * (size_t)pp::BUF + 32768;
+    auto kern = gemm_w8a8o16_pp_kernel<EPI, HAS_O, HAS_Y, 0, SPLITK>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const int tiles = ((p.M + pp::BM - 1) / pp::BM) * ((p.N + pp::BN - 1) / pp::BN);
+    constexpr int G = 8 / SPLITK;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(8 * ((tiles + G - 1) / G))), dim3(pp::T), lds, st, p);
+    return hipGetLastError();
+}
+
+template <int EPI, int SPLITK>
+static hipError_t launch_pp_splitk_epi(const GemmParams& p, hipStream_t st)
+{
+    if (p.O > 0) return launch_pp_splitk_cfg<EPI, true, false, SPLITK>(p, st);
+    if (p.Y != nullptr) return launch_pp_splitk_cfg<EPI, false, true, SPLITK>(p, st);
+    return launch_pp_splitk_cfg<EPI, false, false, SPLITK>(p, st);
+}
+
+hipError_t launch_gemm_pp_splitk(const GemmParams& p, int epi, hipStream_t st)
+{
+    const int s = gemm_splitk_factor(p.M, p.N, p.K);
+    if (s == 0 || p.splitk_ws == nullptr) return hipErrorInvalidValue;
+    switch (epi) {
+    case EPI_DEQUANT:
+        return s == 4 ? launch_pp_splitk_epi<EPI_DEQUANT, 4>(p, st) : launch_pp_splitk_epi<EPI_DEQUANT, 2>(p, st);
+    case EPI_DEQUANT_SILU:
+        return s == 4 ? launch_pp_splitk_epi<EPI_DEQUANT_SILU, 4>(p, st) : launch_pp_splitk_epi<EPI_DEQUANT_SILU, 2>(p, st);
+    case EPI_DEQUANT_SILU_MUL:
+        return s == 4 ? launch_pp_splitk_epi<EPI_DEQUANT_SILU_MUL, 4>(p, st)
+                      : launch_pp_splitk_epi<EPI_DEQUANT_SILU_MUL, 2>(p, st);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 hipError_t launch_gemm_pp_ablate(const GemmParams& p, int abl, hipStream_t st)

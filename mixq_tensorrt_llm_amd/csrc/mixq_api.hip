@@ -238,6 +238,7 @@ size_t mixq_workspace_size(const mixq_handle*, int64_t maxM, int64_t /*N*/, int6
     s += align_up((size_t)maxM * (size_t)K, kWorkspaceAlign);                                 // qA
     s += align_up((size_t)maxM * sizeof(uint16_t), kWorkspaceAlign);                          // sA
     s += align_up((size_t)maxM * (size_t)kNumOutliers * sizeof(uint16_t), kWorkspaceAlign);   // fpA
+    if (maxM >= 256) s += align_up(mixq::gemm_splitk_workspace_bound(), kWorkspaceAlign);     // K-split exchange scratch
     return s;
 }
 
@@ -348,7 +349,7 @@ int mixq_rmsnorm_extract_quant4(int M, int K, const void* x, const void* gamma, 
 
 static int fused_dequant_impl(const int8_t* A, const int8_t* B, const void* scale_row, const void* scale_col,
                               const void* y, void* D, int M, int N, int K, int epi, void* stream,
-                              const void* mul = nullptr)
+                              const void* mul = nullptr, void* scratch = nullptr)
 {
     if (M < 0 || N < 0 || K <= 0) return MIXQ_E_BADARG;
     if (M == 0 || N == 0) return MIXQ_OK;
@@ -365,19 +366,21 @@ static int fused_dequant_impl(const int8_t* A, const int8_t* B, const void* scal
     p.zeros = mixq::zero_page();
     p.M = M, p.N = N, p.K = K, p.O = 0;
     if (!p.zeros) return MIXQ_E_HIP;
+    if (scratch && aligned16(scratch)) p.splitk_ws = scratch; // K split over workgroups where the shape calls for it
     return hip_rc(mixq::launch_gemm(p, epi, static_cast<hipStream_t>(stream)));
 }
 
 int mixq_int8_fused_dequantize(const int8_t* A, const int8_t* B, const void* scale_row, const void* scale_col,
-                               const void* y, void* D, int M, int N, int K, char* /*workspace*/, void* stream)
+                               const void* y, void* D, int M, int N, int K, char* workspace, void* stream)
 {
-    return fused_dequant_impl(A, B, scale_row, scale_col, y, D, M, N, K, mixq::EPI_DEQUANT, stream);
+    return fused_dequant_impl(A, B, scale_row, scale_col, y, D, M, N, K, mixq::EPI_DEQUANT, stream, nullptr, workspace);
 }
 
 int mixq_int8_fused_dequantize_silu(const int8_t* A, const int8_t* B, const void* scale_row, const void* scale_col,
-                                    const void* y, void* D, int M, int N, int K, char* /*workspace*/, void* stream)
+                                    const void* y, void* D, int M, int N, int K, char* workspace, void* stream)
 {
-    return fused_dequant_impl(A, B, scale_row, scale_col, y, D, M, N, K, mixq::EPI_DEQUANT_SILU, stream);
+    return fused_dequant_impl(A, B, scale_row, scale_col, y, D, M, N, K, mixq::EPI_DEQUANT_SILU, stream, nullptr,
+                              workspace);
 }
 
 int mixq_int4quant(int rows, int cols, const void* src, uint8_t* dst, void* scale, void* stream)
@@ -444,13 +447,23 @@ int mixq_unpack_int4_to_int8(const uint8_t* src, int8_t* dst, size_t packed_byte
 
 int mixq_int8_fused_dequantize_silu_mul(const int8_t* A, const int8_t* B, const void* scale_row, const void* scale_col,
                                         const void* y, const void* mul, void* D, int M, int N, int K,
-                                        char* /*workspace*/, void* stream)
+                                        char* workspace, void* stream)
 {
-    return fused_dequant_impl(A, B, scale_row, scale_col, y, D, M, N, K, mixq::EPI_DEQUANT_SILU_MUL, stream, mul);
+    return fused_dequant_impl(A, B, scale_row, scale_col, y, D, M, N, K, mixq::EPI_DEQUANT_SILU_MUL, stream, mul,
+                              workspace);
 }
+
+size_t mixq_gemm_scratch_size(int M, int N, int K) { return mixq::gemm_splitk_workspace_size(M, N, K); }
 
 int mixq_gemm_mixed(const int8_t* qA, const int8_t* W, const void* sA, const void* sW, const void* fpA,
                     const void* fpW, void* Out, int M, int N, int K, int O, void* stream)
+{
+    return mixq_gemm_mixed_scratch(qA, W, sA, sW, fpA, fpW, Out, M, N, K, O, nullptr, 0, stream);
+}
+
+int mixq_gemm_mixed_scratch(const int8_t* qA, const int8_t* W, const void* sA, const void* sW, const void* fpA,
+                            const void* fpW, void* Out, int M, int N, int K, int O, void* scratch, size_t scratch_bytes,
+                            void* stream)
 {
     if (M < 0 || N < 0 || K <= 0 || O < 0) return MIXQ_E_BADARG;
     if (M == 0 || N == 0) return MIXQ_OK;
@@ -467,6 +480,7 @@ int mixq_gemm_mixed(const int8_t* qA, const int8_t* W, const void* sA, const voi
     if (!p.zeros) return MIXQ_E_HIP;
     p.M = M, p.N = N, p.K = K;
     p.dbg = g_dbg_stamps;
+    if (scratch && aligned16(scratch) && scratch_bytes >= mixq::gemm_splitk_workspace_size(M, N, K)) p.splitk_ws = scratch;
     if (O <= kNumOutliers) {
         p.fpA = static_cast<const uint16_t*>(fpA), p.fpW = static_cast<const uint16_t*>(fpW), p.O = O;
         return hip_rc(mixq::launch_gemm(p, mixq::EPI_DEQUANT, st));
@@ -564,7 +578,19 @@ static int enqueue_impl(const mixq_handle* h, const mixq_tensor_desc* inputDesc,
         if (rc != MIXQ_OK) return rc;
         hipStream_t st = static_cast<hipStream_t>(stream);
         if (ev_gemm_start && hipEventRecord(static_cast<hipEvent_t>(ev_gemm_start), st) != hipSuccess) return MIXQ_E_HIP;
-        rc = mixq_gemm_mixed(qA, W, sA, scale_b, fpA, fp_weight, Out, (int)M, (int)N, (int)K, kNumOutliers, stream);
+        // mid-size problems: K split over 2 / 4 workgroups per tile through scratch behind fpA (gemm_pp_kernels.hip).
+        // The arrival words are zeroed on every call: the workspace is shared with whatever else the engine runs.
+        void* scratch = nullptr;
+        const size_t scratch_bytes = mixq::gemm_splitk_workspace_size((int)M, (int)N, (int)K);
+        if (scratch_bytes) {
+            base = align_up(base + (size_t)M * (size_t)kNumOutliers * sizeof(uint16_t), kWorkspaceAlign);
+            scratch = reinterpret_cast<void*>(base);
+            size_t woff = 0, wbytes = 0;
+            mixq::gemm_splitk_words((int)M, (int)N, (int)K, &woff, &wbytes);
+            if (hipMemsetAsync(static_cast<char*>(scratch) + woff, 0, wbytes, st) != hipSuccess) return MIXQ_E_HIP;
+        }
+        rc = mixq_gemm_mixed_scratch(qA, W, sA, scale_b, fpA, fp_weight, Out, (int)M, (int)N, (int)K, kNumOutliers,
+                                     scratch, scratch_bytes, stream);
         if (ev_gemm_stop && hipEventRecord(static_cast<hipEvent_t>(ev_gemm_stop), st) != hipSuccess) return MIXQ_E_HIP;
         return rc;
     }

@@ -59,11 +59,32 @@ def ExtractOutliersAndSetToZeros(ind, input):
     return out
 
 
+_GEMM_SCRATCH = {}
+
+
+def gemm_scratch(t, M, N, K):
+    """Device scratch for the K split over workgroups (include/mixq.h, mixq_gemm_mixed_scratch): None when the shape does
+    not use it, else a zero-initialised buffer owned by (device, current stream) -- launches on one stream are ordered,
+    which is what the kernel's hand-over words need.  Never allocates while the stream is being captured."""
+    n = int(_lib.load().mixq_gemm_scratch_size(M, N, K))
+    if n == 0:
+        return None
+    key = (t.device.index, torch.cuda.current_stream(t.device).cuda_stream)
+    buf = _GEMM_SCRATCH.get(key)
+    if buf is None or buf.numel() < n:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        buf = torch.zeros(n, dtype=torch.uint8, device=t.device)
+        _GEMM_SCRATCH[key] = buf
+    return buf
+
+
 def _fused(name, A, B, scale_row, scale_col, y, M, N, K):
     _dev(*(t for t in (A, B, scale_row, scale_col, y) if t is not None))  # y = None: no addend (zeros in the reference)
     D = torch.empty((M, N), dtype=torch.float16, device=A.device)
     fn = getattr(_lib.load(), name)
-    _lib.check(fn(_p(A), _p(B), _p(scale_row), _p(scale_col), _p(y), _p(D), M, N, K, None, _st(A)), name)
+    _lib.check(fn(_p(A), _p(B), _p(scale_row), _p(scale_col), _p(y), _p(D), M, N, K, _p(gemm_scratch(A, M, N, K)),
+                  _st(A)), name)
     return D
 
 
@@ -116,7 +137,8 @@ def int8FusedDequantizeSiluMul(A, B, scale_row, scale_col, y, mul, M, N, K):
     _dev(*(t for t in (A, B, scale_row, scale_col, y, mul) if t is not None))
     D = torch.empty((M, N), dtype=torch.float16, device=A.device)
     _lib.check(_lib.load().mixq_int8_fused_dequantize_silu_mul(_p(A), _p(B), _p(scale_row), _p(scale_col), _p(y), _p(mul),
-                                                              _p(D), M, N, K, None, _st(A)), "int8FusedDequantizeSiluMul")
+                                                              _p(D), M, N, K, _p(gemm_scratch(A, M, N, K)), _st(A)),
+               "int8FusedDequantizeSiluMul")
     return D
 
 
@@ -261,6 +283,7 @@ def mixq_linear(A, W_int8, sW, fp_weight, ind, out=None, workspace=None):
     if out is None:
         out = torch.empty((M, N), dtype=torch.float16, device=dev)
     _lib.check(lib.mixq_quant_extract(M, K, _p(A), _p(qA), _p(sA), _p(fpA), _p(ind), O, 0, _st(A)), "quant_extract")
-    _lib.check(lib.mixq_gemm_mixed(_p(qA), _p(W_int8), _p(sA), _p(sW), _p(fpA), _p(fp_weight), _p(out), M, N, K, O,
-                                   _st(A)), "gemm_mixed")
+    scr = gemm_scratch(A, M, N, K)
+    _lib.check(lib.mixq_gemm_mixed_scratch(_p(qA), _p(W_int8), _p(sA), _p(sW), _p(fpA), _p(fp_weight), _p(out), M, N, K, O,
+                                           _p(scr), scr.numel() if scr is not None else 0, _st(A)), "gemm_mixed")
     return out

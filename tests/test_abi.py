@@ -96,7 +96,12 @@ def test_workspace_sizes_are_size_t_clean(lib):
     M, N, K = 8192, 12288, 4096
     ws = lib.mixq_workspace_size(h, M, N, K)
     need = M * K + 2 * M + 2 * 128 * M
-    assert need <= ws <= need + 4 * 128 + 128
+    splitk = 256 * 3 * 65536 + 256 * 32           # K-split exchange scratch: one 192-KiB slot + 8 words per CU
+    assert need + splitk <= ws <= need + splitk + 5 * 128 + 128
+    assert lib.mixq_workspace_size(h, 128, N, K) <= 128 * K + 2 * 128 + 2 * 128 * 128 + 4 * 128 + 128   # small M: none
+    assert lib.mixq_gemm_scratch_size(1024, 4096, 11008) == 64 * 4 * 3 * 65536 + 64 * 32   # 4 workgroups per tile
+    assert lib.mixq_gemm_scratch_size(2048, 4096, 4096) == 128 * 2 * 2 * 65536 + 128 * 32  # 2 workgroups per tile
+    assert lib.mixq_gemm_scratch_size(8192, 12288, 4096) == 0 and lib.mixq_gemm_scratch_size(64, 4096, 4096) == 0
     # 1M tokens x 11008: the reference's int arithmetic overflows here
     big = lib.mixq_workspace_size(h, 1 << 20, 4096, 11008)
     assert big > (1 << 20) * 11008 > 2**31
@@ -158,6 +163,8 @@ def test_argument_validation_returns_codes_and_never_touches_the_device():
     assert lib.mixq_gemm_mixed(None, p16, p16, p16, None, None, p16, 8, 64, 64, 0, None) == BADARG
     assert lib.mixq_gemm_mixed(p16, p16, p16, p16, None, None, p16, 8, 64, 64, 128, None) == BADARG  # O > 0 without operands
     assert lib.mixq_gemm_mixed(p16, p16, p16, p16, None, None, p16, 0, 64, 64, 0, None) == OK
+    assert lib.mixq_gemm_mixed_scratch(p16, p16, p16, p16, None, None, p16, 8, 64, 40, 0, None, 0, None) == SHAPE
+    assert lib.mixq_gemm_mixed_scratch(None, p16, p16, p16, None, None, p16, 8, 64, 64, 0, p16, 64, None) == BADARG
     assert lib.mixq_int8_fused_dequantize(p16, p16, p16, p16, None, p16, 8, 64, 24, None, None) == SHAPE
     assert lib.mixq_int8_fused_dequantize_silu_mul(p16, p16, p16, p16, None, None, p16, 8, 64, 64, None, None) == BADARG
     # 4-bit flavour and outlier helpers

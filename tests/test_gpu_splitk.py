@@ -1,0 +1,165 @@
+"""GPU (-m gpu): the K split over 2 / 4 workgroups per tile (csrc/gemm_pp_kernels.hip, SPLITK) -- mid-size problems whose
+256x256 tiles cover at most half / a quarter of the CUs.  The split form must give the SAME BITS as the
+one-workgroup-per-tile kernels (integer partial sums commute; the epilogue is shared), on ragged shapes, partial last K
+slices, every epilogue, repeated launches on one scratch (the arrival words re-arm themselves), inside a HIP graph, and
+through the plugin's enqueue, which carves the scratch from its workspace."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import make_layer
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+@pytest.fixture
+def lib():
+    from mixq_tensorrt_llm_amd import _lib
+    lib = _lib.load()
+    yield lib
+    lib.mixq_debug_set_gemm_variant(79)   # automatic choice again
+
+
+def operands(M, N, K, O, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    d = "cuda:0"
+    qA = torch.randint(-127, 128, (M, K), dtype=torch.int8, generator=g).to(d)
+    W = torch.randint(-127, 128, (N, K), dtype=torch.int8, generator=g).to(d)
+    sA = (torch.rand(M, generator=g) * 0.05 + 0.01).to(torch.float16).to(d)
+    sW = (torch.rand(N, generator=g) * 4e-4 + 1e-4).to(torch.float16).to(d)
+    fpA = torch.randn((M, max(O, 8)), generator=g).to(torch.float16).to(d)[:, :O].contiguous()
+    fpW = (torch.randn((N, max(O, 8)), generator=g) * 0.02).to(torch.float16).to(d)[:, :O].contiguous()
+    return qA, W, sA, sW, fpA, fpW
+
+
+SHAPES = [(300, 528, 2064),     # ragged M and N, partial last K slice, 2 x 3 tiles
+          (512, 1024, 2048),    # whole tiles, 16 slices (4 per workgroup in the 4-way form)
+          (257, 272, 4224),     # one row / 16 columns into the second tile, odd slice count
+          (1100, 1536, 2176)]   # 5 x 6 tiles: 8 groups of XCDs unevenly filled
+
+
+@pytest.mark.parametrize("factor", [2, 4])
+@pytest.mark.parametrize("M,N,K", SHAPES)
+@pytest.mark.parametrize("O", [128, 0, 40])
+def test_split_form_gives_the_bits_of_the_one_workgroup_form(lib, factor, M, N, K, O):
+    qA, W, sA, sW, fpA, fpW = operands(M, N, K, O, seed=M + N + K + O)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    fa, fw = (p(fpA), p(fpW)) if O else (None, None)
+    ref = torch.empty((M, N), dtype=torch.float16, device="cuda:0")
+    assert lib.mixq_gemm_mixed(p(qA), p(W), p(sA), p(sW), fa, fw, p(ref), M, N, K, O, st) == 0
+    lib.mixq_debug_set_gemm_variant(70 + factor)
+    n = lib.mixq_gemm_scratch_size(M, N, K)
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    assert n == tiles * factor * (factor - 1) * (4 // factor) * 65536 + tiles * 32
+    scr = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
+    for round_ in range(3):   # the same scratch again and again: the last reader of every tile re-arms its words
+        out = torch.full((M, N), float("nan"), dtype=torch.float16, device="cuda:0")
+        assert lib.mixq_gemm_mixed_scratch(p(qA), p(W), p(sA), p(sW), fa, fw, p(out), M, N, K, O, p(scr), n, st) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref), f"round {round_}"
+    assert int(scr[n - tiles * 32:].to(torch.int32).sum()) == 0, "arrival words left non-zero"
+    # a scratch that is too small (or absent) selects the one-workgroup form, silently and correctly
+    out = torch.empty((M, N), dtype=torch.float16, device="cuda:0")
+    assert lib.mixq_gemm_mixed_scratch(p(qA), p(W), p(sA), p(sW), fa, fw, p(out), M, N, K, O, p(scr), n - 1, st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("factor", [2, 4])
+@pytest.mark.parametrize("epi", ["dequant", "dequant+y", "silu", "silu+y", "silu_mul"])
+def test_split_form_every_epilogue_of_the_p_flavour(lib, factor, epi):
+    """int8FusedDequantize / ...Silu / ...SiluMul (mixlib): the `workspace` argument of the reference's signature carries
+    the scratch."""
+    M, N, K = 520, 784, 2320
+    qA, W, sA, sW, _, _ = operands(M, N, K, 0, seed=11)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    y = (torch.randn((M, N), generator=g) * 0.5).to(torch.float16).to("cuda:0") if "+y" in epi else None
+    mul = torch.randn((M, N), generator=g).to(torch.float16).to("cuda:0")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def run(scratch):
+        out = torch.empty((M, N), dtype=torch.float16, device="cuda:0")
+        if epi == "silu_mul":
+            rc = lib.mixq_int8_fused_dequantize_silu_mul(p(qA), p(W), p(sA), p(sW), None, p(mul), p(out), M, N, K,
+                                                         p(scratch), st)
+        else:
+            fn = lib.mixq_int8_fused_dequantize_silu if epi.startswith("silu") else lib.mixq_int8_fused_dequantize
+            rc = fn(p(qA), p(W), p(sA), p(sW), p(y), p(out), M, N, K, p(scratch), st)
+        assert rc == 0
+        torch.cuda.synchronize()
+        return out
+
+    ref = run(None)
+    lib.mixq_debug_set_gemm_variant(70 + factor)
+    scr = torch.zeros(lib.mixq_gemm_scratch_size(M, N, K), dtype=torch.uint8, device="cuda:0")
+    assert scr.numel() > 0
+    for _ in range(2):
+        assert torch.equal(run(scr), ref)
+
+
+@pytest.mark.parametrize("factor", [2, 4])
+def test_split_form_through_enqueue_matches_the_oracle(oracle, lib, factor):
+    """The plugin carves the scratch from its workspace and zeroes the arrival words itself (the workspace is shared)."""
+    from test_gpu_parity import REL_TOL, bits, rel_err, run_enqueue
+    M, N, K = 600, 784, 2304
+    A, W, act = make_layer(M, N, K, seed=5)
+    pk = oracle.pack_linear_weights(W, act)
+    lib.mixq_debug_set_gemm_variant(70)
+    plain = run_enqueue(A, pk)
+    lib.mixq_debug_set_gemm_variant(70 + factor)
+    assert lib.mixq_gemm_scratch_size(M, N, K) > 0
+    got = run_enqueue(A, pk)
+    assert np.array_equal(bits(got), bits(plain))
+    want = oracle.linear_prefill(A, pk["weight"], pk["weights_scaling_factor"], pk["fp_weight"], pk["fp_ind"])
+    assert rel_err(got, want) < REL_TOL
+
+
+def test_automatic_choice_and_graph_replay(lib):
+    """Default selection on a shape it is made for (64 tiles, 86 K slices -> 4 workgroups per tile), captured into a HIP
+    graph and replayed: every replay re-uses the scratch the previous one left re-armed."""
+    M, N, K, O = 1024, 4096, 11008, 128
+    lib.mixq_debug_set_gemm_variant(79)
+    n = lib.mixq_gemm_scratch_size(M, N, K)
+    assert n == 64 * 4 * 3 * 65536 + 64 * 32
+    qA, W, sA, sW, fpA, fpW = operands(M, N, K, O, seed=1)
+    ref = torch.empty((M, N), dtype=torch.float16, device="cuda:0")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.mixq_gemm_mixed(p(qA), p(W), p(sA), p(sW), p(fpA), p(fpW), p(ref), M, N, K, O, st) == 0
+    scr = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
+    out = torch.empty((M, N), dtype=torch.float16, device="cuda:0")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        sst = ctypes.c_void_p(side.cuda_stream)
+        call = lambda: lib.mixq_gemm_mixed_scratch(p(qA), p(W), p(sA), p(sW), p(fpA), p(fpW), p(out), M, N, K, O,
+                                                   p(scr), n, sst)
+        assert call() == 0
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            assert call() == 0
+    torch.cuda.current_stream().wait_stream(side)
+    for _ in range(3):
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+
+
+def test_mixlib_wrappers_pick_up_a_per_stream_scratch(lib):
+    from mixq_tensorrt_llm_amd import mixlib
+    M, N, K = 512, 12288, 4096        # 96 tiles -> 2 workgroups per tile
+    assert lib.mixq_gemm_scratch_size(M, N, K) > 0
+    qA, W, sA, sW, _, _ = operands(M, N, K, 0, seed=2)
+    lib.mixq_debug_set_gemm_variant(70)
+    ref = mixlib.int8FusedDequantize(qA, W, sA.reshape(M, 1), sW.reshape(1, N), None, M, N, K)
+    lib.mixq_debug_set_gemm_variant(79)
+    got = mixlib.int8FusedDequantize(qA, W, sA.reshape(M, 1), sW.reshape(1, N), None, M, N, K)
+    assert mixlib.gemm_scratch(qA, M, N, K) is not None
+    assert torch.equal(got, ref)

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--what", default="both")
+    ap.add_argument("--check", action="store_true", help="compare the output with the plain launch bit for bit (20 rounds)")
     ap.add_argument("--zero", action="store_true", help="zero-filled operands (DVFS ceiling probe)")
     ap.add_argument("--stamps", action="store_true", help="print the per-tile timeline from in-kernel s_memtime stamps")
     a = ap.parse_args()
@@ -47,8 +48,12 @@ def main():
     def quant():
         assert lib.mixq_quant_extract(M, K, p(A), p(qA), p(sA), p(fpA), p(ind), O, 0, st) == 0
 
+    nscr = lib.mixq_gemm_scratch_size(M, N, K)   # > 0 only with --variant 72 / 74 / 79 (K split over workgroups)
+    scr = torch.zeros(max(nscr, 16), dtype=torch.uint8, device=dev)
+
     def gemm():
-        assert lib.mixq_gemm_mixed(p(qA), p(W), p(sA), p(sW), p(fpA), p(fpW), p(out), M, N, K, O, st) == 0
+        assert lib.mixq_gemm_mixed_scratch(p(qA), p(W), p(sA), p(sW), p(fpA), p(fpW), p(out), M, N, K, O,
+                                           p(scr) if nscr else None, nscr, st) == 0
 
     if a.what == "decode":
         Wq = torch.randint(0, 256, (K, N), dtype=torch.uint8, device=dev, generator=g)
@@ -70,6 +75,16 @@ def main():
     quant()
     gemm()
     torch.cuda.synchronize()
+    if a.check:
+        bad = 0
+        for _ in range(20):
+            quant(); gemm(); torch.cuda.synchronize()
+            ref = out.clone()
+            out.zero_()
+            assert lib.mixq_gemm_mixed(p(qA), p(W), p(sA), p(sW), p(fpA), p(fpW), p(out), M, N, K, O, st) == 0
+            torch.cuda.synchronize()
+            bad += 0 if torch.equal(ref, out) else 1
+        print("bit-identical to the plain launch (20 rounds):", bad == 0, "scratch bytes", nscr)
     if a.stamps:
         timeline(lib, gemm, M, N, dev, a.variant)
     for name, fn in (("quant", quant), ("gemm", gemm)):
@@ -94,23 +109,25 @@ def main():
 
 def timeline(lib, gemm, M, N, dev, variant=0):
     import numpy as np
-    nblk = ((M + 255) // 256) * ((N + 255) // 256)
+    nblk = 4 * ((M + 255) // 256) * ((N + 255) // 256) + 32   # (up to 4 workgroups per tile in the split form)
     buf = torch.zeros(nblk * 8, dtype=torch.int64, device=dev)
     lib.mixq_debug_set_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
     gemm()
     torch.cuda.synchronize()
     lib.mixq_debug_set_stamp_buffer(None)
     t = buf.cpu().numpy().reshape(nblk, 8).astype(np.float64)
-    t = t[t[:, 0] > 0]   # the persistent variant stamps one tile per resident workgroup
+    t = t[(t[:, 0] > 0) & (t[:, 7] > 0)]   # only workgroups that ran
     nblk = len(t)
     t0 = t[:, 0].min()
     names = ["prologue", "main loop", "outlier stage", "dequant math", "tile->LDS", "issue stores", "drain stores"]
     if variant == 3:  # persistent kernel: stamps of the second tile of every resident workgroup
         names = ["slices 0-1", "steady slices", "tail slices", "fpW half 1", "dequant math", "next slice 0 + LDS", "stores"]
+    if variant in (72, 74, 79):   # K split over workgroups
+        names = ["prologue", "main loop", "park", "outlier stage", "arrival wait", "fetch + add", "epilogue"]
     d = np.diff(t, axis=1)
-    print(f"stamps: {nblk} blocks; kernel span {(t[:, 7].max() - t0):.0f} ticks; per-block total mean {(t[:,7]-t[:,0]).mean():.0f}")
+    print(f"stamps: {nblk} blocks; kernel span {(t[:, -1].max() - t0):.0f} ticks; per-block total mean {(t[:, -1] - t[:, 0]).mean():.0f}")
     for i, nme in enumerate(names):
-        print(f"   {nme:14s} mean {d[:, i].mean():9.0f}  min {d[:, i].min():9.0f}  max {d[:, i].max():9.0f} ticks")
+        print(f"   {nme:20s} mean {d[:, i].mean():9.0f}  min {d[:, i].min():9.0f}  max {d[:, i].max():9.0f} ticks")
     starts = np.sort(t[:, 0] - t0)
     print("   block start times (ticks): " + " ".join(f"{starts[int(q * (nblk - 1))]:.0f}" for q in (0, .1, .2, .4, .6, .8, 1.0)))
 
