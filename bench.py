@@ -112,6 +112,45 @@ def small_m_points(lib, TensorDesc, dev, gen, st_ptr, iters=300):
     return out
 
 
+def mid_m_points(lib, TensorDesc, dev, gen, st_ptr, iters=100):
+    """Informational (never part of `value`): a short prefill -- the same three linears on ONE chunk of 1024 / 2048 tokens,
+    where the 256x256 tiles no longer fill the chip and the library splits K over 2 / 4 workgroups per tile
+    (DESIGN.md 2.3).  Whole operator (quantiser + GEMM) through mixq_enqueue."""
+    out = {}
+    for M in (1024, 2048):
+        per = {}
+        total = 0.0
+        for name, N, K in LLAMA2_7B["linears"]:
+            t = synth_layer(N, K, dev, gen)
+            A = synth_activation(M, K, t["ind_i32"], dev, gen)
+            o = torch.empty((M, N), dtype=torch.float16, device=dev)
+            ins = [A, t["weight"], t["weights_scaling_factor"], t["fp_weight"], t["fp_ind"], t["qweight"],
+                   t["weights_scaling_factor"]]
+            in_desc = (TensorDesc * 7)(*[TensorDesc.make(x.shape) for x in ins])
+            out_desc = TensorDesc.make(o.shape)
+            in_ptrs = (ctypes.c_void_p * 7)(*[x.data_ptr() for x in ins])
+            out_ptrs = (ctypes.c_void_p * 1)(o.data_ptr())
+            h = ctypes.c_void_p(lib.mixq_create(M, N, K))
+            ws = torch.empty(max(lib.mixq_workspace_size(h, M, N, K), 16), dtype=torch.uint8, device=dev)
+            run = lambda: lib.mixq_enqueue(h, in_desc, ctypes.byref(out_desc), in_ptrs, out_ptrs,  # noqa: E731
+                                           ctypes.c_void_p(ws.data_ptr()), st_ptr)
+            for _ in range(10):
+                assert run() == 0
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                run()
+            torch.cuda.synchronize(dev)
+            dt = (time.perf_counter() - t0) / iters
+            lib.mixq_destroy(h)
+            total += dt
+            per[name] = {"us_per_call": dt * 1e6, "TOPS": 2.0 * M * N * (K + NUM_OUTLIERS) / dt / 1e12,
+                         "k_split": lib.mixq_gemm_scratch_size(M, N, K) > 0}
+            del t, A, o, ws
+        out[f"prefill_{M}_tokens"] = {"linears": per, "tokens_per_s": M / (total * LLAMA2_7B["layers"])}
+    return out
+
+
 def cpu_baseline(seconds_target=15.0):
     """The oracle (CPU restatement of the reference arithmetic, OpenMP) on a bounded sample: ONE Llama-2-7B layer
     (its three MixQ linears), M tokens chosen so the run takes ~seconds_target; tokens/s for the full model = M /
@@ -360,6 +399,10 @@ def main():
             res["small_m"] = small_m_points(lib, TensorDesc, dev, gen, st_ptr)
         except Exception as e:  # noqa: BLE001
             res["small_m"] = {"error": repr(e)}
+        try:  # informational mid-M points (short prefill: tiles do not fill the chip); never part of `value`
+            res["mid_m"] = mid_m_points(lib, TensorDesc, dev, gen, st_ptr)
+        except Exception as e:  # noqa: BLE001
+            res["mid_m"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline()
