@@ -121,19 +121,27 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     const int nwg = tiles_m * tiles_n;
     int t_lin, rank = 0;
-    if (SPLITK) { // block = idx * 8 + grp * S + rank: the S workgroups of a tile are consecutive blocks; each of the
-                  // 8 / S groups of XCDs takes a contiguous range of tiles (neighbouring tiles share operand rows in L2)
+    // SPLITK kernels: the first p.splitk_solo tiles (whole waves of tiles, a multiple of 8) are computed by one workgroup
+    // each, exactly like the plain kernel; only the tiles of the last, partial wave are split S ways
+    const int n_solo = SPLITK ? p.splitk_solo : 0;
+    const bool solo = SPLITK && (int)blockIdx.x < n_solo;
+    if (SPLITK && solo) {
+        const int bid = blockIdx.x;
+        t_lin = (bid & 7) * (n_solo >> 3) + (bid >> 3);
+    } else if (SPLITK) { // block = idx * 8 + grp * S + rank: the S workgroups of a tile are consecutive blocks; each of
+                         // the 8 / S groups of XCDs takes a contiguous range of tiles (neighbours share operand rows in L2)
         constexpr int G = 8 / S;
-        const int bid = blockIdx.x, xcd = bid & 7, grp = xcd / S, idx = bid >> 3;
+        const int bid = blockIdx.x - n_solo, xcd = bid & 7, grp = xcd / S, idx = bid >> 3;
         rank = xcd % S;
-        const int q = nwg / G, rem = nwg % G;
+        const int ntail = nwg - n_solo, q = ntail / G, rem = ntail % G;
         if (idx >= q + (grp < rem ? 1 : 0)) return; // (all S blocks of the group leave together)
-        t_lin = (grp < rem ? grp * (q + 1) : rem * (q + 1) + (grp - rem) * q) + idx;
+        t_lin = n_solo + (grp < rem ? grp * (q + 1) : rem * (q + 1) + (grp - rem) * q) + idx;
     } else {
         const int bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         t_lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
     const int jperm = rank * PJ;                                   // accumulator m tile jj <-> m tile jj ^ jperm
+    const int nt = SPLITK && !solo ? NT : 8;                       // 32x32 accumulator tiles this workgroup finishes
     auto jmap = [&](int jj) __attribute__((always_inline)) { return SPLITK ? (jj ^ jperm) : jj; };
     int tile_m, tile_n;
     {
@@ -177,7 +185,7 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
     const bool ktail = (p.K % KS) != 0;
     // K range of this workgroup in slices
     const int k_begin = SPLITK && rank > 0 ? ((nk * rank / S) + 1) & ~1 : 0;
-    const int k_end = SPLITK && rank + 1 < S ? ((nk * (rank + 1) / S) + 1) & ~1 : nk;
+    const int k_end = SPLITK && !solo && rank + 1 < S ? ((nk * (rank + 1) / S) + 1) & ~1 : nk;
     const unsigned lds0 = (unsigned)(size_t)(MIXQ_LDS_PTR(smem)) + wave * 1024; // this wave's 1-KiB DMA window
 
     // 2 x LDS-DMA: region `region` of slice kt.  TAILCHK: slice kt may be partial in K (chunks past K <- zero page).
@@ -285,7 +293,9 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
     // SPLITK bookkeeping words of this tile (behind all slots): [0..3] arrival, [4] workgroups done reading
     constexpr int SLOT = (S - 1) * PJ * 2 * 16 * T; // dwords per (tile, rank) slot
     int* const ws = static_cast<int*>(p.splitk_ws);
-    unsigned* const words = SPLITK ? reinterpret_cast<unsigned*>(ws + (size_t)nwg * S * SLOT) + t_lin * 8 : nullptr;
+    const int t_split = t_lin - n_solo; // index among the split tiles
+    unsigned* const words =
+        SPLITK ? reinterpret_cast<unsigned*>(ws + (size_t)(nwg - n_solo) * S * SLOT) + t_split * 8 : nullptr;
     // ---- prologue: slice 0 completely, then stagger the groups ----------------------------------------------
     issue(0, k_begin, true);
     issue(2, k_begin, true);
@@ -313,8 +323,8 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
 
     // ---- SPLITK: park the shares the other workgroups of the group finish, publish the arrival word
     // slot of (tile, rank): [(S-1) shares][2 n tiles][PJ m tiles][16][512 lanes] dwords (one instruction = a 2-KiB run)
-    if (SPLITK) {
-        int* const mine = ws + ((size_t)t_lin * S + rank) * SLOT + tid;
+    if (SPLITK && !solo) {
+        int* const mine = ws + ((size_t)t_split * S + rank) * SLOT + tid;
 #pragma unroll
         for (int sh = 1; sh < S; ++sh)
 #pragma unroll
@@ -380,7 +390,7 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    if (SPLITK) { // ---- add the other workgroups' partial sums of this workgroup's share
+    if (SPLITK && !solo) { // ---- add the other workgroups' partial sums of this workgroup's share
         stamp(4);
         if (tid < S && tid != rank) {
             int spins = 0;
@@ -394,7 +404,7 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
         int pk[S > 1 ? S - 1 : 1][2][PJ][16];
 #pragma unroll
         for (int sh = 1; sh < S; ++sh) { // share sh of workgroup rank ^ sh is this workgroup's own share
-            const int* const theirs = ws + ((size_t)t_lin * S + (rank ^ sh)) * SLOT + tid;
+            const int* const theirs = ws + ((size_t)t_split * S + (rank ^ sh)) * SLOT + tid;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -423,7 +433,7 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
         }
         stamp(6);
     }
-    if (!SPLITK) stamp(3);
+    if (!SPLITK || solo) stamp(3);
 
     // ---- dequant math + stores, one 32 (m) x 64 (n) block of the wave tile at a time.  Results are packed to fp16 and
     // transposed through a wave-private 4-KiB LDS window (32 rows x 128 B; the 32 KiB above the slice buffers), then
@@ -438,7 +448,7 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
     float sa[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) // (clamped rows are never stored)
-        sa[j] = j < PJ ? h2f(p.sA[min(m0 + wm * 128 + jmap(j) * 32 + lr, p.M - 1)]) : 0.f;
+        sa[j] = 2 * j < nt ? h2f(p.sA[min(m0 + wm * 128 + jmap(j) * 32 + lr, p.M - 1)]) : 0.f;
 
     // side GEMM of tile (i, j): 8 k-steps of 16 outlier columns
     auto side = [&](int i, int j) __attribute__((always_inline)) {
@@ -574,13 +584,14 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
     {
         v16f Pcur = side(0, 0);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
+        for (int t = 0; t < 8; ++t) {
+            if (SPLITK && t >= nt) break; // (uniform)
             v16f Pnext = Pcur;
-            if (t + 1 < NT) Pnext = side((t + 1) & 1, (t + 1) >> 1);
+            if (t + 1 < nt) Pnext = side((t + 1) & 1, (t + 1) >> 1);
             if ((HAS_Y || HAS_MUL) && (t & 1) == 0) { // block j = t >> 1 starts: operands of this block -> registers
                 if (HAS_Y) spread(ypre, yq);
                 if (HAS_MUL) spread(mpre, mq);
-                if (t + 2 < NT) {
+                if (t + 2 < nt) {
                     if (HAS_Y) fetch(p.Y, (t >> 1) + 1, ypre);
                     if (HAS_MUL) fetch(p.Mul, (t >> 1) + 1, mpre);
                 }
@@ -591,7 +602,7 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    if (!SPLITK) {
+    if (!SPLITK || solo) {
         stamp(4);
         stamp(5);
         stamp(6);
@@ -644,40 +655,59 @@ static int num_cus()
 static std::atomic<int> g_splitk_force{-1}; // -1 automatic, 0 off, 2 / 4: that factor wherever the shape allows it
 void set_splitk_force(int v) { g_splitk_force.store(v); }
 
-// Automatic choice, from tools/splitk_select_sweep.py on MI355X: with the tiles on (1/4, 1/2] of the CUs
-// two workgroups per tile always pay; on at most 1/4 of the CUs four pay once K is long enough to amortise the
-// exchange (3 x 64 KiB per workgroup each way) and there are enough tiles for the small-tile kernels to be L2-bound;
-// rows that fill less than one 256-row tile are better served by the small-tile kernels.
-int gemm_splitk_factor(int M, int N, int K)
+// Automatic choice, from tools/splitk_select_sweep.py on MI355X.
+//  * tiles <= CUs / 2 (one partial wave of tiles): with the tiles on (1/4, 1/2] of the CUs two workgroups per tile
+//    always pay; on at most 1/4 of the CUs four pay once K is long enough to amortise the exchange (3 x 64 KiB per
+//    workgroup each way) and there are enough tiles for the small-tile kernels to be L2-bound; rows that fill less
+//    than one 256-row tile are better served by the small-tile kernels.
+//  * tiles > CUs (whole waves + a partial one): the whole waves run one workgroup per tile ("solo"), the tiles of the
+//    last wave are split if they cover at most half of the CUs -- instead of a last wave that takes a full tile time
+//    on a fraction of the chip.
+SplitPlan gemm_splitk_plan(int M, int N, int K)
 {
+    SplitPlan none{0, 0};
     const int force = g_splitk_force.load();
-    if (force == 0 || M <= 128) return 0;
-    const int64_t tiles = (int64_t)((M + pp::BM - 1) / pp::BM) * ((N + pp::BN - 1) / pp::BN);
+    if (force == 0 || M <= 128) return none;
+    const int tiles = ((M + pp::BM - 1) / pp::BM) * ((N + pp::BN - 1) / pp::BN);
     const int nk = (K + pp::KS - 1) / pp::KS;
-    const int cus = num_cus();
-    if (force == 4) return 4 * tiles <= cus && nk >= 16 ? 4 : 0;
-    if (force == 2) return 2 * tiles <= cus && nk >= 8 ? 2 : 0;
-    if (M < 256 || 2 * tiles > cus) return 0;
-    if (4 * tiles > cus) return nk >= 16 ? 2 : 0;
-    if (nk >= 64 && 8 * tiles >= cus) return 4;
-    if (nk >= 40 && 16 * tiles >= 3 * cus) return 2;
-    return 0;
+    const int cus = num_cus() & ~7;
+    if (tiles > cus) { // hybrid
+        const int tail = tiles % cus;
+        if (tail == 0 || 2 * tail > cus) return none;
+        // measured: -10..-16 % with a tail on up to 1/4 of the CUs (4 ways), -4..-11 % up to ~0.4 of the CUs (2 ways),
+        // nothing left at 1/2 (the plain kernel's last wave overlaps the one before and runs at higher clocks)
+        int s = 4 * tail <= cus && nk >= 24 ? 4 : (16 * tail <= 7 * cus && nk >= 12 ? 2 : 0);
+        if (force == 2 && nk >= 8) s = 2;
+        if (force == 2 && s == 4) s = 2;
+        if (force == 4 && s != 4) s = 4 * tail <= cus && nk >= 16 ? 4 : 0;
+        return s ? SplitPlan{s, tiles - tail} : none;
+    }
+    if (force == 4) return 4 * tiles <= cus && nk >= 16 ? SplitPlan{4, 0} : none;
+    if (force == 2) return 2 * tiles <= cus && nk >= 8 ? SplitPlan{2, 0} : none;
+    if (M < 256 || 2 * tiles > cus) return none;
+    if (4 * tiles > cus) return nk >= 16 ? SplitPlan{2, 0} : none;
+    if (nk >= 64 && 8 * tiles >= cus) return SplitPlan{4, 0};
+    if (nk >= 40 && 16 * tiles >= 3 * cus) return SplitPlan{2, 0};
+    return none;
 }
+
+int gemm_splitk_factor(int M, int N, int K) { return gemm_splitk_plan(M, N, K).s; }
 
 static size_t splitk_slot_bytes(int s) { return (size_t)(s - 1) * (4 / s) * 2 * 16 * pp::T * 4; }
 
 size_t gemm_splitk_workspace_size(int M, int N, int K)
 {
-    const int s = gemm_splitk_factor(M, N, K);
-    if (s == 0) return 0;
-    const size_t tiles = (size_t)((M + pp::BM - 1) / pp::BM) * ((N + pp::BN - 1) / pp::BN);
-    return tiles * s * splitk_slot_bytes(s) + tiles * 32;
+    const SplitPlan pl = gemm_splitk_plan(M, N, K);
+    if (pl.s == 0) return 0;
+    const size_t tiles = (size_t)((M + pp::BM - 1) / pp::BM) * ((N + pp::BN - 1) / pp::BN) - pl.solo;
+    return tiles * pl.s * splitk_slot_bytes(pl.s) + tiles * 32;
 }
 
 void gemm_splitk_words(int M, int N, int K, size_t* offset, size_t* bytes)
 {
+    const SplitPlan pl = gemm_splitk_plan(M, N, K);
     const size_t total = gemm_splitk_workspace_size(M, N, K);
-    const size_t tiles = (size_t)((M + pp::BM - 1) / pp::BM) * ((N + pp::BN - 1) / pp::BN);
+    const size_t tiles = (size_t)((M + pp::BM - 1) / pp::BM) * ((N + pp::BN - 1) / pp::BN) - pl.solo;
     *bytes = total ? tiles * 32 : 0;
     *offset = total ? total - tiles * 32 : 0;
 }
@@ -696,9 +726,9 @@ static hipError_t launch_pp_splitk_cfg(const GemmParams& p, hipStream_t st)
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    const int tiles = ((p.M + pp::BM - 1) / pp::BM) * ((p.N + pp::BN - 1) / pp::BN);
+    const int tail = ((p.M + pp::BM - 1) / pp::BM) * ((p.N + pp::BN - 1) / pp::BN) - p.splitk_solo;
     constexpr int G = 8 / SPLITK;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(8 * ((tiles + G - 1) / G))), dim3(pp::T), lds, st, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.splitk_solo + 8 * ((tail + G - 1) / G))), dim3(pp::T), lds, st, p);
     return hipGetLastError();
 }
 
@@ -710,10 +740,13 @@ static hipError_t launch_pp_splitk_epi(const GemmParams& p, hipStream_t st)
     return launch_pp_splitk_cfg<EPI, false, false, SPLITK>(p, st);
 }
 
-hipError_t launch_gemm_pp_splitk(const GemmParams& p, int epi, hipStream_t st)
+hipError_t launch_gemm_pp_splitk(const GemmParams& p_in, int epi, hipStream_t st)
 {
-    const int s = gemm_splitk_factor(p.M, p.N, p.K);
-    if (s == 0 || p.splitk_ws == nullptr) return hipErrorInvalidValue;
+    const SplitPlan pl = gemm_splitk_plan(p_in.M, p_in.N, p_in.K);
+    const int s = pl.s;
+    if (s == 0 || p_in.splitk_ws == nullptr) return hipErrorInvalidValue;
+    GemmParams p = p_in;
+    p.splitk_solo = pl.solo;
     switch (epi) {
     case EPI_DEQUANT:
         return s == 4 ? launch_pp_splitk_epi<EPI_DEQUANT, 4>(p, st) : launch_pp_splitk_epi<EPI_DEQUANT, 2>(p, st);

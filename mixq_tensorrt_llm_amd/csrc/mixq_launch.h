@@ -21,6 +21,7 @@ struct GemmParams {
     const void* zeros;    // >= 16 B of device zeros (K / O tails)
     int M, N, K, O;
     void* dbg;            // measurement only: 8 x uint64 s_memtime stamps per block (ping-pong kernel), else null
+    int splitk_solo;      // (set by launch_gemm_pp_splitk) leading tiles that are not split
     void* splitk_ws;      // device scratch of gemm_splitk_workspace_size bytes whose arrival words are zero, or null: lets
                           // launch_gemm split K over 2 / 4 workgroups per 256x256 tile when the tiles alone cover at
                           // most half / a quarter of the CUs (gemm_pp_kernels.hip)
@@ -28,7 +29,12 @@ struct GemmParams {
 
 hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st);
 hipError_t launch_gemm_pp(const GemmParams& p, int epi, hipStream_t st);  // 256x256 ping-pong schedule
-int gemm_splitk_factor(int M, int N, int K);              // 0 (one workgroup per tile) / 2 / 4
+struct SplitPlan {
+    int s;    // workgroups per split tile: 0 (no split form for this shape) / 2 / 4
+    int solo; // leading tiles (whole waves) computed by one workgroup each, inside the same launch
+};
+SplitPlan gemm_splitk_plan(int M, int N, int K);
+int gemm_splitk_factor(int M, int N, int K);              // = plan.s
 size_t gemm_splitk_workspace_size(int M, int N, int K);   // 0: the shape does not use the split form (or it is off)
 size_t gemm_splitk_workspace_bound();                     // max of the above over all shapes (for workspace sizing)
 void gemm_splitk_words(int M, int N, int K, size_t* offset, size_t* bytes); // the arrival words inside that scratch

@@ -72,6 +72,35 @@ def test_split_form_gives_the_bits_of_the_one_workgroup_form(lib, factor, M, N, 
 
 
 @pytest.mark.parametrize("factor", [2, 4])
+@pytest.mark.parametrize("M,N,K", [(2048, 8448, 2176),    # 8 x 33 = 264 tiles: one whole wave of 256 + 8 split tiles
+                                   (2000, 8464, 2064)])   # ragged, 8 x 34 = 272 tiles, partial last K slice
+def test_whole_waves_solo_plus_split_tail_in_one_launch(lib, factor, M, N, K):
+    """More tiles than CUs: the whole waves of tiles run one workgroup per tile, the tiles of the last, partial wave are
+    split -- all inside one launch of the split kernel."""
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    if not cus < tiles <= cus + cus // factor:
+        pytest.skip(f"shape is sized for 256 CUs (device has {cus})")
+    O = 128
+    qA, W, sA, sW, fpA, fpW = operands(M, N, K, O, seed=M + N)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ref = torch.empty((M, N), dtype=torch.float16, device="cuda:0")
+    lib.mixq_debug_set_gemm_variant(70)
+    assert lib.mixq_gemm_mixed(p(qA), p(W), p(sA), p(sW), p(fpA), p(fpW), p(ref), M, N, K, O, st) == 0
+    lib.mixq_debug_set_gemm_variant(70 + factor)
+    n = lib.mixq_gemm_scratch_size(M, N, K)
+    tail = tiles % cus
+    assert n == tail * factor * (factor - 1) * (4 // factor) * 65536 + tail * 32
+    scr = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
+    for _ in range(3):
+        out = torch.full((M, N), float("nan"), dtype=torch.float16, device="cuda:0")
+        assert lib.mixq_gemm_mixed_scratch(p(qA), p(W), p(sA), p(sW), p(fpA), p(fpW), p(out), M, N, K, O, p(scr), n,
+                                           st) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("factor", [2, 4])
 @pytest.mark.parametrize("epi", ["dequant", "dequant+y", "silu", "silu+y", "silu_mul"])
 def test_split_form_every_epilogue_of_the_p_flavour(lib, factor, epi):
     """int8FusedDequantize / ...Silu / ...SiluMul (mixlib): the `workspace` argument of the reference's signature carries
