@@ -198,6 +198,8 @@ def main():
                          "of all three shapes (48 / 43 / 16 tile columns) fill the 256 CUs in whole rounds")
     ap.add_argument("--tp", type=int, default=1, help="rows-of-W sharding degree (1 = pure DP, no collective)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mid-m", action="store_true",
+                    help="add the informational 1024 / 2048-token prefill points (K split over workgroups) to the JSON line")
     ap.add_argument("--order", choices=["layer", "chunk"], default="layer",
                     help="layer: each linear sees all tokens before the next one (batched prefill); chunk: chunked prefill")
     ap.add_argument("--no-tp-leg", action="store_true", help="skip the informational TP (row-sharded W) leg at N > 1")
@@ -399,10 +401,13 @@ def main():
             res["small_m"] = small_m_points(lib, TensorDesc, dev, gen, st_ptr)
         except Exception as e:  # noqa: BLE001
             res["small_m"] = {"error": repr(e)}
-        try:  # informational mid-M points (short prefill: tiles do not fill the chip); never part of `value`
-            res["mid_m"] = mid_m_points(lib, TensorDesc, dev, gen, st_ptr)
-        except Exception as e:  # noqa: BLE001
-            res["mid_m"] = {"error": repr(e)}
+        if args.mid_m:  # informational mid-M points (short prefill: tiles do not fill the chip); never part of `value`.
+            # Opt-in: its launches of the ping-pong kernel would otherwise dilute that kernel's average in a
+            # rocprofv3 --stats summary of this command, which has to agree with roofline.avg_launch_ms.
+            try:
+                res["mid_m"] = mid_m_points(lib, TensorDesc, dev, gen, st_ptr)
+            except Exception as e:  # noqa: BLE001
+                res["mid_m"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline()

@@ -18,6 +18,8 @@ if [ "$MODE" = "full" ]; then
 else
   timeout 600 python bench.py --tokens 131072 --steps 1 --warmup 1 2>&1 | tail -3 | tee "$OUT/bench.log"
 fi
+echo "== mid-M leg (short prefill, K split over workgroups)"
+timeout 600 python bench.py --tokens 65536 --steps 1 --warmup 1 --no-cpu-baseline --mid-m 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps(d['mid_m']))" | tee "$OUT/mid_m.json"
 echo "== bench A/B (v1 two-barrier kernel)"
 timeout 600 python bench.py --tokens 131072 --steps 1 --warmup 1 --variant 1 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('v1', d['value'], d['roofline']['achieved'], d['roofline']['avg_launch_ms'])"
 echo "== rocprofv3 kernel trace"
