@@ -396,7 +396,7 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
             int spins = 0;
             while (__hip_atomic_load(words + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1 << 26)) __builtin_trap();
+                if (++spins > (1 << 23)) __builtin_trap(); // seconds: only a co-running kernel that never ends gets here
             }
         }
         __syncthreads();

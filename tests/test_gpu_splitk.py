@@ -192,3 +192,36 @@ def test_mixlib_wrappers_pick_up_a_per_stream_scratch(lib):
     got = mixlib.int8FusedDequantize(qA, W, sA.reshape(M, 1), sW.reshape(1, N), None, M, N, K)
     assert mixlib.gemm_scratch(qA, M, N, K) is not None
     assert torch.equal(got, ref)
+
+
+def test_split_form_next_to_other_work_on_the_gpu(lib):
+    """The groups of a split tile wait for each other, so the protocol must make progress when the kernel does not get
+    the whole chip: (a) behind / next to large one-workgroup-per-tile GEMMs on another stream, (b) two split GEMMs on two
+    streams with a scratch each.  Every result must still be the plain kernel's bits."""
+    M, N, K, O = 1024, 4096, 11008, 128
+    lib.mixq_debug_set_gemm_variant(79)
+    n = lib.mixq_gemm_scratch_size(M, N, K)
+    assert n > 0
+    qA, W, sA, sW, fpA, fpW = operands(M, N, K, O, seed=21)
+    ref = torch.empty((M, N), dtype=torch.float16, device="cuda:0")
+    st0 = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.mixq_gemm_mixed(p(qA), p(W), p(sA), p(sW), p(fpA), p(fpW), p(ref), M, N, K, O, st0) == 0
+    # the neighbour: 8192 x 12288 x 4096 (1536 tiles, ~0.35 ms per launch, every CU busy)
+    Mb, Nb, Kb = 8192, 12288, 4096
+    qB, WB, sAB, sWB, fpAB, fpWB = operands(Mb, Nb, Kb, O, seed=22)
+    outB = torch.empty((Mb, Nb), dtype=torch.float16, device="cuda:0")
+    torch.cuda.synchronize()
+    sa_, sb_, sc_ = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    scr = [torch.zeros(n, dtype=torch.uint8, device="cuda:0") for _ in range(2)]
+    outs = [[torch.empty((M, N), dtype=torch.float16, device="cuda:0") for _ in range(12)] for _ in range(2)]
+    torch.cuda.synchronize()
+    for it in range(12):
+        assert lib.mixq_gemm_mixed(p(qB), p(WB), p(sAB), p(sWB), p(fpAB), p(fpWB), p(outB), Mb, Nb, Kb, O,
+                                   ctypes.c_void_p(sb_.cuda_stream)) == 0
+        for which, stream in enumerate((sa_, sc_)):
+            assert lib.mixq_gemm_mixed_scratch(p(qA), p(W), p(sA), p(sW), p(fpA), p(fpW), p(outs[which][it]), M, N, K,
+                                               O, p(scr[which]), n, ctypes.c_void_p(stream.cuda_stream)) == 0
+    torch.cuda.synchronize()
+    for which in range(2):
+        for it in range(12):
+            assert torch.equal(outs[which][it], ref), (which, it)
