@@ -673,7 +673,7 @@ SplitPlan gemm_splitk_plan(int M, int N, int K)
     const int cus = num_cus() & ~7;
     if (tiles > cus) { // hybrid
         const int tail = tiles % cus;
-        if (tail == 0 || 2 * tail > cus) return none;
+        if (tail == 0 || 2 * tail > cus || (force < 0 && M < 256)) return none; // (mixq_workspace_size reserves from 256 rows)
         // measured: -10..-16 % with a tail on up to 1/4 of the CUs (4 ways), -4..-11 % up to ~0.4 of the CUs (2 ways),
         // nothing left at 1/2 (the plain kernel's last wave overlaps the one before and runs at higher clocks)
         int s = 4 * tail <= cus && nk >= 24 ? 4 : (16 * tail <= 7 * cus && nk >= 12 ? 2 : 0);

@@ -581,7 +581,8 @@ static int enqueue_impl(const mixq_handle* h, const mixq_tensor_desc* inputDesc,
         // mid-size problems: K split over 2 / 4 workgroups per tile through scratch behind fpA (gemm_pp_kernels.hip).
         // The arrival words are zeroed on every call: the workspace is shared with whatever else the engine runs.
         void* scratch = nullptr;
-        const size_t scratch_bytes = mixq::gemm_splitk_workspace_size((int)M, (int)N, (int)K);
+        const size_t scratch_bytes = M >= 256 ? mixq::gemm_splitk_workspace_size((int)M, (int)N, (int)K) : 0; // (reserved
+                                                                                     // by mixq_workspace_size from 256 rows)
         if (scratch_bytes) {
             base = align_up(base + (size_t)M * (size_t)kNumOutliers * sizeof(uint16_t), kWorkspaceAlign);
             scratch = reinterpret_cast<void*>(base);
