@@ -225,3 +225,33 @@ def test_split_form_next_to_other_work_on_the_gpu(lib):
     for which in range(2):
         for it in range(12):
             assert torch.equal(outs[which][it], ref), (which, it)
+
+
+@pytest.mark.parametrize("factor", [2, 4])
+def test_scratch_reuse_with_changing_data_never_sees_stale_partial_sums(lib, factor):
+    """Back-to-back launches on one stream and ONE scratch with alternating operands: a hand-over that could be served
+    from a stale cache line (the previous launch's partial sums at the same scratch address, in another XCD's L2) would
+    produce the other operand set's result."""
+    M, N, K, O = 1024, 4096, 4352, 128       # 64 tiles, 34 slices
+    sets = [operands(M, N, K, O, seed=100 + i) for i in range(2)]
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    refs = []
+    lib.mixq_debug_set_gemm_variant(70)
+    for qA, W, sA, sW, fpA, fpW in sets:
+        r = torch.empty((M, N), dtype=torch.float16, device="cuda:0")
+        assert lib.mixq_gemm_mixed(p(qA), p(W), p(sA), p(sW), p(fpA), p(fpW), p(r), M, N, K, O, st) == 0
+        refs.append(r)
+    assert not torch.equal(refs[0], refs[1])
+    lib.mixq_debug_set_gemm_variant(70 + factor)
+    n = lib.mixq_gemm_scratch_size(M, N, K)
+    assert n > 0
+    scr = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
+    outs = [torch.empty((M, N), dtype=torch.float16, device="cuda:0") for _ in range(10)]
+    torch.cuda.synchronize()
+    for it, out in enumerate(outs):          # no host synchronisation in between
+        qA, W, sA, sW, fpA, fpW = sets[it & 1]
+        assert lib.mixq_gemm_mixed_scratch(p(qA), p(W), p(sA), p(sW), p(fpA), p(fpW), p(out), M, N, K, O, p(scr), n,
+                                           st) == 0
+    torch.cuda.synchronize()
+    for it, out in enumerate(outs):
+        assert torch.equal(out, refs[it & 1]), it
