@@ -255,3 +255,36 @@ def test_scratch_reuse_with_changing_data_never_sees_stale_partial_sums(lib, fac
     torch.cuda.synchronize()
     for it, out in enumerate(outs):
         assert torch.equal(out, refs[it & 1]), it
+
+
+def test_enqueue_with_split_form_is_capturable_in_a_hip_graph(oracle, lib):
+    """mixq_enqueue on a split shape = memset of the arrival words + quantiser + split GEMM: all three are captured and
+    replayed on new data in the same buffers."""
+    from mixq_tensorrt_llm_amd import plugin
+    from test_gpu_parity import bits, run_enqueue, to_dev
+    M, N, K = 600, 784, 2304
+    A, W, act = make_layer(M, N, K, seed=9)
+    pk = oracle.pack_linear_weights(W, act)
+    lib.mixq_debug_set_gemm_variant(72)
+    assert lib.mixq_gemm_scratch_size(M, N, K) > 0
+    layer = plugin.MixQLinear(K, N, device=torch.device("cuda:0")).load(pk)
+    x = to_dev(np.zeros_like(A))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        out = layer(x)
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            out = layer(x)
+    torch.cuda.current_stream().wait_stream(side)
+    for trial in range(3):
+        A2 = np.ascontiguousarray(np.roll(A, trial * 5, axis=0))
+        x.copy_(to_dev(A2))
+        graph.replay()
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().reshape(M, N)
+        lib.mixq_debug_set_gemm_variant(70)
+        eager = run_enqueue(A2, pk)
+        lib.mixq_debug_set_gemm_variant(72)
+        assert np.array_equal(bits(got), bits(eager)), trial
