@@ -288,3 +288,48 @@ def test_enqueue_with_split_form_is_capturable_in_a_hip_graph(oracle, lib):
         eager = run_enqueue(A2, pk)
         lib.mixq_debug_set_gemm_variant(72)
         assert np.array_equal(bits(got), bits(eager)), trial
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 4608, 3584),     # Qwen2-7B qkv, short prefill (72 tiles)
+                                   (2048, 3584, 18944),    # Qwen2-7B down projection (112 tiles)
+                                   (8192, 1024, 28672),    # Llama-2-70B down projection, TP = 8 shard (128 tiles)
+                                   (4096, 1280, 8192),     # Llama-2-70B qkv, TP = 8 shard (80 tiles)
+                                   (1536, 11008, 4096)])   # Llama-2-7B gate: 258 tiles = one wave + 2 split tiles
+def test_model_shapes_of_the_baseline_configs_automatic_choice(lib, M, N, K):
+    """SURVEY 8d configs 4 / 5 (and a tail case of config 2) at the chunk sizes where the split form is selected by
+    default: same bits as the one-workgroup kernels."""
+    O = 128
+    g = torch.Generator(device="cuda:0").manual_seed(M + N + K)
+    d = "cuda:0"
+    qA = torch.randint(-127, 128, (M, K), dtype=torch.int8, device=d, generator=g)
+    W = torch.randint(-127, 128, (N, K), dtype=torch.int8, device=d, generator=g)
+    sA = (torch.rand(M, device=d, generator=g) * 0.05 + 0.01).to(torch.float16)
+    sW = (torch.rand(N, device=d, generator=g) * 4e-4 + 1e-4).to(torch.float16)
+    fpA = torch.randn((M, O), device=d, generator=g).to(torch.float16)
+    fpW = (torch.randn((N, O), device=d, generator=g) * 0.02).to(torch.float16)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    lib.mixq_debug_set_gemm_variant(70)
+    ref = torch.empty((M, N), dtype=torch.float16, device=d)
+    assert lib.mixq_gemm_mixed(p(qA), p(W), p(sA), p(sW), p(fpA), p(fpW), p(ref), M, N, K, O, st) == 0
+    lib.mixq_debug_set_gemm_variant(79)
+    n = lib.mixq_gemm_scratch_size(M, N, K)
+    if torch.cuda.get_device_properties(0).multi_processor_count == 256:
+        assert n > 0, "the automatic rule is expected to split this shape on a 256-CU part"
+    scr = torch.zeros(max(n, 16), dtype=torch.uint8, device=d)
+    out = torch.empty((M, N), dtype=torch.float16, device=d)
+    for _ in range(2):
+        out.zero_()
+        assert lib.mixq_gemm_mixed_scratch(p(qA), p(W), p(sA), p(sW), p(fpA), p(fpW), p(out), M, N, K, O, p(scr), n,
+                                           st) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+    # spot check against exact integer arithmetic: 64 random outputs recomputed in int64 / fp32 on the host
+    idx_m = torch.randint(0, M, (64,), generator=torch.Generator().manual_seed(1)).tolist()
+    idx_n = torch.randint(0, N, (64,), generator=torch.Generator().manual_seed(2)).tolist()
+    for m, nn in zip(idx_m, idx_n):
+        acc = int((qA[m].to(torch.int64) * W[nn].to(torch.int64)).sum())
+        side = float((fpA[m].float() * fpW[nn].float()).sum())
+        side16 = float(torch.tensor(side, dtype=torch.float32).to(torch.float16))
+        want = np.float32(acc) * (np.float32(float(sW[nn])) * np.float32(float(sA[m]))) + np.float32(side16)
+        got = float(out[m, nn])
+        assert abs(got - float(want)) <= 2e-3 * max(1.0, abs(float(want))), (m, nn, got, float(want))
