@@ -22,6 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--vendor", action="store_true")
+    ap.add_argument("--shapes", default="", help='explicit list "M,N,K;M,N,K;..." instead of the built-in grid')
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.load()
@@ -31,11 +32,14 @@ def main():
     p = lambda t: ctypes.c_void_p(t.data_ptr())
     scr = torch.zeros(64 << 20, dtype=torch.uint8, device=dev)
     print("M N K tiles nk | plain_us s2_us s4_us vendor_us | best")
-    for N, K in NK:
+    grid = [(N, K, MS) for N, K in NK]
+    if a.shapes:
+        grid = [(int(t.split(",")[1]), int(t.split(",")[2]), [int(t.split(",")[0])]) for t in a.shapes.split(";") if t]
+    for N, K, ms in grid:
         W = torch.randint(-127, 128, (N, K), dtype=torch.int8, device=dev, generator=g)
         sW = (torch.rand(N, device=dev, generator=g) * 4e-4 + 4e-4).to(torch.float16)
         fpW = (torch.randn((N, O), device=dev, generator=g) * 0.02).to(torch.float16)
-        for M in MS:
+        for M in ms:
             qA = torch.randint(-127, 128, (M, K), dtype=torch.int8, device=dev, generator=g)
             sA = (torch.rand(M, device=dev, generator=g) * 0.05 + 0.01).to(torch.float16)
             fpA = torch.randn((M, O), device=dev, generator=g).to(torch.float16)
