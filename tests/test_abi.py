@@ -176,3 +176,26 @@ def test_argument_validation_returns_codes_and_never_touches_the_device():
     assert lib.mixq_find_outliers_workspace_size(4096) == 512 and lib.mixq_int4_fused_workspace_size(32, 64, 16) == 32 * 32 + 64 * 32
     for code in (1, 2, 3, 4, 5):
         assert lib.mixq_error_string(code)
+
+
+def test_scratch_of_any_shape_fits_the_plugin_workspace(lib):
+    """mixq_enqueue carves the K-split scratch from the plugin workspace behind qA / sA / fpA: for every shape the scratch
+    the GEMM asks for must fit what mixq_workspace_size reserved (host arithmetic only)."""
+    h = lib.mixq_create(0, 0, 0)
+    rng = np.random.default_rng(7)
+    shapes = [(int(m), int(n) * 16, int(k) * 16) for m, n, k in
+              zip(rng.integers(1, 20000, 400), rng.integers(1, 2000, 400), rng.integers(1, 2000, 400))]
+    shapes += [(1024, 4096, 11008), (2048, 4096, 11008), (1536, 11008, 4096), (4096, 1024, 28672), (256, 65536, 4096),
+               (255, 65536, 4096), (200, 80000, 4096), (65536, 12288, 4096)]
+    used = 0
+    for M, N, K in shapes:
+        need = lib.mixq_gemm_scratch_size(M, N, K)
+        al = lambda x: (x + 127) & ~127
+        carved = 128 + al(M * K) + al(2 * M) + al(2 * 128 * M)
+        ws = lib.mixq_workspace_size(h, M, N, K)
+        if M < 256:
+            continue     # enqueue does not use the split form below 256 rows (nothing is reserved there)
+        assert carved + need <= ws, (M, N, K, need, ws)
+        used += need > 0
+    assert used > 20
+    lib.mixq_destroy(h)
