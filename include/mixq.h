@@ -165,8 +165,9 @@ MIXQ_API int mixq_gemm_mixed(const int8_t* qA, const int8_t* W, const void* sA, 
  * most half / a quarter of the CUs split K over 2 / 4 workgroups per tile, which exchange their int32 partial sums
  * through `scratch` and each finish a share of the tile: bit-identical results, 10-35 % less time on the shapes it is
  * chosen for (csrc/gemm_pp_kernels.hip).  mixq_gemm_scratch_size(M,N,K) = bytes needed (0: the split
- * form is not used for this shape; never more than ~48 MiB).  The scratch must be ZERO-FILLED before its first use (the
- * kernel leaves its arrival words zero again) and must not be shared by launches that can run concurrently (one scratch
+ * form is not used for this shape; never more than ~48 MiB).  The scratch must be ZERO-FILLED before its first use (its
+ * first 8 KiB hold the hand-over words of every shape; each launch leaves them zero again, so one scratch serves
+ * launches of any shapes in stream order) and must not be shared by launches that can run concurrently (one scratch
  * per stream).  A null / too small scratch selects the one-workgroup-per-tile kernels (= mixq_gemm_mixed).
  * mixq_enqueue carves this scratch from the plugin workspace itself (and zeroes the arrival words on every call).
  * mixq_debug_set_gemm_variant(70) switches the split form off, 72 / 74 force a factor, 79 = automatic (default). */

@@ -290,12 +290,13 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
             static_cast<unsigned long long*>(p.dbg)[(size_t)blockIdx.x * 8 + idx] = __builtin_readcyclecounter();
     };
     stamp(0);
-    // SPLITK bookkeeping words of this tile (behind all slots): [0..3] arrival, [4] workgroups done reading
+    // SPLITK bookkeeping words of this tile: [0..3] arrival, [4] workgroups done reading.  They live in the FIRST
+    // kSplitkWordsBytes of the scratch whatever the shape, so that one scratch can serve launches of different shapes:
+    // every launch leaves them zero, and no launch ever parks data there.
     constexpr int SLOT = (S - 1) * PJ * 2 * 16 * T; // dwords per (tile, rank) slot
-    int* const ws = static_cast<int*>(p.splitk_ws);
     const int t_split = t_lin - n_solo; // index among the split tiles
-    unsigned* const words =
-        SPLITK ? reinterpret_cast<unsigned*>(ws + (size_t)(nwg - n_solo) * S * SLOT) + t_split * 8 : nullptr;
+    unsigned* const words = SPLITK ? static_cast<unsigned*>(p.splitk_ws) + t_split * 8 : nullptr;
+    int* const ws = reinterpret_cast<int*>(static_cast<char*>(p.splitk_ws) + kSplitkWordsBytes);
     // ---- prologue: slice 0 completely, then stagger the groups ----------------------------------------------
     issue(0, k_begin, true);
     issue(2, k_begin, true);
@@ -700,19 +701,16 @@ size_t gemm_splitk_workspace_size(int M, int N, int K)
     const SplitPlan pl = gemm_splitk_plan(M, N, K);
     if (pl.s == 0) return 0;
     const size_t tiles = (size_t)((M + pp::BM - 1) / pp::BM) * ((N + pp::BN - 1) / pp::BN) - pl.solo;
-    return tiles * pl.s * splitk_slot_bytes(pl.s) + tiles * 32;
+    return kSplitkWordsBytes + tiles * pl.s * splitk_slot_bytes(pl.s);
 }
 
 void gemm_splitk_words(int M, int N, int K, size_t* offset, size_t* bytes)
 {
-    const SplitPlan pl = gemm_splitk_plan(M, N, K);
-    const size_t total = gemm_splitk_workspace_size(M, N, K);
-    const size_t tiles = (size_t)((M + pp::BM - 1) / pp::BM) * ((N + pp::BN - 1) / pp::BN) - pl.solo;
-    *bytes = total ? tiles * 32 : 0;
-    *offset = total ? total - tiles * 32 : 0;
+    *offset = 0;
+    *bytes = gemm_splitk_workspace_size(M, N, K) ? kSplitkWordsBytes : 0;
 }
 
-size_t gemm_splitk_workspace_bound() { return (size_t)num_cus() * splitk_slot_bytes(4) + (size_t)num_cus() * 32; }
+size_t gemm_splitk_workspace_bound() { return kSplitkWordsBytes + (size_t)num_cus() * splitk_slot_bytes(4); }
 
 template <int EPI, bool HAS_O, bool HAS_Y, int SPLITK>
 static hipError_t launch_pp_splitk_cfg(const GemmParams& p, hipStream_t st)

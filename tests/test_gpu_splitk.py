@@ -56,14 +56,14 @@ def test_split_form_gives_the_bits_of_the_one_workgroup_form(lib, factor, M, N, 
     lib.mixq_debug_set_gemm_variant(70 + factor)
     n = lib.mixq_gemm_scratch_size(M, N, K)
     tiles = ((M + 255) // 256) * ((N + 255) // 256)
-    assert n == tiles * factor * (factor - 1) * (4 // factor) * 65536 + tiles * 32
+    assert n == 8192 + tiles * factor * (factor - 1) * (4 // factor) * 65536
     scr = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
     for round_ in range(3):   # the same scratch again and again: the last reader of every tile re-arms its words
         out = torch.full((M, N), float("nan"), dtype=torch.float16, device="cuda:0")
         assert lib.mixq_gemm_mixed_scratch(p(qA), p(W), p(sA), p(sW), fa, fw, p(out), M, N, K, O, p(scr), n, st) == 0
         torch.cuda.synchronize()
         assert torch.equal(out, ref), f"round {round_}"
-    assert int(scr[n - tiles * 32:].to(torch.int32).sum()) == 0, "arrival words left non-zero"
+    assert int(scr[:8192].to(torch.int32).sum()) == 0, "arrival words left non-zero"
     # a scratch that is too small (or absent) selects the one-workgroup form, silently and correctly
     out = torch.empty((M, N), dtype=torch.float16, device="cuda:0")
     assert lib.mixq_gemm_mixed_scratch(p(qA), p(W), p(sA), p(sW), fa, fw, p(out), M, N, K, O, p(scr), n - 1, st) == 0
@@ -90,7 +90,7 @@ def test_whole_waves_solo_plus_split_tail_in_one_launch(lib, factor, M, N, K):
     lib.mixq_debug_set_gemm_variant(70 + factor)
     n = lib.mixq_gemm_scratch_size(M, N, K)
     tail = tiles % cus
-    assert n == tail * factor * (factor - 1) * (4 // factor) * 65536 + tail * 32
+    assert n == 8192 + tail * factor * (factor - 1) * (4 // factor) * 65536
     scr = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
     for _ in range(3):
         out = torch.full((M, N), float("nan"), dtype=torch.float16, device="cuda:0")
@@ -155,7 +155,7 @@ def test_automatic_choice_and_graph_replay(lib):
     M, N, K, O = 1024, 4096, 11008, 128
     lib.mixq_debug_set_gemm_variant(79)
     n = lib.mixq_gemm_scratch_size(M, N, K)
-    assert n == 64 * 4 * 3 * 65536 + 64 * 32
+    assert n == 8192 + 64 * 4 * 3 * 65536
     qA, W, sA, sW, fpA, fpW = operands(M, N, K, O, seed=1)
     ref = torch.empty((M, N), dtype=torch.float16, device="cuda:0")
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -333,3 +333,33 @@ def test_model_shapes_of_the_baseline_configs_automatic_choice(lib, M, N, K):
         want = np.float32(acc) * (np.float32(float(sW[nn])) * np.float32(float(sA[m]))) + np.float32(side16)
         got = float(out[m, nn])
         assert abs(got - float(want)) <= 2e-3 * max(1.0, abs(float(want))), (m, nn, got, float(want))
+
+
+def test_one_scratch_serves_launches_of_different_shapes(lib):
+    """The mixlib wrappers keep ONE scratch per stream for every layer: the hand-over words sit at a fixed place at the
+    start of the scratch, so the data a launch parks can never be mistaken for another shape's arrival words."""
+    lib.mixq_debug_set_gemm_variant(79)
+    shapes = [(1024, 4096, 11008), (512, 12288, 4096), (1536, 11008, 4096), (2048, 4096, 11008), (768, 4096, 8192),
+              (1024, 4096, 11008)]
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    scr = torch.zeros(max(lib.mixq_gemm_scratch_size(*s) for s in shapes), dtype=torch.uint8, device="cuda:0")
+    sets, refs = [], []
+    lib.mixq_debug_set_gemm_variant(70)
+    for i, (M, N, K) in enumerate(shapes):
+        ops = operands(M, N, K, 128, seed=300 + i)
+        r = torch.empty((M, N), dtype=torch.float16, device="cuda:0")
+        assert lib.mixq_gemm_mixed(*[p(t) for t in ops], p(r), M, N, K, 128, st) == 0
+        sets.append(ops), refs.append(r)
+    lib.mixq_debug_set_gemm_variant(79)
+    for round_ in range(3):
+        outs = []
+        for (M, N, K), ops in zip(shapes, sets):      # back to back, no synchronisation
+            o = torch.empty((M, N), dtype=torch.float16, device="cuda:0")
+            n = lib.mixq_gemm_scratch_size(M, N, K)
+            assert n > 0
+            assert lib.mixq_gemm_mixed_scratch(*[p(t) for t in ops], p(o), M, N, K, 128, p(scr), n, st) == 0
+            outs.append(o)
+        torch.cuda.synchronize()
+        for i, (o, r) in enumerate(zip(outs, refs)):
+            assert torch.equal(o, r), (round_, shapes[i])
+    assert int(scr[:8192].to(torch.int32).sum()) == 0
