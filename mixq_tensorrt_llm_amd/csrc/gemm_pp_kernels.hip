@@ -688,6 +688,7 @@ SplitPlan gemm_splitk_plan(int M, int N, int K)
     if (M < 256 || 2 * tiles > cus) return none;
     if (4 * tiles > cus) return nk >= 16 ? SplitPlan{2, 0} : none;
     if (nk >= 64 && 8 * tiles >= cus) return SplitPlan{4, 0};
+    if (nk >= 96 && 64 * tiles >= 5 * cus) return SplitPlan{4, 0}; // 20..31 tiles pay with K >= 12288 (-7..-27 %)
     if (nk >= 40 && 16 * tiles >= 3 * cus) return SplitPlan{2, 0};
     return none;
 }
