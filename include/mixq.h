@@ -162,15 +162,15 @@ MIXQ_API int mixq_int8_fused_dequantize_silu(const int8_t* A, const int8_t* B, c
 MIXQ_API int mixq_gemm_mixed(const int8_t* qA, const int8_t* W, const void* sA, const void* sW, const void* fpA,
                              const void* fpW, void* Out, int M, int N, int K, int O, void* stream);
 /* The fused GEMM with caller-owned device scratch (MI355X extension).  Mid-size problems whose 256x256 tiles cover at
- * most half / a quarter of the CUs split K over 2 / 4 workgroups per tile, which exchange their int32 partial sums
+ * most 1/2, 1/4, 1/8 of the CUs split K over 2 / 4 / 8 workgroups per tile, which exchange their int32 partial sums
  * through `scratch` and each finish a share of the tile: bit-identical results, 10-35 % less time on the shapes it is
  * chosen for (csrc/gemm_pp_kernels.hip).  mixq_gemm_scratch_size(M,N,K) = bytes needed (0: the split
- * form is not used for this shape; never more than ~48 MiB).  The scratch must be ZERO-FILLED before its first use (its
- * first 8 KiB hold the hand-over words of every shape; each launch leaves them zero again, so one scratch serves
+ * form is not used for this shape; never more than ~56 MiB).  The scratch must be ZERO-FILLED before its first use (its
+ * first 16 KiB hold the hand-over words of every shape; each launch leaves them zero again, so one scratch serves
  * launches of any shapes in stream order) and must not be shared by launches that can run concurrently (one scratch
  * per stream).  A null / too small scratch selects the one-workgroup-per-tile kernels (= mixq_gemm_mixed).
  * mixq_enqueue carves this scratch from the plugin workspace itself (and zeroes the arrival words on every call).
- * mixq_debug_set_gemm_variant(70) switches the split form off, 72 / 74 force a factor, 79 = automatic (default). */
+ * mixq_debug_set_gemm_variant(70) switches the split form off, 72 / 74 / 78 force a factor, 79 = automatic (default). */
 MIXQ_API size_t mixq_gemm_scratch_size(int M, int N, int K);
 MIXQ_API int mixq_gemm_mixed_scratch(const int8_t* qA, const int8_t* W, const void* sA, const void* sW, const void* fpA,
                                      const void* fpW, void* Out, int M, int N, int K, int O, void* scratch,

@@ -410,7 +410,7 @@ static std::atomic<int> g_variant{-1};
 
 void set_gemm_variant(int v)
 {
-    if (v >= 70 && v <= 79) { // K split over workgroups (ping-pong kernel): 70 off, 72 / 74 forced factor, 79 automatic
+    if (v >= 70 && v <= 79) { // K split over workgroups (ping-pong kernel): 70 off, 72 / 74 / 78 forced factor, 79 automatic
         set_splitk_force(v == 79 ? -1 : v - 70);
         return;
     }

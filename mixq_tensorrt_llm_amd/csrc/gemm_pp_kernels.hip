@@ -81,7 +81,7 @@ __device__ __forceinline__ void glds16_sbase(const char* sbase, unsigned voff, u
 // ABL: measurement-only ablations (wrong results): 1 = no global_load_lds in the loop, 2 = no vmcnt waits,
 // 4 = no ds_reads in the loop, 8 = every tile loads tile (0,0)'s operands (all L2 hits), 16 = no epilogue.
 // ABL = 0 is the product kernel.
-// SPLITK = 2 / 4: K split over S workgroups per output tile, for mid-size problems whose tiles alone cover at most
+// SPLITK = 2 / 4 / 8: K split over S workgroups per output tile, for mid-size problems whose tiles alone cover at most
 // 1/S of the CUs.  The S workgroups of a tile are S consecutive blocks (dispatched together, resident together); each
 //   1. multiplies its quarter / half of the K slices into the usual 256x256 int32 accumulators, with the 32-row m tiles
 //      of its wave tile PERMUTED (accumulator tile jj holds m tile jj ^ (r * PJ), r = rank in the group, PJ = 4 / S:
@@ -103,9 +103,10 @@ template <int EPI, bool HAS_O, bool HAS_Y, int ABL = 0, int SPLITK = 0>
 __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p)
 {
     constexpr int S = SPLITK ? SPLITK : 1; // workgroups per tile
-    constexpr int PJ = 4 / S;              // 32-row m tiles (per wave) this workgroup finishes
-    constexpr int NT = 2 * PJ;             // 32x32 accumulator tiles it finishes
-    static_assert(SPLITK == 0 || SPLITK == 2 || SPLITK == 4, "");
+    constexpr int PJ = S >= 4 ? 1 : 4 / S; // 32-row m tiles (per wave) this workgroup finishes
+    constexpr int NI = S == 8 ? 1 : 2;     // 32-column n tiles (per wave) it finishes: S = 8 splits the n pair as well
+    constexpr int NT = NI * PJ;            // 32x32 accumulator tiles it finishes
+    static_assert(SPLITK == 0 || SPLITK == 2 || SPLITK == 4 || SPLITK == 8, "");
     using namespace pp;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -140,7 +141,9 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
         const int bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         t_lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int jperm = rank * PJ;                                   // accumulator m tile jj <-> m tile jj ^ jperm
+    const int jperm = (rank * PJ) & 3;                             // accumulator m tile jj <-> m tile jj ^ jperm
+    const int iperm = S == 8 ? rank >> 2 : 0;                      // accumulator n tile ii <-> n tile ii ^ iperm
+    auto imap = [&](int ii) __attribute__((always_inline)) { return S == 8 ? (ii ^ iperm) : ii; };
     const int nt = SPLITK && !solo ? NT : 8;                       // 32x32 accumulator tiles this workgroup finishes
     auto jmap = [&](int jj) __attribute__((always_inline)) { return SPLITK ? (jj ^ jperm) : jj; };
     int tile_m, tile_n;
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
             for (int i = 0; i < 2; ++i) {
                 const int q = i * 64 + (tid >> 3);
                 const int sw = (q >> 1) & 7;
-                const int nl = (q >> 5) * 64 + h * 32 + (q & 31);
+                const int nl = (q >> 5) * 64 + (S == 8 ? h ^ iperm : h) * 32 + (q & 31);
                 const int ml = SPLITK ? (q >> 6) * 128 + (h ^ (jperm >> 1)) * 64 + ((q & 63) ^ ((jperm & 1) << 5))
                                       : (q >> 6) * 128 + h * 64 + (q & 63);
                 const int rn = min(n0 + nl, p.N - 1) - n0, rm = min(m0 + ml, p.M - 1) - m0; // clamped rows, >= 0
@@ -290,12 +293,12 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
             static_cast<unsigned long long*>(p.dbg)[(size_t)blockIdx.x * 8 + idx] = __builtin_readcyclecounter();
     };
     stamp(0);
-    // SPLITK bookkeeping words of this tile: [0..3] arrival, [4] workgroups done reading.  They live in the FIRST
+    // SPLITK bookkeeping words of this tile (16 per tile): [0..7] arrival, [8] workgroups done reading.  They live in the FIRST
     // kSplitkWordsBytes of the scratch whatever the shape, so that one scratch can serve launches of different shapes:
     // every launch leaves them zero, and no launch ever parks data there.
-    constexpr int SLOT = (S - 1) * PJ * 2 * 16 * T; // dwords per (tile, rank) slot
+    constexpr int SLOT = (S - 1) * NI * PJ * 16 * T; // dwords per (tile, rank) slot
     const int t_split = t_lin - n_solo; // index among the split tiles
-    unsigned* const words = SPLITK ? static_cast<unsigned*>(p.splitk_ws) + t_split * 8 : nullptr;
+    unsigned* const words = SPLITK ? static_cast<unsigned*>(p.splitk_ws) + t_split * 16 : nullptr; // [0..7] arrival, [8] done
     int* const ws = reinterpret_cast<int*>(static_cast<char*>(p.splitk_ws) + kSplitkWordsBytes);
     // ---- prologue: slice 0 completely, then stagger the groups ----------------------------------------------
     issue(0, k_begin, true);
@@ -323,19 +326,24 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
     stamp(2);
 
     // ---- SPLITK: park the shares the other workgroups of the group finish, publish the arrival word
-    // slot of (tile, rank): [(S-1) shares][2 n tiles][PJ m tiles][16][512 lanes] dwords (one instruction = a 2-KiB run)
+    // slot of (tile, rank): [(S-1) shares][NI n tiles][PJ m tiles][16][512 lanes] dwords (one instruction = a 2-KiB run)
+    // share sh = accumulator tiles (n tile i0(sh) + i, m tile j0(sh) + x): S <= 4: both n tiles of m tiles sh * PJ ..;
+    // S = 8: the single tile (sh >> 2, sh & 3).  Share sh of rank r holds the tiles that rank r ^ sh finishes.
+    auto share_i0 = [](int sh) { return S == 8 ? sh >> 2 : 0; };
+    auto share_j0 = [](int sh) { return S == 8 ? sh & 3 : sh * PJ; };
     if (SPLITK && !solo) {
         int* const mine = ws + ((size_t)t_split * S + rank) * SLOT + tid;
 #pragma unroll
         for (int sh = 1; sh < S; ++sh)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int x = 0; x < PJ; ++x)
 #pragma unroll
                     for (int e = 0; e < 16; ++e)
-                        __hip_atomic_store(mine + ((((sh - 1) * 2 + i) * PJ + x) * 16 + e) * T, acc[i][sh * PJ + x][e],
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(mine + ((((sh - 1) * NI + i) * PJ + x) * 16 + e) * T,
+                                           acc[share_i0(sh) + i][share_j0(sh) + x][e], __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every write-through acknowledged
         __syncthreads();
         if (tid == 0) __hip_atomic_store(words + rank, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -402,23 +410,23 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
         }
         __syncthreads();
         stamp(5);
-        int pk[S > 1 ? S - 1 : 1][2][PJ][16];
+        int pk[S > 1 ? S - 1 : 1][NI][PJ][16];
 #pragma unroll
         for (int sh = 1; sh < S; ++sh) { // share sh of workgroup rank ^ sh is this workgroup's own share
             const int* const theirs = ws + ((size_t)t_split * S + (rank ^ sh)) * SLOT + tid;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int x = 0; x < PJ; ++x)
 #pragma unroll
                     for (int e = 0; e < 16; ++e)
-                        pk[sh - 1][i][x][e] = __hip_atomic_load(theirs + ((((sh - 1) * 2 + i) * PJ + x) * 16 + e) * T,
+                        pk[sh - 1][i][x][e] = __hip_atomic_load(theirs + ((((sh - 1) * NI + i) * PJ + x) * 16 + e) * T,
                                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
 #pragma unroll
         for (int sh = 1; sh < S; ++sh)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int x = 0; x < PJ; ++x)
 #pragma unroll
@@ -426,10 +434,10 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads(); // every wave of this workgroup has its data
         if (tid == 0) {
-            const unsigned before = __hip_atomic_fetch_add(words + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned before = __hip_atomic_fetch_add(words + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (before == (unsigned)(S - 1)) { // the whole group is done reading: re-arm for the next launch
 #pragma unroll
-                for (int w = 0; w < 5; ++w) __hip_atomic_store(words + w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int w = 0; w < 9; ++w) __hip_atomic_store(words + w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         stamp(6);
@@ -457,7 +465,7 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
 #pragma unroll
         for (int e = 0; e < 16; ++e) P[e] = 0.f;
         if (HAS_O) {
-            const char* xo = smem + (wn * 64 + i * 32 + lr) * OSLICE;
+            const char* xo = smem + (wn * 64 + imap(i) * 32 + lr) * OSLICE;
             const char* yo = smem + BN * OSLICE + (wm * 128 + jmap(j) * 32 + lr) * OSLICE;
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh) { // two batches of 4 k-steps keep the fragment registers at 32
@@ -480,7 +488,7 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-            swq[i][g] = *reinterpret_cast<const uint2*>(p.sW + min(n0 + wn * 64 + i * 32 + 4 * lh + 8 * g, p.N - 4));
+            swq[i][g] = *reinterpret_cast<const uint2*>(p.sW + min(n0 + wn * 64 + imap(i) * 32 + 4 * lh + 8 * g, p.N - 4));
     // [M,N] fp16 operands of the epilogue (the caller's addend y, the gate*up multiplicand) take the store path in
     // reverse: coalesced 16-byte loads of 128-byte row segments (8 rows per instruction), one block ahead, then through
     // the wave's window into the accumulator layout (8 bytes = 4 consecutive n of row lane & 31).  Reading them in the
@@ -514,7 +522,7 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-                out[i][g] = *reinterpret_cast<const uint2*>(wstg + lr * 128 + (((i * 4 + g) ^ (lr & 7)) << 4) + lh * 8);
+                out[i][g] = *reinterpret_cast<const uint2*>(wstg + lr * 128 + (((imap(i) * 4 + g) ^ (lr & 7)) << 4) + lh * 8);
     };
     if (HAS_Y) fetch(p.Y, 0, ypre);
     if (HAS_MUL) fetch(p.Mul, 0, mpre);
@@ -553,6 +561,13 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
                 v2h o16 = f2h2_of_f32_results(v0, v1);
                 if (EPI == EPI_DEQUANT_SILU_MUL) o16 = o16 * __builtin_bit_cast(v2h, e2 ? mulq.y : mulq.x); // gate * up
                 __builtin_memcpy(&ow[e2 >> 1], &o16, 4);
+            }
+            if (S == 8) { // a single 32x32 tile per wave: 8-byte stores straight from the accumulator layout
+                const int m = m0 + wm * 128 + jmap(j) * 32 + lr;
+                const int n = n0 + wn * 64 + imap(i) * 32 + 4 * lh + 8 * g;
+                if (m < p.M && n < p.N)
+                    *reinterpret_cast<uint2*>(static_cast<uint16_t*>(p.D) + (int64_t)m * p.N + n) = uint2{ow[0], ow[1]};
+                continue;
             }
             const int c = i * 4 + g; // 16-byte chunk of the 128-byte row
             *reinterpret_cast<uint2*>(wstg + wrow + ((c ^ (lr & 7)) << 4)) = uint2{ow[0], ow[1]};
@@ -598,7 +613,7 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
                 }
             }
             dequant(t & 1, t >> 1, Pcur);
-            if (t & 1) flush(t >> 1);
+            if (S != 8 && (t & 1)) flush(t >> 1);
             Pcur = Pnext;
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -681,12 +696,18 @@ SplitPlan gemm_splitk_plan(int M, int N, int K)
         if (force == 2 && nk >= 8) s = 2;
         if (force == 2 && s == 4) s = 2;
         if (force == 4 && s != 4) s = 4 * tail <= cus && nk >= 16 ? 4 : 0;
+        if (force == 8) s = 8 * tail <= cus && nk >= 32 ? 8 : 0;
         return s ? SplitPlan{s, tiles - tail} : none;
     }
+    if (force == 8) return 8 * tiles <= cus && nk >= 32 ? SplitPlan{8, 0} : none;
     if (force == 4) return 4 * tiles <= cus && nk >= 16 ? SplitPlan{4, 0} : none;
     if (force == 2) return 2 * tiles <= cus && nk >= 8 ? SplitPlan{2, 0} : none;
     if (M < 256 || 2 * tiles > cus) return none;
     if (4 * tiles > cus) return nk >= 16 ? SplitPlan{2, 0} : none;
+    if (8 * tiles <= cus) { // at most 1/8 of the CUs: 8 ways once K amortises 7 x 32 KiB each way per workgroup
+        const bool pays = 8 * tiles == cus ? nk >= 192 : 64 * tiles >= 3 * cus ? nk >= 86 : 32 * tiles >= cus && nk >= 160;
+        if (pays) return SplitPlan{8, 0};
+    }
     if (nk >= 64 && 8 * tiles >= cus) return SplitPlan{4, 0};
     if (nk >= 96 && 64 * tiles >= 5 * cus) return SplitPlan{4, 0}; // 20..31 tiles pay with K >= 12288 (-7..-27 %)
     if (nk >= 40 && 16 * tiles >= 3 * cus) return SplitPlan{2, 0};
@@ -695,7 +716,10 @@ SplitPlan gemm_splitk_plan(int M, int N, int K)
 
 int gemm_splitk_factor(int M, int N, int K) { return gemm_splitk_plan(M, N, K).s; }
 
-static size_t splitk_slot_bytes(int s) { return (size_t)(s - 1) * (4 / s) * 2 * 16 * pp::T * 4; }
+static size_t splitk_slot_bytes(int s) // (S - 1) shares of a 256x256 int32 tile's 1/S-th
+{
+    return (size_t)(s - 1) * (pp::BM * pp::BN * 4 / s);
+}
 
 size_t gemm_splitk_workspace_size(int M, int N, int K)
 {
@@ -711,7 +735,7 @@ void gemm_splitk_words(int M, int N, int K, size_t* offset, size_t* bytes)
     *bytes = gemm_splitk_workspace_size(M, N, K) ? kSplitkWordsBytes : 0;
 }
 
-size_t gemm_splitk_workspace_bound() { return kSplitkWordsBytes + (size_t)num_cus() * splitk_slot_bytes(4); }
+size_t gemm_splitk_workspace_bound() { return kSplitkWordsBytes + (size_t)num_cus() * splitk_slot_bytes(8); }
 
 template <int EPI, bool HAS_O, bool HAS_Y, int SPLITK>
 static hipError_t launch_pp_splitk_cfg(const GemmParams& p, hipStream_t st)
@@ -748,12 +772,17 @@ hipError_t launch_gemm_pp_splitk(const GemmParams& p_in, int epi, hipStream_t st
     p.splitk_solo = pl.solo;
     switch (epi) {
     case EPI_DEQUANT:
-        return s == 4 ? launch_pp_splitk_epi<EPI_DEQUANT, 4>(p, st) : launch_pp_splitk_epi<EPI_DEQUANT, 2>(p, st);
+        return s == 8   ? launch_pp_splitk_epi<EPI_DEQUANT, 8>(p, st)
+               : s == 4 ? launch_pp_splitk_epi<EPI_DEQUANT, 4>(p, st)
+                        : launch_pp_splitk_epi<EPI_DEQUANT, 2>(p, st);
     case EPI_DEQUANT_SILU:
-        return s == 4 ? launch_pp_splitk_epi<EPI_DEQUANT_SILU, 4>(p, st) : launch_pp_splitk_epi<EPI_DEQUANT_SILU, 2>(p, st);
+        return s == 8   ? launch_pp_splitk_epi<EPI_DEQUANT_SILU, 8>(p, st)
+               : s == 4 ? launch_pp_splitk_epi<EPI_DEQUANT_SILU, 4>(p, st)
+                        : launch_pp_splitk_epi<EPI_DEQUANT_SILU, 2>(p, st);
     case EPI_DEQUANT_SILU_MUL:
-        return s == 4 ? launch_pp_splitk_epi<EPI_DEQUANT_SILU_MUL, 4>(p, st)
-                      : launch_pp_splitk_epi<EPI_DEQUANT_SILU_MUL, 2>(p, st);
+        return s == 8   ? launch_pp_splitk_epi<EPI_DEQUANT_SILU_MUL, 8>(p, st)
+               : s == 4 ? launch_pp_splitk_epi<EPI_DEQUANT_SILU_MUL, 4>(p, st)
+                        : launch_pp_splitk_epi<EPI_DEQUANT_SILU_MUL, 2>(p, st);
     default: return hipErrorInvalidValue;
     }
 }

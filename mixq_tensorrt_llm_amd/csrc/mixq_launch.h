@@ -29,9 +29,9 @@ struct GemmParams {
 
 hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st);
 hipError_t launch_gemm_pp(const GemmParams& p, int epi, hipStream_t st);  // 256x256 ping-pong schedule
-constexpr size_t kSplitkWordsBytes = 8192; // hand-over words of up to 256 split tiles, at the start of the scratch
+constexpr size_t kSplitkWordsBytes = 16384; // hand-over words (64 B per tile) of up to 256 split tiles, at the start of the scratch
 struct SplitPlan {
-    int s;    // workgroups per split tile: 0 (no split form for this shape) / 2 / 4
+    int s;    // workgroups per split tile: 0 (no split form for this shape) / 2 / 4 / 8
     int solo; // leading tiles (whole waves) computed by one workgroup each, inside the same launch
 };
 SplitPlan gemm_splitk_plan(int M, int N, int K);

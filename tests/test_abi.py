@@ -96,11 +96,11 @@ def test_workspace_sizes_are_size_t_clean(lib):
     M, N, K = 8192, 12288, 4096
     ws = lib.mixq_workspace_size(h, M, N, K)
     need = M * K + 2 * M + 2 * 128 * M
-    splitk = 256 * 3 * 65536 + 8192               # K-split exchange scratch: one 192-KiB slot per CU + the hand-over words
+    splitk = 256 * 7 * 32768 + 16384              # K-split exchange scratch: one 224-KiB slot per CU + the hand-over words
     assert need + splitk <= ws <= need + splitk + 5 * 128 + 128
     assert lib.mixq_workspace_size(h, 128, N, K) <= 128 * K + 2 * 128 + 2 * 128 * 128 + 4 * 128 + 128   # small M: none
-    assert lib.mixq_gemm_scratch_size(1024, 4096, 11008) == 8192 + 64 * 4 * 3 * 65536   # 4 workgroups per tile
-    assert lib.mixq_gemm_scratch_size(2048, 4096, 4096) == 8192 + 128 * 2 * 2 * 65536  # 2 workgroups per tile
+    assert lib.mixq_gemm_scratch_size(1024, 4096, 11008) == 16384 + 64 * 3 * 262144   # 4 workgroups per tile
+    assert lib.mixq_gemm_scratch_size(2048, 4096, 4096) == 16384 + 128 * 1 * 262144  # 2 workgroups per tile
     assert lib.mixq_gemm_scratch_size(8192, 12288, 4096) == 0 and lib.mixq_gemm_scratch_size(64, 4096, 4096) == 0
     # 1M tokens x 11008: the reference's int arithmetic overflows here
     big = lib.mixq_workspace_size(h, 1 << 20, 4096, 11008)

@@ -44,10 +44,12 @@ SHAPES = [(300, 528, 2064),     # ragged M and N, partial last K slice, 2 x 3 ti
           (1100, 1536, 2176)]   # 5 x 6 tiles: 8 groups of XCDs unevenly filled
 
 
-@pytest.mark.parametrize("factor", [2, 4])
+@pytest.mark.parametrize("factor", [2, 4, 8])
 @pytest.mark.parametrize("M,N,K", SHAPES)
 @pytest.mark.parametrize("O", [128, 0, 40])
 def test_split_form_gives_the_bits_of_the_one_workgroup_form(lib, factor, M, N, K, O):
+    if factor == 8:
+        K = 2 * K + 16          # 8 ways need >= 32 K slices
     qA, W, sA, sW, fpA, fpW = operands(M, N, K, O, seed=M + N + K + O)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     fa, fw = (p(fpA), p(fpW)) if O else (None, None)
@@ -56,14 +58,14 @@ def test_split_form_gives_the_bits_of_the_one_workgroup_form(lib, factor, M, N, 
     lib.mixq_debug_set_gemm_variant(70 + factor)
     n = lib.mixq_gemm_scratch_size(M, N, K)
     tiles = ((M + 255) // 256) * ((N + 255) // 256)
-    assert n == 8192 + tiles * factor * (factor - 1) * (4 // factor) * 65536
+    assert n == 16384 + tiles * (factor - 1) * 262144   # hand-over words + (S - 1) x 256 KiB per split tile
     scr = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
     for round_ in range(3):   # the same scratch again and again: the last reader of every tile re-arms its words
         out = torch.full((M, N), float("nan"), dtype=torch.float16, device="cuda:0")
         assert lib.mixq_gemm_mixed_scratch(p(qA), p(W), p(sA), p(sW), fa, fw, p(out), M, N, K, O, p(scr), n, st) == 0
         torch.cuda.synchronize()
         assert torch.equal(out, ref), f"round {round_}"
-    assert int(scr[:8192].to(torch.int32).sum()) == 0, "arrival words left non-zero"
+    assert int(scr[:16384].to(torch.int32).sum()) == 0, "arrival words left non-zero"
     # a scratch that is too small (or absent) selects the one-workgroup form, silently and correctly
     out = torch.empty((M, N), dtype=torch.float16, device="cuda:0")
     assert lib.mixq_gemm_mixed_scratch(p(qA), p(W), p(sA), p(sW), fa, fw, p(out), M, N, K, O, p(scr), n - 1, st) == 0
@@ -90,7 +92,7 @@ def test_whole_waves_solo_plus_split_tail_in_one_launch(lib, factor, M, N, K):
     lib.mixq_debug_set_gemm_variant(70 + factor)
     n = lib.mixq_gemm_scratch_size(M, N, K)
     tail = tiles % cus
-    assert n == 8192 + tail * factor * (factor - 1) * (4 // factor) * 65536
+    assert n == 16384 + tail * (factor - 1) * 262144
     scr = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
     for _ in range(3):
         out = torch.full((M, N), float("nan"), dtype=torch.float16, device="cuda:0")
@@ -100,12 +102,12 @@ def test_whole_waves_solo_plus_split_tail_in_one_launch(lib, factor, M, N, K):
         assert torch.equal(out, ref)
 
 
-@pytest.mark.parametrize("factor", [2, 4])
+@pytest.mark.parametrize("factor", [2, 4, 8])
 @pytest.mark.parametrize("epi", ["dequant", "dequant+y", "silu", "silu+y", "silu_mul"])
 def test_split_form_every_epilogue_of_the_p_flavour(lib, factor, epi):
     """int8FusedDequantize / ...Silu / ...SiluMul (mixlib): the `workspace` argument of the reference's signature carries
     the scratch."""
-    M, N, K = 520, 784, 2320
+    M, N, K = 520, 784, 2320 if factor < 8 else 4624
     qA, W, sA, sW, _, _ = operands(M, N, K, 0, seed=11)
     g = torch.Generator(device="cpu").manual_seed(3)
     y = (torch.randn((M, N), generator=g) * 0.5).to(torch.float16).to("cuda:0") if "+y" in epi else None
@@ -132,11 +134,11 @@ def test_split_form_every_epilogue_of_the_p_flavour(lib, factor, epi):
         assert torch.equal(run(scr), ref)
 
 
-@pytest.mark.parametrize("factor", [2, 4])
+@pytest.mark.parametrize("factor", [2, 4, 8])
 def test_split_form_through_enqueue_matches_the_oracle(oracle, lib, factor):
     """The plugin carves the scratch from its workspace and zeroes the arrival words itself (the workspace is shared)."""
     from test_gpu_parity import REL_TOL, bits, rel_err, run_enqueue
-    M, N, K = 600, 784, 2304
+    M, N, K = 600, 784, 2304 if factor < 8 else 4352
     A, W, act = make_layer(M, N, K, seed=5)
     pk = oracle.pack_linear_weights(W, act)
     lib.mixq_debug_set_gemm_variant(70)
@@ -155,7 +157,7 @@ def test_automatic_choice_and_graph_replay(lib):
     M, N, K, O = 1024, 4096, 11008, 128
     lib.mixq_debug_set_gemm_variant(79)
     n = lib.mixq_gemm_scratch_size(M, N, K)
-    assert n == 8192 + 64 * 4 * 3 * 65536
+    assert n == 16384 + 64 * 3 * 262144
     qA, W, sA, sW, fpA, fpW = operands(M, N, K, O, seed=1)
     ref = torch.empty((M, N), dtype=torch.float16, device="cuda:0")
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -227,12 +229,12 @@ def test_split_form_next_to_other_work_on_the_gpu(lib):
             assert torch.equal(outs[which][it], ref), (which, it)
 
 
-@pytest.mark.parametrize("factor", [2, 4])
+@pytest.mark.parametrize("factor", [2, 4, 8])
 def test_scratch_reuse_with_changing_data_never_sees_stale_partial_sums(lib, factor):
     """Back-to-back launches on one stream and ONE scratch with alternating operands: a hand-over that could be served
     from a stale cache line (the previous launch's partial sums at the same scratch address, in another XCD's L2) would
     produce the other operand set's result."""
-    M, N, K, O = 1024, 4096, 4352, 128       # 64 tiles, 34 slices
+    M, N, K, O = (1024, 4096, 4352, 128) if factor < 8 else (512, 4096, 4352, 128)   # 64 / 32 tiles, 34 slices
     sets = [operands(M, N, K, O, seed=100 + i) for i in range(2)]
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     refs = []
@@ -362,4 +364,4 @@ def test_one_scratch_serves_launches_of_different_shapes(lib):
         torch.cuda.synchronize()
         for i, (o, r) in enumerate(zip(outs, refs)):
             assert torch.equal(o, r), (round_, shapes[i])
-    assert int(scr[:8192].to(torch.int32).sum()) == 0
+    assert int(scr[:16384].to(torch.int32).sum()) == 0

@@ -30,8 +30,8 @@ def main():
     O = 128
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     p = lambda t: ctypes.c_void_p(t.data_ptr())
-    scr = torch.zeros(64 << 20, dtype=torch.uint8, device=dev)
-    print("M N K tiles nk | plain_us s2_us s4_us vendor_us | best")
+    scr = torch.zeros(72 << 20, dtype=torch.uint8, device=dev)
+    print("M N K tiles nk | plain_us s2_us s4_us s8_us vendor_us | best")
     grid = [(N, K, MS) for N, K in NK]
     if a.shapes:
         grid = [(int(t.split(",")[1]), int(t.split(",")[2]), [int(t.split(",")[0])]) for t in a.shapes.split(";") if t]
@@ -45,7 +45,7 @@ def main():
             fpA = torch.randn((M, O), device=dev, generator=g).to(torch.float16)
             out = torch.empty((M, N), dtype=torch.float16, device=dev)
             res, ref = {}, None
-            for v in (70, 72, 74):
+            for v in (70, 72, 74, 78):
                 lib.mixq_debug_set_gemm_variant(v)
                 nscr = lib.mixq_gemm_scratch_size(M, N, K)
                 if v != 70 and nscr == 0:
@@ -83,7 +83,7 @@ def main():
                 ven = e0.elapsed_time(e1) / a.iters * 1e3
             tiles = ((M + 255) // 256) * ((N + 255) // 256)
             best = min((t, v) for v, t in res.items() if t == t)[1]
-            print(f"{M} {N} {K} {tiles} {(K + 127) // 128} | {res[70]:.1f} {res[72]:.1f} {res[74]:.1f} {ven:.1f} | {best}", flush=True)
+            print(f"{M} {N} {K} {tiles} {(K + 127) // 128} | {res[70]:.1f} {res[72]:.1f} {res[74]:.1f} {res[78]:.1f} {ven:.1f} | {best}", flush=True)
     lib.mixq_debug_set_gemm_variant(0)
 
 

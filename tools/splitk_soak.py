@@ -24,7 +24,7 @@ def main():
     cg = torch.Generator().manual_seed(a.seed)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
-    scr = torch.zeros(64 << 20, dtype=torch.uint8, device=dev)
+    scr = torch.zeros(72 << 20, dtype=torch.uint8, device=dev)
     done = bad = tried = 0
     hist = {}
     while done < a.shapes and tried < 100 * a.shapes:
@@ -33,7 +33,7 @@ def main():
         N = int(torch.randint(1, 1200, (1,), generator=cg)) * 16
         K = int(torch.randint(8, 1800, (1,), generator=cg)) * 16
         O = [128, 128, 0, 64][int(torch.randint(0, 4, (1,), generator=cg))]
-        mode = [79, 79, 72, 74][int(torch.randint(0, 4, (1,), generator=cg))]
+        mode = [79, 79, 72, 74, 78][int(torch.randint(0, 5, (1,), generator=cg))]
         lib.mixq_debug_set_gemm_variant(mode)
         n = lib.mixq_gemm_scratch_size(M, N, K)
         if n == 0 or M * N > (1 << 27) or M * K > (1 << 27) or N * K > (1 << 28):
@@ -74,7 +74,7 @@ def main():
         done += 1
     lib.mixq_debug_set_gemm_variant(79)
     print(f"{done} shapes x 4 launches (modes {hist}), {bad} mismatches; hand-over words left zero: "
-          f"{int(scr[:8192].to(torch.int32).sum()) == 0}")
+          f"{int(scr[:16384].to(torch.int32).sum()) == 0}")
     sys.exit(1 if bad else 0)
 
 
