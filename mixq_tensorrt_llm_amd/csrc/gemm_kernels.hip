@@ -40,7 +40,13 @@ constexpr int GROUP_M = 4;
 // PREO: the outlier operands of the epilogue get their own LDS region behind the stages and are copied there at kernel
 // start, under the main loop, instead of after it (used by the one-workgroup-per-CU split-K configurations, where the
 // extra (BM + BN) x 256 bytes of LDS cost no occupancy and the kernel is a chain of latencies).
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int NSTAGE = 2, int KG = 1, bool PREO = false>
+// XS > 1: K is split over XS WORKGROUPS per tile as well (consecutive blocks), for problems with so few tiles that most
+// CUs would otherwise watch a few of them stream K.  Every workgroup parks its partial tile (BM x BN int32: 8-16 KiB)
+// in p.splitk_ws with write-through stores and counts itself in; the one that arrives LAST adds the others' parked
+// sums and runs the epilogue, the others are gone by then -- nobody ever waits, so there is nothing to dead-lock.
+// Hand-over accesses are relaxed agent-scope atomics as in gemm_pp_kernels.hip (no fences); the counter of a tile lives
+// in the first kSplitkWordsBytes of the scratch and is left zero.  Same int32 sums, same bits.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int NSTAGE = 2, int KG = 1, bool PREO = false, int XS = 1>
 __global__ __launch_bounds__(WAVES_M* WAVES_N* KG * 64) void gemm_w8a8o16_kernel(const GemmParams p)
 {
     constexpr int NWAVES = WAVES_M * WAVES_N;
@@ -73,8 +79,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KG * 64) void gemm_w8a8o16_kernel
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     const int nwg = tiles_m * tiles_n;
     int t_lin;
+    const int xrank = XS > 1 ? (int)blockIdx.x % XS : 0; // which part of K this workgroup multiplies
     {
-        const int bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        const int bid = XS > 1 ? (int)blockIdx.x / XS : (int)blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         t_lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3); // bijective for any nwg
     }
     int tile_m, tile_n;
@@ -113,7 +120,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KG * 64) void gemm_w8a8o16_kernel
     }
     static_assert((T / 8) % 16 == 0, "row swizzle term must be i-invariant");
 
-    const int nk = (p.K + KSLICE - 1) / KSLICE;
+    const int nk_all = (p.K + KSLICE - 1) / KSLICE;
+    const int kbeg = XS > 1 ? nk_all * xrank / XS : 0;              // this workgroup's slices: [kbeg, kbeg + nk)
+    const int nk = (XS > 1 ? nk_all * (xrank + 1) / XS : nk_all) - kbeg;
     const bool ktail = (p.K % KSLICE) != 0;
 
     // fpW / fpA tiles -> LDS (256-B rows, slot = chunk ^ (row & 15)); all threads of the workgroup take part
@@ -147,8 +156,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KG * 64) void gemm_w8a8o16_kernel
     auto stage = [&](int buf, int kt) {
         char* xb = smem + buf * STAGE_BYTES;
         char* yb = xb + X_BYTES;
-        const int64_t kbyte = (int64_t)kt * KSLICE;
-        const bool last_partial = ktail && (kt == nk - 1);
+        const int64_t kbyte = (int64_t)(kbeg + kt) * KSLICE;
+        const bool last_partial = ktail && (kbeg + kt == nk_all - 1);
 #pragma unroll
         for (int i = 0; i < XL; ++i) {
             const char* s = xsrc[i] + kbyte;
@@ -251,6 +260,49 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KG * 64) void gemm_w8a8o16_kernel
         }
     }
 
+    // ---- K split over workgroups: park, count in, and only the last one to arrive goes on ----------------------------
+    if (XS > 1) {
+        // (the main-loop stages and the partial accumulators in LDS are dead by now: their first word carries the count;
+        //  a static __shared__ variable would push the 64x64 form past the 160 KiB it already fills)
+        volatile unsigned& arrived_s = *reinterpret_cast<volatile unsigned*>(smem_all);
+        constexpr int TILE_DW = TN * TM * 16 * T; // dwords of one parked tile: [n tile][m tile][16][T threads of group 0]
+        unsigned* const counter = static_cast<unsigned*>(p.splitk_ws) + t_lin;
+        int* const slots = reinterpret_cast<int*>(static_cast<char*>(p.splitk_ws) + kSplitkWordsBytes) +
+                           (size_t)t_lin * XS * TILE_DW;
+        if (group == 0) {
+            int* const mine = slots + (size_t)xrank * TILE_DW + tid;
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        __hip_atomic_store(mine + ((i * TM + j) * 16 + e) * T, acc[i][j][e], __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every write-through acknowledged
+        }
+        __syncthreads();
+        if (tid_all == 0)
+            arrived_s = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (arrived_s != (unsigned)(XS - 1)) return; // not the last one: done (the whole workgroup leaves)
+        if (tid_all == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // re-armed
+        if (group == 0) {
+#pragma unroll
+            for (int o = 1; o < XS; ++o) { // the other XS - 1 parts, in a rotation that depends on nothing but the rank
+                const int* const theirs = slots + (size_t)((xrank + o) % XS) * TILE_DW + tid;
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e)
+                            acc[i][j][e] += __hip_atomic_load(theirs + ((i * TM + j) * 16 + e) * T, __ATOMIC_RELAXED,
+                                                              __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+
     // ---- outlier side GEMM operands (unless they were copied at kernel start) ----------------------------------------
     if (has_outliers && !PREO) {
         __syncthreads(); // main-loop LDS (and the partial accumulators) are dead
@@ -338,13 +390,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KG * 64) void gemm_w8a8o16_kernel
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int NSTAGE = 2, int KG = 1, bool PREO = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int NSTAGE = 2, int KG = 1, bool PREO = false, int XS = 1>
 static hipError_t launch_cfg(const GemmParams& p, hipStream_t st)
 {
     constexpr int T = WAVES_M * WAVES_N * KG * 64;
     constexpr size_t lds = (size_t)KG * NSTAGE * (size_t)(BM + BN) * KSLICE + (PREO ? (size_t)(BM + BN) * OSLICE : 0);
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = gemm_w8a8o16_kernel<BM, BN, WAVES_M, WAVES_N, EPI, NSTAGE, KG, PREO>;
+    auto kern = gemm_w8a8o16_kernel<BM, BN, WAVES_M, WAVES_N, EPI, NSTAGE, KG, PREO, XS>;
     static bool attr_done = false; // benign race: idempotent
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -353,9 +405,54 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t st)
         attr_done = true;
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(T), lds, st, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * XS)), dim3(T), lds, st, p);
     return hipGetLastError();
 }
+
+// ---- K split over workgroups for the two small-tile forms with in-workgroup split (see the kernel header) ------------
+static std::atomic<int> g_xsplit_force{-1}; // -1 automatic, 0 off, 2 / 4 forced where the shape allows it
+void set_xsplit_force(int v) { g_xsplit_force.store(v); }
+
+// 0 = not used.  Applies to the problems launch_epi gives to the 32x64 / 64x64 tiles with 4 K groups (at most 256 tiles):
+// XS = 4 / 2 more workgroups per tile while that still leaves at most one workgroup per CU, and K is long enough for
+// each of the 4 x XS parts to keep a few slices.
+// The plan: which of the two tilings, and how many workgroups per tile.  The tiling is the first of 32x64 / 64x64 that
+// gives at most 128 tiles (so that at least two workgroups per tile fit on the chip at one workgroup per CU).
+struct XSplitPlan {
+    int xs;    // 0 = not used
+    bool t32;  // 32x64 tiles (else 64x64)
+    int tiles;
+};
+static XSplitPlan xsplit_plan(int M, int N, int K)
+{
+    XSplitPlan none{0, false, 0};
+    const int force = g_xsplit_force.load();
+    if (force == 0 || M <= 4) return none;
+    if (force < 0 && M <= 16 && K < 16384) return none; // M <= 16: the skinny kernel unless K is very long (measured)
+    const int64_t n64 = (N + 63) / 64;
+    const int64_t wg32 = (int64_t)((M + 31) / 32) * n64, wg64 = (int64_t)((M + 63) / 64) * n64;
+    const bool t32 = wg32 <= 128;
+    const int64_t tiles = t32 ? wg32 : wg64;
+    if (tiles > 128) return none;
+    const int nk = (K + KSLICE - 1) / KSLICE;
+    int xs = tiles <= 64 ? 4 : 2;
+    if (force == 2) xs = 2;
+    if (force == 4 && xs != 4) return none;
+    if (nk < 8 * xs) return none;               // every one of the 4 x XS K parts keeps at least two slices
+    if (force < 0 && nk < 64) return none;      // automatic: K >= 8192 (measured: at K = 4096 the exchange eats the gain)
+    return XSplitPlan{xs, t32, (int)tiles};
+}
+
+int gemm_xsplit_factor(int M, int N, int K) { return xsplit_plan(M, N, K).xs; }
+
+size_t gemm_xsplit_workspace_size(int M, int N, int K)
+{
+    const XSplitPlan pl = xsplit_plan(M, N, K);
+    if (pl.xs == 0) return 0;
+    return kSplitkWordsBytes + (size_t)pl.tiles * pl.xs * (size_t)((pl.t32 ? 32 : 64) * 64 * 4);
+}
+
+size_t gemm_xsplit_workspace_bound() { return kSplitkWordsBytes + (size_t)128 * 4 * 64 * 64 * 4; }
 
 static std::atomic<int> g_force_cfg{-1}; // measurement knob (variant 10 + i): force tile configuration i
 
@@ -395,6 +492,13 @@ static hipError_t launch_epi(const GemmParams& p, hipStream_t st)
     // tile and split K among themselves (KG = 4, then 2); with ~3 tiles per CU plain 64x64 tiles; beyond that 128x128.
     const int64_t n64 = (p.N + 63) / 64;
     const int64_t wg32 = (int64_t)((p.M + 31) / 32) * n64, wg64 = (int64_t)((p.M + 63) / 64) * n64;
+    if (EPI != EPI_INT32 && p.splitk_ws != nullptr) { // few tiles: K split over 2 / 4 workgroups per tile as well
+        const XSplitPlan pl = xsplit_plan(p.M, p.N, p.K);
+        if (pl.xs == 4) return pl.t32 ? launch_cfg<32, 64, 1, 2, EPI, 2, 4, true, 4>(p, st)
+                                      : launch_cfg<64, 64, 2, 2, EPI, 2, 4, true, 4>(p, st);
+        if (pl.xs == 2) return pl.t32 ? launch_cfg<32, 64, 1, 2, EPI, 2, 4, true, 2>(p, st)
+                                      : launch_cfg<64, 64, 2, 2, EPI, 2, 4, true, 2>(p, st);
+    }
     if (wg32 <= 256) return launch_cfg<32, 64, 1, 2, EPI, 2, 4, true>(p, st);
     if (wg64 <= 256) return launch_cfg<64, 64, 2, 2, EPI, 2, 4, true>(p, st);
     if (wg64 <= 512) return launch_cfg<64, 64, 2, 2, EPI, 2, 2>(p, st);
@@ -412,6 +516,11 @@ void set_gemm_variant(int v)
 {
     if (v >= 70 && v <= 79) { // K split over workgroups (ping-pong kernel): 70 off, 72 / 74 / 78 forced factor, 79 automatic
         set_splitk_force(v == 79 ? -1 : v - 70);
+        if (v == 70 || v == 79) set_xsplit_force(v == 79 ? -1 : 0);
+        return;
+    }
+    if (v >= 60 && v <= 69) { // the same for the small-tile kernels: 60 off, 62 / 64 forced factor, 69 automatic
+        set_xsplit_force(v == 69 ? -1 : v - 60);
         return;
     }
     if (v >= 40 && v < 100) { // 40 + kw: skinny kernel with kw K-split waves (measurements)
@@ -446,7 +555,11 @@ hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st)
     if (p.M <= 0 || p.N <= 0) return hipSuccess;
     const int variant = gemm_variant();
     // M <= 16, and M <= 32 on narrow outputs: the weight-streaming GEMV-like kernel (measured against the split-K tiles)
-    if (variant != 1 && gemm_skinny_supported(p) && (p.M <= 16 || (p.M <= 32 && p.N < 8192)))
+    // ... unless K is long and the tiles are few: then the small tiles with K split over workgroups win (M = 24 / 32 on
+    // 4096 x 11008: 14 vs 18 us; on 1024 x 28672: 17 vs 39 us)
+    const bool xsplit_wins = epi != EPI_INT32 && p.splitk_ws != nullptr && p.K >= 8192 &&
+                             gemm_xsplit_factor(p.M, p.N, p.K) != 0;
+    if (variant != 1 && !xsplit_wins && gemm_skinny_supported(p) && (p.M <= 16 || (p.M <= 32 && p.N < 8192)))
         return launch_gemm_skinny(p, epi, st);
     const int64_t tiles256 = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256);
     if (variant >= 100) return launch_gemm_pp_ablate(p, variant - 100, st); // measurement-only ablations

@@ -238,7 +238,9 @@ size_t mixq_workspace_size(const mixq_handle*, int64_t maxM, int64_t /*N*/, int6
     s += align_up((size_t)maxM * (size_t)K, kWorkspaceAlign);                                 // qA
     s += align_up((size_t)maxM * sizeof(uint16_t), kWorkspaceAlign);                          // sA
     s += align_up((size_t)maxM * (size_t)kNumOutliers * sizeof(uint16_t), kWorkspaceAlign);   // fpA
-    if (maxM >= 256) s += align_up(mixq::gemm_splitk_workspace_bound(), kWorkspaceAlign);     // K-split exchange scratch
+    // exchange scratch of the K splits over workgroups: the 256x256 form from 256 rows, the small-tile form below that
+    if (maxM >= 256) s += align_up(mixq::gemm_splitk_workspace_bound(), kWorkspaceAlign);
+    else if (maxM > 4) s += align_up(mixq::gemm_xsplit_workspace_bound(), kWorkspaceAlign);
     return s;
 }
 
@@ -453,7 +455,14 @@ int mixq_int8_fused_dequantize_silu_mul(const int8_t* A, const int8_t* B, const 
                               workspace);
 }
 
-size_t mixq_gemm_scratch_size(int M, int N, int K) { return mixq::gemm_splitk_workspace_size(M, N, K); }
+// scratch of whichever cross-workgroup K split launch_gemm would pick for this shape (at most one applies)
+static size_t gemm_scratch_bytes(int M, int N, int K)
+{
+    const size_t a = mixq::gemm_splitk_workspace_size(M, N, K);
+    return a ? a : mixq::gemm_xsplit_workspace_size(M, N, K);
+}
+
+size_t mixq_gemm_scratch_size(int M, int N, int K) { return gemm_scratch_bytes(M, N, K); }
 
 int mixq_gemm_mixed(const int8_t* qA, const int8_t* W, const void* sA, const void* sW, const void* fpA,
                     const void* fpW, void* Out, int M, int N, int K, int O, void* stream)
@@ -480,7 +489,7 @@ int mixq_gemm_mixed_scratch(const int8_t* qA, const int8_t* W, const void* sA, c
     if (!p.zeros) return MIXQ_E_HIP;
     p.M = M, p.N = N, p.K = K;
     p.dbg = g_dbg_stamps;
-    if (scratch && aligned16(scratch) && scratch_bytes >= mixq::gemm_splitk_workspace_size(M, N, K)) p.splitk_ws = scratch;
+    if (scratch && aligned16(scratch) && scratch_bytes >= gemm_scratch_bytes(M, N, K)) p.splitk_ws = scratch;
     if (O <= kNumOutliers) {
         p.fpA = static_cast<const uint16_t*>(fpA), p.fpW = static_cast<const uint16_t*>(fpW), p.O = O;
         return hip_rc(mixq::launch_gemm(p, mixq::EPI_DEQUANT, st));
@@ -574,22 +583,26 @@ static int enqueue_impl(const mixq_handle* h, const mixq_tensor_desc* inputDesc,
         base = align_up(base + (size_t)M * sizeof(uint16_t), kWorkspaceAlign);
         void* fpA = reinterpret_cast<void*>(base);
 
-        int rc = mixq_quant_extract((int)M, (int)K, const_cast<void*>(A), qA, sA, fpA, ind, kNumOutliers, 0, stream);
-        if (rc != MIXQ_OK) return rc;
+        // Mid-size and small problems split K over several workgroups per tile, which hand their partial sums over
+        // through scratch behind fpA (gemm_pp_kernels.hip, gemm_kernels.hip).  mixq_workspace_size reserves the 256x256
+        // form's scratch from 256 rows on and the small-tile form's below that.  The hand-over words at its start are
+        // cleared on every call -- the workspace is shared with whatever else the engine runs -- by the quantiser, which
+        // runs one launch earlier anyway.
         hipStream_t st = static_cast<hipStream_t>(stream);
-        if (ev_gemm_start && hipEventRecord(static_cast<hipEvent_t>(ev_gemm_start), st) != hipSuccess) return MIXQ_E_HIP;
-        // mid-size problems: K split over 2 / 4 workgroups per tile through scratch behind fpA (gemm_pp_kernels.hip).
-        // The arrival words are zeroed on every call: the workspace is shared with whatever else the engine runs.
         void* scratch = nullptr;
-        const size_t scratch_bytes = M >= 256 ? mixq::gemm_splitk_workspace_size((int)M, (int)N, (int)K) : 0; // (reserved
-                                                                                     // by mixq_workspace_size from 256 rows)
+        const size_t scratch_bytes = M >= 256   ? gemm_scratch_bytes((int)M, (int)N, (int)K)
+                                     : M > 4   ? mixq::gemm_xsplit_workspace_size((int)M, (int)N, (int)K)
+                                                : 0;
         if (scratch_bytes) {
             base = align_up(base + (size_t)M * (size_t)kNumOutliers * sizeof(uint16_t), kWorkspaceAlign);
             scratch = reinterpret_cast<void*>(base);
-            size_t woff = 0, wbytes = 0;
-            mixq::gemm_splitk_words((int)M, (int)N, (int)K, &woff, &wbytes);
-            if (hipMemsetAsync(static_cast<char*>(scratch) + woff, 0, wbytes, st) != hipSuccess) return MIXQ_E_HIP;
         }
+        if (K % 8) return MIXQ_E_SHAPE;
+        if (!aligned16(A)) return MIXQ_E_ALIGN;
+        int rc = hip_rc(mixq::launch_quant_extract(const_cast<void*>(A), qA, sA, fpA, ind, (int)M, (int)K, kNumOutliers,
+                                                   false, st, scratch));
+        if (rc != MIXQ_OK) return rc;
+        if (ev_gemm_start && hipEventRecord(static_cast<hipEvent_t>(ev_gemm_start), st) != hipSuccess) return MIXQ_E_HIP;
         rc = mixq_gemm_mixed_scratch(qA, W, sA, scale_b, fpA, fp_weight, Out, (int)M, (int)N, (int)K, kNumOutliers,
                                      scratch, scratch_bytes, stream);
         if (ev_gemm_stop && hipEventRecord(static_cast<hipEvent_t>(ev_gemm_stop), st) != hipSuccess) return MIXQ_E_HIP;

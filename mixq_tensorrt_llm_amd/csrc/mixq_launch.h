@@ -41,6 +41,11 @@ size_t gemm_splitk_workspace_bound();                     // max of the above ov
 void gemm_splitk_words(int M, int N, int K, size_t* offset, size_t* bytes); // the arrival words inside that scratch
 hipError_t launch_gemm_pp_splitk(const GemmParams& p, int epi, hipStream_t st);
 void set_splitk_force(int v); // -1 automatic (default), 0 off, 2 / 4: that factor wherever the shape allows it
+// the same idea for the small-tile kernels with in-workgroup split (gemm_kernels.hip, XS): few tiles, long K
+int gemm_xsplit_factor(int M, int N, int K);              // 0 / 2 / 4
+size_t gemm_xsplit_workspace_size(int M, int N, int K);
+size_t gemm_xsplit_workspace_bound();
+void set_xsplit_force(int v); // -1 automatic (default), 0 off, 2 / 4 forced
 bool gemm_skinny_supported(const GemmParams& p);
 hipError_t launch_gemm_skinny(const GemmParams& p, int epi, hipStream_t st); // M <= 64: GEMV-like, HBM-bound on W
 bool gemm_pp2_supported(const GemmParams& p, int epi);
@@ -52,7 +57,8 @@ hipError_t launch_gemm_fp16(const void* fpA, const void* fpW, void* Out, int M, 
 hipError_t launch_dequantization(void* out, const int32_t* x, const void* sRow, const void* sCol, int M, int N,
                                  hipStream_t st);
 hipError_t launch_quant_extract(void* A, int8_t* qA, void* sA, void* fpA, const int32_t* ind, int M, int K, int O,
-                                bool zero, hipStream_t st);
+                                bool zero, hipStream_t st,
+                                void* zero_words = nullptr); // (kSplitkWordsBytes to clear on the way, or null)
 hipError_t launch_quant_with_scale(const void* src, const void* scale, int8_t* dst, int M, int K, hipStream_t st);
 hipError_t launch_extract(void* A, void* fpA, const int32_t* ind, int M, int K, int O, bool zero, hipStream_t st);
 hipError_t launch_rmsnorm_quant(const void* X, const void* gamma, void* out, void* outl, const int32_t* ind, int8_t* q,

@@ -22,8 +22,13 @@ constexpr int QBLOCK = 256;
 template <int TPR, int MAXV, bool ZERO>
 __global__ __launch_bounds__(QBLOCK) void quant_extract_kernel(uint16_t* __restrict__ A, int8_t* __restrict__ qA,
                                                                uint16_t* __restrict__ sA, uint16_t* __restrict__ fpA,
-                                                               const int32_t* __restrict__ ind, int M, int K, int O)
+                                                               const int32_t* __restrict__ ind, int M, int K, int O,
+                                                               unsigned* __restrict__ zero_words)
 {
+    // (enqueue: the hand-over words of the GEMM's K split over workgroups are cleared here, one launch earlier, instead
+    //  of by a memset node of their own -- the plugin workspace is shared with whatever else the engine runs)
+    if (zero_words != nullptr && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < (int)(kSplitkWordsBytes / 4); i += QBLOCK) zero_words[i] = 0u;
     constexpr int RPB = QBLOCK / TPR; // rows per block
     __shared__ int red[QBLOCK / 64];
     extern __shared__ __attribute__((aligned(16))) unsigned char zmask[]; // ZERO only: K bits, 1 = outlier column
@@ -159,8 +164,11 @@ template <bool ZERO>
 __global__ __launch_bounds__(QBLOCK) void quant_extract_long_kernel(uint16_t* __restrict__ A, int8_t* __restrict__ qA,
                                                                     uint16_t* __restrict__ sA,
                                                                     uint16_t* __restrict__ fpA,
-                                                                    const int32_t* __restrict__ ind, int M, int K, int O)
+                                                                    const int32_t* __restrict__ ind, int M, int K, int O,
+                                                                    unsigned* __restrict__ zero_words)
 {
+    if (zero_words != nullptr && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < (int)(kSplitkWordsBytes / 4); i += QBLOCK) zero_words[i] = 0u;
     __shared__ int red[QBLOCK / 64];
     extern __shared__ __attribute__((aligned(16))) unsigned char zmask[];
     const int tid = threadIdx.x;
@@ -259,39 +267,40 @@ hipError_t launch_quant_with_scale(const void* src, const void* scale, int8_t* d
 
 template <int TPR, int MAXV>
 static hipError_t launch_qe(uint16_t* A, int8_t* qA, uint16_t* sA, uint16_t* fpA, const int32_t* ind, int M, int K,
-                            int O, bool zero, hipStream_t st)
+                            int O, bool zero, hipStream_t st, unsigned* zw)
 {
     constexpr int RPB = QBLOCK / TPR;
     dim3 grid((unsigned)((M + RPB - 1) / RPB)), block(QBLOCK);
     if (zero) {
         size_t sm = (size_t)((K + 31) / 32) * 4;
-        hipLaunchKernelGGL((quant_extract_kernel<TPR, MAXV, true>), grid, block, sm, st, A, qA, sA, fpA, ind, M, K, O);
+        hipLaunchKernelGGL((quant_extract_kernel<TPR, MAXV, true>), grid, block, sm, st, A, qA, sA, fpA, ind, M, K, O, zw);
     } else {
-        hipLaunchKernelGGL((quant_extract_kernel<TPR, MAXV, false>), grid, block, 0, st, A, qA, sA, fpA, ind, M, K, O);
+        hipLaunchKernelGGL((quant_extract_kernel<TPR, MAXV, false>), grid, block, 0, st, A, qA, sA, fpA, ind, M, K, O, zw);
     }
     return hipGetLastError();
 }
 
 hipError_t launch_quant_extract(void* A, int8_t* qA, void* sA, void* fpA, const int32_t* ind, int M, int K, int O,
-                                bool zero, hipStream_t st)
+                                bool zero, hipStream_t st, void* zero_words)
 {
     if (M <= 0) return hipSuccess;
+    unsigned* const zw = static_cast<unsigned*>(zero_words);
     uint16_t* a = static_cast<uint16_t*>(A);
     uint16_t* s = static_cast<uint16_t*>(sA);
     uint16_t* f = static_cast<uint16_t*>(fpA);
     const int nvec = K / 8;
-    if (nvec <= 64 * 2) return launch_qe<64, 2>(a, qA, s, f, ind, M, K, O, zero, st);
-    if (nvec <= 64 * 4) return launch_qe<64, 4>(a, qA, s, f, ind, M, K, O, zero, st);
-    if (nvec <= 64 * 8) return launch_qe<64, 8>(a, qA, s, f, ind, M, K, O, zero, st);
-    if (nvec <= 64 * 16) return launch_qe<64, 16>(a, qA, s, f, ind, M, K, O, zero, st);
-    if (nvec <= 256 * 8) return launch_qe<256, 8>(a, qA, s, f, ind, M, K, O, zero, st);
-    if (nvec <= 256 * 16) return launch_qe<256, 16>(a, qA, s, f, ind, M, K, O, zero, st);
+    if (nvec <= 64 * 2) return launch_qe<64, 2>(a, qA, s, f, ind, M, K, O, zero, st, zw);
+    if (nvec <= 64 * 4) return launch_qe<64, 4>(a, qA, s, f, ind, M, K, O, zero, st, zw);
+    if (nvec <= 64 * 8) return launch_qe<64, 8>(a, qA, s, f, ind, M, K, O, zero, st, zw);
+    if (nvec <= 64 * 16) return launch_qe<64, 16>(a, qA, s, f, ind, M, K, O, zero, st, zw);
+    if (nvec <= 256 * 8) return launch_qe<256, 8>(a, qA, s, f, ind, M, K, O, zero, st, zw);
+    if (nvec <= 256 * 16) return launch_qe<256, 16>(a, qA, s, f, ind, M, K, O, zero, st, zw);
     dim3 grid((unsigned)M), block(QBLOCK);
     if (zero) {
         size_t sm = (size_t)((K + 31) / 32) * 4;
-        hipLaunchKernelGGL((quant_extract_long_kernel<true>), grid, block, sm, st, a, qA, s, f, ind, M, K, O);
+        hipLaunchKernelGGL((quant_extract_long_kernel<true>), grid, block, sm, st, a, qA, s, f, ind, M, K, O, zw);
     } else {
-        hipLaunchKernelGGL((quant_extract_long_kernel<false>), grid, block, 0, st, a, qA, s, f, ind, M, K, O);
+        hipLaunchKernelGGL((quant_extract_long_kernel<false>), grid, block, 0, st, a, qA, s, f, ind, M, K, O, zw);
     }
     return hipGetLastError();
 }

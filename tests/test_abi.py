@@ -98,7 +98,9 @@ def test_workspace_sizes_are_size_t_clean(lib):
     need = M * K + 2 * M + 2 * 128 * M
     splitk = 256 * 7 * 32768 + 16384              # K-split exchange scratch: one 224-KiB slot per CU + the hand-over words
     assert need + splitk <= ws <= need + splitk + 5 * 128 + 128
-    assert lib.mixq_workspace_size(h, 128, N, K) <= 128 * K + 2 * 128 + 2 * 128 * 128 + 4 * 128 + 128   # small M: none
+    xsplit = 16384 + 128 * 4 * 64 * 64 * 4        # below 256 rows: the small-tile form's scratch (128 tiles x 4 parts)
+    assert lib.mixq_workspace_size(h, 128, N, K) <= 128 * K + 2 * 128 + 2 * 128 * 128 + xsplit + 5 * 128 + 128
+    assert lib.mixq_workspace_size(h, 4, N, K) <= 4 * K + 8 + 8 * 128 + 4 * 128 + 128     # decode: none
     assert lib.mixq_gemm_scratch_size(1024, 4096, 11008) == 16384 + 64 * 3 * 262144   # 4 workgroups per tile
     assert lib.mixq_gemm_scratch_size(2048, 4096, 4096) == 16384 + 128 * 1 * 262144  # 2 workgroups per tile
     assert lib.mixq_gemm_scratch_size(8192, 12288, 4096) == 0 and lib.mixq_gemm_scratch_size(64, 4096, 4096) == 0
@@ -185,7 +187,8 @@ def test_scratch_of_any_shape_fits_the_plugin_workspace(lib):
     rng = np.random.default_rng(7)
     shapes = [(int(m), int(n) * 16, int(k) * 16) for m, n, k in
               zip(rng.integers(1, 20000, 400), rng.integers(1, 2000, 400), rng.integers(1, 2000, 400))]
-    shapes += [(1024, 4096, 11008), (2048, 4096, 11008), (1536, 11008, 4096), (4096, 1024, 28672), (256, 65536, 4096),
+    shapes += [(32, 4096, 11008), (24, 1024, 28672), (64, 4096, 11008), (128, 4096, 16384), (200, 2048, 8192),
+               (1024, 4096, 11008), (2048, 4096, 11008), (1536, 11008, 4096), (4096, 1024, 28672), (256, 65536, 4096),
                (255, 65536, 4096), (200, 80000, 4096), (65536, 12288, 4096)]
     used = 0
     for M, N, K in shapes:
@@ -193,8 +196,8 @@ def test_scratch_of_any_shape_fits_the_plugin_workspace(lib):
         al = lambda x: (x + 127) & ~127
         carved = 128 + al(M * K) + al(2 * M) + al(2 * 128 * M)
         ws = lib.mixq_workspace_size(h, M, N, K)
-        if M < 256:
-            continue     # enqueue does not use the split form below 256 rows (nothing is reserved there)
+        if M <= 4:
+            continue     # decode path: no quantised operand, no scratch
         assert carved + need <= ws, (M, N, K, need, ws)
         used += need > 0
     assert used > 20

@@ -29,12 +29,15 @@ def main():
     hist = {}
     while done < a.shapes and tried < 100 * a.shapes:
         tried += 1
-        M = int(torch.randint(129, 6000, (1,), generator=cg))
+        small = int(torch.randint(0, 2, (1,), generator=cg)) == 1   # half of the shapes: decode batches / short chunks
+        M = int(torch.randint(5, 300, (1,), generator=cg)) if small else int(torch.randint(129, 6000, (1,), generator=cg))
         N = int(torch.randint(1, 1200, (1,), generator=cg)) * 16
         K = int(torch.randint(8, 1800, (1,), generator=cg)) * 16
         O = [128, 128, 0, 64][int(torch.randint(0, 4, (1,), generator=cg))]
         mode = [79, 79, 72, 74, 78][int(torch.randint(0, 5, (1,), generator=cg))]
+        xmode = [69, 69, 62, 64][int(torch.randint(0, 4, (1,), generator=cg))]   # the small-tile form's knob
         lib.mixq_debug_set_gemm_variant(mode)
+        lib.mixq_debug_set_gemm_variant(xmode)
         n = lib.mixq_gemm_scratch_size(M, N, K)
         if n == 0 or M * N > (1 << 27) or M * K > (1 << 27) or N * K > (1 << 28):
             continue
@@ -48,6 +51,7 @@ def main():
         lib.mixq_debug_set_gemm_variant(70)
         assert lib.mixq_gemm_mixed(p(qA), p(W), p(sA), p(sW), p(fpA), p(fpW), p(ref), M, N, K, O, st) == 0
         lib.mixq_debug_set_gemm_variant(mode)
+        lib.mixq_debug_set_gemm_variant(xmode)
         ok = True
         for _ in range(4):
             o2 = torch.empty((M, N), dtype=torch.float16, device=dev)
@@ -57,7 +61,7 @@ def main():
             if ok and not torch.equal(o2, ref):
                 ok, out = False, o2
         tiles = ((M + 255) // 256) * ((N + 255) // 256)
-        hist[mode] = hist.get(mode, 0) + 1
+        hist[(mode, xmode)] = hist.get((mode, xmode), 0) + 1
         if not ok:
             bad += 1
             # which side is wrong?  recompute a few differing outputs exactly
@@ -66,13 +70,14 @@ def main():
             acc = int((qA[m].to(torch.int64) * W[nn].to(torch.int64)).sum())
             side = float((fpA[m].float() * fpW[nn].float()).sum()) if O else 0.0
             want = acc * float(sW[nn]) * float(sA[m]) + side
-            print(f"MISMATCH M={M} N={N} K={K} (K%128={K % 128}) O={O} mode={mode} tiles={tiles} ndiff={len(diff)} at ({m},{nn}): "
+            print(f"MISMATCH M={M} N={N} K={K} (K%128={K % 128}) O={O} mode={mode}/{xmode} tiles={tiles} ndiff={len(diff)} at ({m},{nn}): "
                   f"split={float(out[m, nn]):.4f} plain={float(ref[m, nn]):.4f} exact={want:.4f} "
                   f"rows {int(diff[:,0].min())}..{int(diff[:,0].max())} cols {int(diff[:,1].min())}..{int(diff[:,1].max())}", flush=True)
         elif os.environ.get("SOAK_VERBOSE"):
             print(f"ok M={M} N={N} K={K} (K%128={K % 128}) O={O} mode={mode} tiles={tiles}", flush=True)
         done += 1
     lib.mixq_debug_set_gemm_variant(79)
+    lib.mixq_debug_set_gemm_variant(69)
     print(f"{done} shapes x 4 launches (modes {hist}), {bad} mismatches; hand-over words left zero: "
           f"{int(scr[:16384].to(torch.int32).sum()) == 0}")
     sys.exit(1 if bad else 0)
