@@ -40,15 +40,16 @@ constexpr int GROUP_M = 4;
 // PREO: the outlier operands of the epilogue get their own LDS region behind the stages and are copied there at kernel
 // start, under the main loop, instead of after it (used by the one-workgroup-per-CU split-K configurations, where the
 // extra (BM + BN) x 256 bytes of LDS cost no occupancy and the kernel is a chain of latencies).
-// XS > 1: K is split over XS WORKGROUPS per tile as well (consecutive blocks), for problems with so few tiles that most
+// XSP: K is split over XS = p.xsplit WORKGROUPS per tile as well (consecutive blocks), for problems with so few tiles that most
 // CUs would otherwise watch a few of them stream K.  Every workgroup parks its partial tile (BM x BN int32: 8-16 KiB)
 // in p.splitk_ws with write-through stores and counts itself in; the one that arrives LAST adds the others' parked
 // sums and runs the epilogue, the others are gone by then -- nobody ever waits, so there is nothing to dead-lock.
 // Hand-over accesses are relaxed agent-scope atomics as in gemm_pp_kernels.hip (no fences); the counter of a tile lives
 // in the first kSplitkWordsBytes of the scratch and is left zero.  Same int32 sums, same bits.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int NSTAGE = 2, int KG = 1, bool PREO = false, int XS = 1>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int NSTAGE = 2, int KG = 1, bool PREO = false, bool XSP = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N* KG * 64) void gemm_w8a8o16_kernel(const GemmParams p)
 {
+    const int XS = XSP ? p.xsplit : 1; // workgroups per tile (2 / 4 / 8 / 16: index arithmetic only, so a run-time value)
     constexpr int NWAVES = WAVES_M * WAVES_N;
     constexpr int T = NWAVES * 64;      // threads of one K group
     constexpr int TT = T * KG;          // threads of the workgroup
@@ -79,9 +80,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KG * 64) void gemm_w8a8o16_kernel
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     const int nwg = tiles_m * tiles_n;
     int t_lin;
-    const int xrank = XS > 1 ? (int)blockIdx.x % XS : 0; // which part of K this workgroup multiplies
+    const int xrank = XSP ? (int)blockIdx.x % XS : 0; // which part of K this workgroup multiplies
     {
-        const int bid = XS > 1 ? (int)blockIdx.x / XS : (int)blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        const int bid = XSP ? (int)blockIdx.x / XS : (int)blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         t_lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3); // bijective for any nwg
     }
     int tile_m, tile_n;
@@ -121,8 +122,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KG * 64) void gemm_w8a8o16_kernel
     static_assert((T / 8) % 16 == 0, "row swizzle term must be i-invariant");
 
     const int nk_all = (p.K + KSLICE - 1) / KSLICE;
-    const int kbeg = XS > 1 ? nk_all * xrank / XS : 0;              // this workgroup's slices: [kbeg, kbeg + nk)
-    const int nk = (XS > 1 ? nk_all * (xrank + 1) / XS : nk_all) - kbeg;
+    const int kbeg = XSP ? nk_all * xrank / XS : 0;                 // this workgroup's slices: [kbeg, kbeg + nk)
+    const int nk = (XSP ? nk_all * (xrank + 1) / XS : nk_all) - kbeg;
     const bool ktail = (p.K % KSLICE) != 0;
 
     // fpW / fpA tiles -> LDS (256-B rows, slot = chunk ^ (row & 15)); all threads of the workgroup take part
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KG * 64) void gemm_w8a8o16_kernel
     }
 
     // ---- K split over workgroups: park, count in, and only the last one to arrive goes on ----------------------------
-    if (XS > 1) {
+    if (XSP) {
         // (the main-loop stages and the partial accumulators in LDS are dead by now: their first word carries the count;
         //  a static __shared__ variable would push the 64x64 form past the 160 KiB it already fills)
         volatile unsigned& arrived_s = *reinterpret_cast<volatile unsigned*>(smem_all);
@@ -288,7 +289,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KG * 64) void gemm_w8a8o16_kernel
         if (arrived_s != (unsigned)(XS - 1)) return; // not the last one: done (the whole workgroup leaves)
         if (tid_all == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // re-armed
         if (group == 0) {
-#pragma unroll
             for (int o = 1; o < XS; ++o) { // the other XS - 1 parts, in a rotation that depends on nothing but the rank
                 const int* const theirs = slots + (size_t)((xrank + o) % XS) * TILE_DW + tid;
 #pragma unroll
@@ -390,13 +390,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KG * 64) void gemm_w8a8o16_kernel
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int NSTAGE = 2, int KG = 1, bool PREO = false, int XS = 1>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int NSTAGE = 2, int KG = 1, bool PREO = false, bool XSP = false>
 static hipError_t launch_cfg(const GemmParams& p, hipStream_t st)
 {
     constexpr int T = WAVES_M * WAVES_N * KG * 64;
     constexpr size_t lds = (size_t)KG * NSTAGE * (size_t)(BM + BN) * KSLICE + (PREO ? (size_t)(BM + BN) * OSLICE : 0);
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = gemm_w8a8o16_kernel<BM, BN, WAVES_M, WAVES_N, EPI, NSTAGE, KG, PREO, XS>;
+    auto kern = gemm_w8a8o16_kernel<BM, BN, WAVES_M, WAVES_N, EPI, NSTAGE, KG, PREO, XSP>;
     static bool attr_done = false; // benign race: idempotent
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -405,7 +405,7 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t st)
         attr_done = true;
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * XS)), dim3(T), lds, st, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * (XSP ? p.xsplit : 1))), dim3(T), lds, st, p);
     return hipGetLastError();
 }
 
@@ -435,11 +435,14 @@ static XSplitPlan xsplit_plan(int M, int N, int K)
     const int64_t tiles = t32 ? wg32 : wg64;
     if (tiles > 128) return none;
     const int nk = (K + KSLICE - 1) / KSLICE;
-    int xs = tiles <= 64 ? 4 : 2;
-    if (force == 2) xs = 2;
-    if (force == 4 && xs != 4) return none;
-    if (nk < 8 * xs) return none;               // every one of the 4 x XS K parts keeps at least two slices
-    if (force < 0 && nk < 64) return none;      // automatic: K >= 8192 (measured: at K = 4096 the exchange eats the gain)
+    if (force < 0 && nk < 64) return none; // automatic: K >= 8192 (measured: at K = 4096 the exchange eats the gain)
+    int xs = 16; // as many as leave at most one workgroup per CU and 16 slices per workgroup (4 per K group): measured
+    while (xs > 1 && ((int64_t)xs * tiles > 256 || nk < 16 * xs)) xs >>= 1;
+    if (force > 0) {
+        if ((int64_t)force * tiles > 256 || nk < 8 * force) return none;
+        xs = force;
+    }
+    if (xs < 2) return none;
     return XSplitPlan{xs, t32, (int)tiles};
 }
 
@@ -452,7 +455,7 @@ size_t gemm_xsplit_workspace_size(int M, int N, int K)
     return kSplitkWordsBytes + (size_t)pl.tiles * pl.xs * (size_t)((pl.t32 ? 32 : 64) * 64 * 4);
 }
 
-size_t gemm_xsplit_workspace_bound() { return kSplitkWordsBytes + (size_t)128 * 4 * 64 * 64 * 4; }
+size_t gemm_xsplit_workspace_bound() { return kSplitkWordsBytes + (size_t)256 * 64 * 64 * 4; } // <= 256 workgroups
 
 static std::atomic<int> g_force_cfg{-1}; // measurement knob (variant 10 + i): force tile configuration i
 
@@ -494,10 +497,12 @@ static hipError_t launch_epi(const GemmParams& p, hipStream_t st)
     const int64_t wg32 = (int64_t)((p.M + 31) / 32) * n64, wg64 = (int64_t)((p.M + 63) / 64) * n64;
     if (EPI != EPI_INT32 && p.splitk_ws != nullptr) { // few tiles: K split over 2 / 4 workgroups per tile as well
         const XSplitPlan pl = xsplit_plan(p.M, p.N, p.K);
-        if (pl.xs == 4) return pl.t32 ? launch_cfg<32, 64, 1, 2, EPI, 2, 4, true, 4>(p, st)
-                                      : launch_cfg<64, 64, 2, 2, EPI, 2, 4, true, 4>(p, st);
-        if (pl.xs == 2) return pl.t32 ? launch_cfg<32, 64, 1, 2, EPI, 2, 4, true, 2>(p, st)
-                                      : launch_cfg<64, 64, 2, 2, EPI, 2, 4, true, 2>(p, st);
+        if (pl.xs > 1) {
+            GemmParams q = p;
+            q.xsplit = pl.xs;
+            return pl.t32 ? launch_cfg<32, 64, 1, 2, EPI, 2, 4, true, true>(q, st)
+                          : launch_cfg<64, 64, 2, 2, EPI, 2, 4, true, true>(q, st);
+        }
     }
     if (wg32 <= 256) return launch_cfg<32, 64, 1, 2, EPI, 2, 4, true>(p, st);
     if (wg64 <= 256) return launch_cfg<64, 64, 2, 2, EPI, 2, 4, true>(p, st);
@@ -519,8 +524,8 @@ void set_gemm_variant(int v)
         if (v == 70 || v == 79) set_xsplit_force(v == 79 ? -1 : 0);
         return;
     }
-    if (v >= 60 && v <= 69) { // the same for the small-tile kernels: 60 off, 62 / 64 forced factor, 69 automatic
-        set_xsplit_force(v == 69 ? -1 : v - 60);
+    if (v >= 60 && v <= 69) { // the same for the small-tile kernels: 60 off, 62 / 64 / 68 / 66 forced 2 / 4 / 8 / 16, 69 auto
+        set_xsplit_force(v == 69 ? -1 : v == 66 ? 16 : v - 60);
         return;
     }
     if (v >= 40 && v < 100) { // 40 + kw: skinny kernel with kw K-split waves (measurements)

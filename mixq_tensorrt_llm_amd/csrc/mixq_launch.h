@@ -21,6 +21,7 @@ struct GemmParams {
     const void* zeros;    // >= 16 B of device zeros (K / O tails)
     int M, N, K, O;
     void* dbg;            // measurement only: 8 x uint64 s_memtime stamps per block (ping-pong kernel), else null
+    int xsplit;           // (set by launch_epi) workgroups per tile of the small-tile kernels' K split, else 0
     int splitk_solo;      // (set by launch_gemm_pp_splitk) leading tiles that are not split
     void* splitk_ws;      // device scratch of gemm_splitk_workspace_size bytes whose arrival words are zero, or null: lets
                           // launch_gemm split K over 2 / 4 workgroups per 256x256 tile when the tiles alone cover at
@@ -42,10 +43,10 @@ void gemm_splitk_words(int M, int N, int K, size_t* offset, size_t* bytes); // t
 hipError_t launch_gemm_pp_splitk(const GemmParams& p, int epi, hipStream_t st);
 void set_splitk_force(int v); // -1 automatic (default), 0 off, 2 / 4: that factor wherever the shape allows it
 // the same idea for the small-tile kernels with in-workgroup split (gemm_kernels.hip, XS): few tiles, long K
-int gemm_xsplit_factor(int M, int N, int K);              // 0 / 2 / 4
+int gemm_xsplit_factor(int M, int N, int K);              // 0 / 2 / 4 / 8 / 16
 size_t gemm_xsplit_workspace_size(int M, int N, int K);
 size_t gemm_xsplit_workspace_bound();
-void set_xsplit_force(int v); // -1 automatic (default), 0 off, 2 / 4 forced
+void set_xsplit_force(int v); // -1 automatic (default), 0 off, 2 / 4 / 8 / 16 forced
 bool gemm_skinny_supported(const GemmParams& p);
 hipError_t launch_gemm_skinny(const GemmParams& p, int epi, hipStream_t st); // M <= 64: GEMV-like, HBM-bound on W
 bool gemm_pp2_supported(const GemmParams& p, int epi);

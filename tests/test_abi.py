@@ -98,7 +98,7 @@ def test_workspace_sizes_are_size_t_clean(lib):
     need = M * K + 2 * M + 2 * 128 * M
     splitk = 256 * 7 * 32768 + 16384              # K-split exchange scratch: one 224-KiB slot per CU + the hand-over words
     assert need + splitk <= ws <= need + splitk + 5 * 128 + 128
-    xsplit = 16384 + 128 * 4 * 64 * 64 * 4        # below 256 rows: the small-tile form's scratch (128 tiles x 4 parts)
+    xsplit = 16384 + 256 * 64 * 64 * 4            # below 256 rows: the small-tile form's scratch (256 workgroups x 16 KiB)
     assert lib.mixq_workspace_size(h, 128, N, K) <= 128 * K + 2 * 128 + 2 * 128 * 128 + xsplit + 5 * 128 + 128
     assert lib.mixq_workspace_size(h, 4, N, K) <= 4 * K + 8 + 8 * 128 + 4 * 128 + 128     # decode: none
     assert lib.mixq_gemm_scratch_size(1024, 4096, 11008) == 16384 + 64 * 3 * 262144   # 4 workgroups per tile

@@ -30,10 +30,12 @@ SHAPES = [(24, 1040, 4240),     # 32x64 tiles (17), partial last K slice, ragged
           (7, 784, 4608)]       # below the skinny limit: only when forced
 
 
-@pytest.mark.parametrize("factor", [2, 4])
+@pytest.mark.parametrize("factor", [2, 4, 8, 6])     # 6 = knob value of 16 ways
 @pytest.mark.parametrize("M,N,K", SHAPES)
 @pytest.mark.parametrize("O", [128, 0, 40])
 def test_small_tile_split_gives_the_bits_of_the_one_workgroup_form(lib, factor, M, N, K, O):
+    if factor in (8, 6):
+        K = 4 * K        # 8 / 16 ways need 64 / 128 K slices
     qA, W, sA, sW, fpA, fpW = operands(M, N, K, O, seed=M + N + K + O)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     fa, fw = (p(fpA), p(fpW)) if O else (None, None)
@@ -75,7 +77,7 @@ def test_small_tile_split_other_epilogues(lib, epi):
         return out
 
     ref = run(None)
-    n = lib.mixq_gemm_scratch_size(M, N, K)     # automatic choice: 34 tiles of 32x64, 65 slices -> 4 ways
+    n = lib.mixq_gemm_scratch_size(M, N, K)     # automatic choice: 34 tiles of 32x64, 65 slices -> 4 ways (16 slices each)
     assert n == 16384 + 34 * 4 * 32 * 64 * 4
     scr = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
     for _ in range(3):

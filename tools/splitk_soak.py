@@ -35,7 +35,7 @@ def main():
         K = int(torch.randint(8, 1800, (1,), generator=cg)) * 16
         O = [128, 128, 0, 64][int(torch.randint(0, 4, (1,), generator=cg))]
         mode = [79, 79, 72, 74, 78][int(torch.randint(0, 5, (1,), generator=cg))]
-        xmode = [69, 69, 62, 64][int(torch.randint(0, 4, (1,), generator=cg))]   # the small-tile form's knob
+        xmode = [69, 69, 62, 64, 68, 66][int(torch.randint(0, 6, (1,), generator=cg))]   # the small-tile form's knob
         lib.mixq_debug_set_gemm_variant(mode)
         lib.mixq_debug_set_gemm_variant(xmode)
         n = lib.mixq_gemm_scratch_size(M, N, K)
