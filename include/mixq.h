@@ -169,7 +169,11 @@ MIXQ_API int mixq_gemm_mixed(const int8_t* qA, const int8_t* W, const void* sA, 
  * first 16 KiB hold the hand-over words of every shape; each launch leaves them zero again, so one scratch serves
  * launches of any shapes in stream order) and must not be shared by launches that can run concurrently (one scratch
  * per stream).  A null / too small scratch selects the one-workgroup-per-tile kernels (= mixq_gemm_mixed).
- * mixq_enqueue carves this scratch from the plugin workspace itself (and zeroes the arrival words on every call).
+ * Decode batches / short chunks on narrow outputs with K >= 8192 use the same scratch for the small-tile kernels' K split
+ * (2..16 workgroups per 32x64 / 64x64 tile, "last block finishes": csrc/gemm_kernels.hip).
+ * mixq_enqueue carves this scratch from the plugin workspace itself; its quantiser clears the hand-over words on every
+ * call (no extra launch).  mixq_debug_set_gemm_variant(60 / 62 / 64 / 68 / 66 / 69) = small-tile split off / 2 / 4 / 8 /
+ * 16 ways / automatic.
  * mixq_debug_set_gemm_variant(70) switches the split form off, 72 / 74 / 78 force a factor, 79 = automatic (default). */
 MIXQ_API size_t mixq_gemm_scratch_size(int M, int N, int K);
 MIXQ_API int mixq_gemm_mixed_scratch(const int8_t* qA, const int8_t* W, const void* sA, const void* sW, const void* fpA,
