@@ -113,11 +113,11 @@ def small_m_points(lib, TensorDesc, dev, gen, st_ptr, iters=300):
 
 
 def mid_m_points(lib, TensorDesc, dev, gen, st_ptr, iters=100):
-    """Informational (never part of `value`): a short prefill -- the same three linears on ONE chunk of 1024 / 2048 tokens,
-    where the 256x256 tiles no longer fill the chip and the library splits K over 2 / 4 workgroups per tile
-    (DESIGN.md 2.3).  Whole operator (quantiser + GEMM) through mixq_enqueue."""
+    """Informational (never part of `value`): decode batches (32 / 128 rows) and a short prefill (1024 / 2048 tokens) of
+    the same three linears, where the tiles no longer fill the chip and the library splits K over several workgroups per
+    tile.  Whole operator (quantiser + GEMM) through mixq_enqueue."""
     out = {}
-    for M in (1024, 2048):
+    for M in (32, 128, 1024, 2048):
         per = {}
         total = 0.0
         for name, N, K in LLAMA2_7B["linears"]:
@@ -147,7 +147,7 @@ def mid_m_points(lib, TensorDesc, dev, gen, st_ptr, iters=100):
             per[name] = {"us_per_call": dt * 1e6, "TOPS": 2.0 * M * N * (K + NUM_OUTLIERS) / dt / 1e12,
                          "k_split": lib.mixq_gemm_scratch_size(M, N, K) > 0}
             del t, A, o, ws
-        out[f"prefill_{M}_tokens"] = {"linears": per, "tokens_per_s": M / (total * LLAMA2_7B["layers"])}
+        out[f"chunk_of_{M}_tokens"] = {"linears": per, "tokens_per_s": M / (total * LLAMA2_7B["layers"])}
     return out
 
 
