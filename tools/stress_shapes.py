@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised shape sweep (GPU): for many (M, N, K, O) the default kernel selection must give int32 sums equal to the
 integer matrix product and fused outputs bit-identical to a fixed reference configuration (variant 13 = 64x128 tiles of
-the two-barrier kernel).  Not part of pytest (minutes, not seconds): python tools/stress_shapes.py [count] [seed]"""
+the two-barrier kernel, one workgroup per tile); the default selection includes the K splits over workgroups (the mixlib
+wrappers bring their per-stream scratch).  Not part of pytest (minutes, not seconds): python tools/stress_shapes.py [count] [seed]"""
 import os
 import sys
 import time
@@ -22,7 +23,9 @@ t0 = time.time()
 for it in range(count):
     M = int(rng.choice([rng.integers(5, 70), rng.integers(60, 300), rng.integers(250, 1100), rng.integers(1000, 4200)]))
     N = int(rng.integers(1, 300)) * 16
-    K = int(rng.integers(1, 260)) * 16
+    K = int(rng.integers(1, 260)) * 16 if rng.random() < 0.6 else int(rng.integers(500, 1400)) * 16   # long K: the K splits
+    if M * K > (1 << 26):
+        M = max(5, (1 << 26) // K)
     O = int(rng.choice([0, 8, 64, 128]))
     if O > K:
         O = 0
