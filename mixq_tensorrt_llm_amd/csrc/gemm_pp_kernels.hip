@@ -729,12 +729,6 @@ size_t gemm_splitk_workspace_size(int M, int N, int K)
     return kSplitkWordsBytes + tiles * pl.s * splitk_slot_bytes(pl.s);
 }
 
-void gemm_splitk_words(int M, int N, int K, size_t* offset, size_t* bytes)
-{
-    *offset = 0;
-    *bytes = gemm_splitk_workspace_size(M, N, K) ? kSplitkWordsBytes : 0;
-}
-
 size_t gemm_splitk_workspace_bound() { return kSplitkWordsBytes + (size_t)num_cus() * splitk_slot_bytes(8); }
 
 template <int EPI, bool HAS_O, bool HAS_Y, int SPLITK>

@@ -39,7 +39,6 @@ SplitPlan gemm_splitk_plan(int M, int N, int K);
 int gemm_splitk_factor(int M, int N, int K);              // = plan.s
 size_t gemm_splitk_workspace_size(int M, int N, int K);   // 0: the shape does not use the split form (or it is off)
 size_t gemm_splitk_workspace_bound();                     // max of the above over all shapes (for workspace sizing)
-void gemm_splitk_words(int M, int N, int K, size_t* offset, size_t* bytes); // the arrival words inside that scratch
 hipError_t launch_gemm_pp_splitk(const GemmParams& p, int epi, hipStream_t st);
 void set_splitk_force(int v); // -1 automatic (default), 0 off, 2 / 4: that factor wherever the shape allows it
 // the same idea for the small-tile kernels with in-workgroup split (gemm_kernels.hip, XS): few tiles, long K
