@@ -83,13 +83,19 @@ __device__ __forceinline__ void glds16_sbase(const char* sbase, unsigned voff, u
 // ABL = 0 is the product kernel.
 // SPLITK = 2 / 4 / 8: K split over S workgroups per output tile, for mid-size problems whose tiles alone cover at most
 // 1/S of the CUs.  The S workgroups of a tile are S consecutive blocks (dispatched together, resident together); each
-//   1. multiplies its quarter / half of the K slices into the usual 256x256 int32 accumulators, with the 32-row m tiles
-//      of its wave tile PERMUTED (accumulator tile jj holds m tile jj ^ (r * PJ), r = rank in the group, PJ = 4 / S:
-//      a change of the staging offsets only), so that the share it will finish always sits in acc[.][0 .. PJ-1];
+//   1. multiplies its 1/S of the K slices into the usual 256x256 int32 accumulators, with the 32-row m tiles of its
+//      wave tile PERMUTED (accumulator tile jj holds m tile jj ^ (r * PJ), r = rank in the group, PJ = 4 / S; with
+//      S = 8 the two 32-column n tiles are permuted the same way by rank bit 2: a change of the staging offsets
+//      only), so that the share it will finish always sits in acc[0 .. NI-1][0 .. PJ-1];
 //   2. parks the other S-1 shares in p.splitk_ws (its own slot), waits for the write-through acknowledgements,
 //      publishes its arrival word, and stages its outlier operands while the others do the same;
-//   3. waits for the other arrival words, adds the S-1 foreign partial sums of its own share (64 / 96 loads per lane,
-//      all in flight together, landing in the registers step 2 freed) and runs the usual epilogue on that share.
+//   3. waits for the other arrival words, adds the S-1 foreign partial sums of its own share (64 / 96 / 112 loads per
+//      lane, all in flight together, landing in the registers step 2 freed) and runs the usual epilogue on that share
+//      (S = 8: one 32x32 tile per wave, stored with 8-byte stores straight from the accumulator layout).
+// With more tiles than CUs, the first p.splitk_solo tiles (whole waves) are computed by one workgroup each inside the
+// same launch ("solo" blocks: full K range, no exchange) and only the tiles of the last, partial wave are split.
+// The hand-over words of every shape live in the first kSplitkWordsBytes of the scratch, the slots behind them, so one
+// scratch per stream serves launches of any shapes.
 // Same int32 sums (integer addition commutes), same epilogue, same bits as the one-workgroup form.
 // Hand-over accesses are relaxed AGENT-scope atomics: `global_store sc1` writes through to memory and
 // `global_load sc1` is served coherently, per access, for any pair of XCDs -- no bulk L2 write-back / invalidate (a
