@@ -46,7 +46,7 @@ SHAPES = [(300, 528, 2064),     # ragged M and N, partial last K slice, 2 x 3 ti
 
 @pytest.mark.parametrize("factor", [2, 4, 8])
 @pytest.mark.parametrize("M,N,K", SHAPES)
-@pytest.mark.parametrize("O", [128, 0, 40])
+@pytest.mark.parametrize("O", [128, 0, 40, 256])   # 256: side GEMM first, then the addend form (C = D = Out)
 def test_split_form_gives_the_bits_of_the_one_workgroup_form(lib, factor, M, N, K, O):
     if factor == 8:
         K = 2 * K + 16          # 8 ways need >= 32 K slices

@@ -32,7 +32,7 @@ SHAPES = [(24, 1040, 4240),     # 32x64 tiles (17), partial last K slice, ragged
 
 @pytest.mark.parametrize("factor", [2, 4, 8, 6])     # 6 = knob value of 16 ways
 @pytest.mark.parametrize("M,N,K", SHAPES)
-@pytest.mark.parametrize("O", [128, 0, 40])
+@pytest.mark.parametrize("O", [128, 0, 40, 256])   # 256: side GEMM first, then the addend form (C = D = Out)
 def test_small_tile_split_gives_the_bits_of_the_one_workgroup_form(lib, factor, M, N, K, O):
     if factor in (8, 6):
         K = 4 * K        # 8 / 16 ways need 64 / 128 K slices
