@@ -410,7 +410,8 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t st)
 }
 
 // ---- K split over workgroups for the two small-tile forms with in-workgroup split (see the kernel header) ------------
-static std::atomic<int> g_xsplit_force{-1}; // -1 automatic, 0 off, 2 / 4 forced where the shape allows it
+static std::atomic<int> g_xsplit_force{-1}; // -1 automatic, 0 off, 2 / 4 / 8 / 16 forced where the shape allows it
+static std::atomic<int> g_xsplit_prefer64{1}; // on a tie take the 64x64 tiling (measured: equal or up to 26 % faster); knob 61 / 63
 void set_xsplit_force(int v) { g_xsplit_force.store(v); }
 
 // 0 = not used.  Applies to the problems launch_epi gives to the 32x64 / 64x64 tiles with 4 K groups (at most 256 tiles):
@@ -431,17 +432,23 @@ static XSplitPlan xsplit_plan(int M, int N, int K)
     if (force < 0 && M <= 16 && K < 16384) return none; // M <= 16: the skinny kernel unless K is very long (measured)
     const int64_t n64 = (N + 63) / 64;
     const int64_t wg32 = (int64_t)((M + 31) / 32) * n64, wg64 = (int64_t)((M + 63) / 64) * n64;
-    const bool t32 = wg32 <= 128;
-    const int64_t tiles = t32 ? wg32 : wg64;
-    if (tiles > 128) return none;
     const int nk = (K + KSLICE - 1) / KSLICE;
     if (force < 0 && nk < 64) return none; // automatic: K >= 8192 (measured: at K = 4096 the exchange eats the gain)
-    int xs = 16; // as many as leave at most one workgroup per CU and 16 slices per workgroup (4 per K group): measured
-    while (xs > 1 && ((int64_t)xs * tiles > 256 || nk < 16 * xs)) xs >>= 1;
-    if (force > 0) {
-        if ((int64_t)force * tiles > 256 || nk < 8 * force) return none;
-        xs = force;
-    }
+    // per tiling: as many workgroups per tile as leave at most one workgroup per CU and 16 slices per workgroup (4 per K
+    // group; forced factors: 8 slices); the tiling that puts more workgroups on the chip wins, ties go to `prefer64`
+    auto factor = [&](int64_t tiles) {
+        if (tiles > 128) return 0;
+        if (force > 0) return ((int64_t)force * tiles <= 256 && nk >= 8 * force) ? force : 0;
+        int xs = 16;
+        while (xs > 1 && ((int64_t)xs * tiles > 256 || nk < 16 * xs)) xs >>= 1;
+        return xs >= 2 ? xs : 0;
+    };
+    const int xs32 = factor(wg32), xs64 = M > 32 ? factor(wg64) : 0;
+    if (xs32 == 0 && xs64 == 0) return none;
+    const bool prefer64 = g_xsplit_prefer64.load() != 0;
+    const bool t32 = xs64 == 0 || (xs32 != 0 && (wg32 * xs32 > wg64 * xs64 || (wg32 * xs32 == wg64 * xs64 && !prefer64)));
+    const int64_t tiles = t32 ? wg32 : wg64;
+    const int xs = t32 ? xs32 : xs64;
     if (xs < 2) return none;
     return XSplitPlan{xs, t32, (int)tiles};
 }
@@ -525,6 +532,10 @@ void set_gemm_variant(int v)
         return;
     }
     if (v >= 60 && v <= 69) { // the same for the small-tile kernels: 60 off, 62 / 64 / 68 / 66 forced 2 / 4 / 8 / 16, 69 auto
+        if (v == 61 || v == 63) { // (61 / 63: ties between the two tilings go to 64x64 / 32x64)
+            g_xsplit_prefer64.store(v == 61);
+            return;
+        }
         set_xsplit_force(v == 69 ? -1 : v == 66 ? 16 : v - 60);
         return;
     }
