@@ -411,7 +411,7 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t st)
 
 // ---- K split over workgroups for the two small-tile forms with in-workgroup split (see the kernel header) ------------
 static std::atomic<int> g_xsplit_force{-1}; // -1 automatic, 0 off, 2 / 4 / 8 / 16 forced where the shape allows it
-static std::atomic<int> g_xsplit_prefer64{1}; // on a tie take the 64x64 tiling (measured: equal or up to 26 % faster); knob 61 / 63
+static std::atomic<int> g_xsplit_max_bm{64}; // tallest tile the plan may take (knob 63 / 65: 32 / 64 rows)
 void set_xsplit_force(int v) { g_xsplit_force.store(v); }
 
 // 0 = not used.  Applies to the problems launch_epi gives to the 32x64 / 64x64 tiles with 4 K groups (at most 256 tiles):
@@ -421,21 +421,21 @@ void set_xsplit_force(int v) { g_xsplit_force.store(v); }
 // gives at most 128 tiles (so that at least two workgroups per tile fit on the chip at one workgroup per CU).
 struct XSplitPlan {
     int xs;    // 0 = not used
-    bool t32;  // 32x64 tiles (else 64x64)
+    int bm;    // tile rows: 32 or 64 (tile columns: 64)
     int tiles;
 };
 static XSplitPlan xsplit_plan(int M, int N, int K)
 {
-    XSplitPlan none{0, false, 0};
+    XSplitPlan none{0, 0, 0};
     const int force = g_xsplit_force.load();
     if (force == 0 || M <= 4) return none;
     if (force < 0 && M <= 16 && K < 16384) return none; // M <= 16: the skinny kernel unless K is very long (measured)
     const int64_t n64 = (N + 63) / 64;
-    const int64_t wg32 = (int64_t)((M + 31) / 32) * n64, wg64 = (int64_t)((M + 63) / 64) * n64;
     const int nk = (K + KSLICE - 1) / KSLICE;
     if (force < 0 && nk < 64) return none; // automatic: K >= 8192 (measured: at K = 4096 the exchange eats the gain)
-    // per tiling: as many workgroups per tile as leave at most one workgroup per CU and 16 slices per workgroup (4 per K
-    // group; forced factors: 8 slices); the tiling that puts more workgroups on the chip wins, ties go to `prefer64`
+    // per tiling: as many workgroups per tile as leave at most one workgroup per CU and 16 slices per workgroup (forced
+    // factors: 8 slices); the tiling that puts more workgroups on the chip wins, 64x64 on a tie (measured: equal or up to
+    // 26 % faster than 32x64 -- fewer operand bytes per MAC; a 128x64 tiling with 2 K groups was measured too: slower)
     auto factor = [&](int64_t tiles) {
         if (tiles > 128) return 0;
         if (force > 0) return ((int64_t)force * tiles <= 256 && nk >= 8 * force) ? force : 0;
@@ -443,14 +443,15 @@ static XSplitPlan xsplit_plan(int M, int N, int K)
         while (xs > 1 && ((int64_t)xs * tiles > 256 || nk < 16 * xs)) xs >>= 1;
         return xs >= 2 ? xs : 0;
     };
-    const int xs32 = factor(wg32), xs64 = M > 32 ? factor(wg64) : 0;
-    if (xs32 == 0 && xs64 == 0) return none;
-    const bool prefer64 = g_xsplit_prefer64.load() != 0;
-    const bool t32 = xs64 == 0 || (xs32 != 0 && (wg32 * xs32 > wg64 * xs64 || (wg32 * xs32 == wg64 * xs64 && !prefer64)));
-    const int64_t tiles = t32 ? wg32 : wg64;
-    const int xs = t32 ? xs32 : xs64;
-    if (xs < 2) return none;
-    return XSplitPlan{xs, t32, (int)tiles};
+    const int max_bm = g_xsplit_max_bm.load();
+    XSplitPlan best = none;
+    for (int bm = 32; bm <= max_bm; bm *= 2) {
+        if (bm > 32 && M <= bm / 2) break; // a taller tile would only add empty rows
+        const int64_t tiles = (int64_t)((M + bm - 1) / bm) * n64;
+        const int xs = factor(tiles);
+        if (xs != 0 && tiles * xs >= (int64_t)best.tiles * best.xs) best = XSplitPlan{xs, bm, (int)tiles};
+    }
+    return best;
 }
 
 int gemm_xsplit_factor(int M, int N, int K) { return xsplit_plan(M, N, K).xs; }
@@ -459,10 +460,10 @@ size_t gemm_xsplit_workspace_size(int M, int N, int K)
 {
     const XSplitPlan pl = xsplit_plan(M, N, K);
     if (pl.xs == 0) return 0;
-    return kSplitkWordsBytes + (size_t)pl.tiles * pl.xs * (size_t)((pl.t32 ? 32 : 64) * 64 * 4);
+    return kSplitkWordsBytes + (size_t)pl.tiles * pl.xs * (size_t)(pl.bm * 64 * 4);
 }
 
-size_t gemm_xsplit_workspace_bound() { return kSplitkWordsBytes + (size_t)256 * 64 * 64 * 4; } // <= 256 workgroups
+size_t gemm_xsplit_workspace_bound() { return kSplitkWordsBytes + (size_t)256 * 64 * 64 * 4; } // <= 256 workgroups x 16 KiB
 
 static std::atomic<int> g_force_cfg{-1}; // measurement knob (variant 10 + i): force tile configuration i
 
@@ -507,8 +508,8 @@ static hipError_t launch_epi(const GemmParams& p, hipStream_t st)
         if (pl.xs > 1) {
             GemmParams q = p;
             q.xsplit = pl.xs;
-            return pl.t32 ? launch_cfg<32, 64, 1, 2, EPI, 2, 4, true, true>(q, st)
-                          : launch_cfg<64, 64, 2, 2, EPI, 2, 4, true, true>(q, st);
+            return pl.bm == 32 ? launch_cfg<32, 64, 1, 2, EPI, 2, 4, true, true>(q, st)
+                               : launch_cfg<64, 64, 2, 2, EPI, 2, 4, true, true>(q, st);
         }
     }
     if (wg32 <= 256) return launch_cfg<32, 64, 1, 2, EPI, 2, 4, true>(p, st);
@@ -532,8 +533,8 @@ void set_gemm_variant(int v)
         return;
     }
     if (v >= 60 && v <= 69) { // the same for the small-tile kernels: 60 off, 62 / 64 / 68 / 66 forced 2 / 4 / 8 / 16, 69 auto
-        if (v == 61 || v == 63) { // (61 / 63: ties between the two tilings go to 64x64 / 32x64)
-            g_xsplit_prefer64.store(v == 61);
+        if (v == 63 || v == 65) { // (tallest tile of the plan: 32 / 64 rows)
+            g_xsplit_max_bm.store(v == 63 ? 32 : 64);
             return;
         }
         set_xsplit_force(v == 69 ? -1 : v == 66 ? 16 : v - 60);

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--O", type=int, default=128)
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--variant2", type=int, default=None, help="a second knob set after --variant (e.g. 1 then 64)")
+    ap.add_argument("--variant3", type=int, default=None, help="a third knob")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--what", default="both")
     ap.add_argument("--check", action="store_true", help="compare the output with the plain launch bit for bit (20 rounds)")
@@ -31,6 +32,8 @@ def main():
     lib.mixq_debug_set_gemm_variant(a.variant)
     if a.variant2 is not None:
         lib.mixq_debug_set_gemm_variant(a.variant2)
+    if a.variant3 is not None:
+        lib.mixq_debug_set_gemm_variant(a.variant3)
     g = torch.Generator(device=dev).manual_seed(0)
     M, N, K, O = a.M, a.N, a.K, a.O
     A = torch.randn((M, K), device=dev, generator=g).to(torch.float16)
