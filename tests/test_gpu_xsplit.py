@@ -127,3 +127,35 @@ def test_shared_scratch_across_shapes_and_both_split_forms(lib):
         for i, (o, r) in enumerate(zip(outs, refs)):
             assert torch.equal(o, r), (round_, shapes[i])
     assert int(scr[:16384].to(torch.int32).sum()) == 0
+
+
+def test_enqueue_with_small_tile_split_is_capturable_in_a_hip_graph(oracle, lib):
+    """quantiser (clears the hand-over words) + split GEMM: two kernel nodes, replayed on new data in the same buffers."""
+    from mixq_tensorrt_llm_amd import plugin
+    from test_gpu_parity import bits, run_enqueue, to_dev
+    M, N, K = 48, 1024, 8192
+    A, W, act = make_layer(M, N, K, seed=13)
+    pk = oracle.pack_linear_weights(W, act)
+    lib.mixq_debug_set_gemm_variant(69)
+    assert lib.mixq_gemm_scratch_size(M, N, K) > 0
+    layer = plugin.MixQLinear(K, N, device=torch.device("cuda:0")).load(pk)
+    x = to_dev(np.zeros_like(A))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        out = layer(x)
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            out = layer(x)
+    torch.cuda.current_stream().wait_stream(side)
+    for trial in range(3):
+        A2 = np.ascontiguousarray(np.roll(A, trial * 7, axis=0))
+        x.copy_(to_dev(A2))
+        graph.replay()
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().reshape(M, N)
+        lib.mixq_debug_set_gemm_variant(60)
+        eager = run_enqueue(A2, pk)
+        lib.mixq_debug_set_gemm_variant(69)
+        assert np.array_equal(bits(got), bits(eager)), trial
