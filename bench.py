@@ -44,11 +44,16 @@ class Hip:
         self.lib.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
         self.lib.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
         self.lib.hipEventDestroy.argtypes = [ctypes.c_void_p]
+        self.lib.hipEventRecord.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 
     def event(self):
         e = ctypes.c_void_p()
         assert self.lib.hipEventCreate(ctypes.byref(e)) == 0
         return e
+
+    def record(self, ev, stream_ptr):
+        rc = self.lib.hipEventRecord(ev, stream_ptr)
+        assert rc == 0, f"hipEventRecord rc={rc}"
 
     def elapsed_ms(self, a, b):
         ms = ctypes.c_float()
@@ -182,28 +187,84 @@ def cpu_baseline(seconds_target=15.0):
         M = int(min(16384, max(M * 2, M * seconds_target / max(t, 1e-3))))
         M -= M % 16
     tok_s = M / (t * LLAMA2_7B["layers"])
+    # BASELINE configs[0] (mandatory): ONE 4096 x 4096 MixQ linear at bs = 32, the same call the `small_m`
+    # object times on the GPU -- median of a few repetitions, microseconds per call
+    W0 = rng.integers(-127, 128, size=(4096, 4096), dtype=np.int8)
+    ind0 = rng.permutation(4096)[:NUM_OUTLIERS].astype(np.int32)
+    W0[:, ind0] = 0
+    sW0 = (rng.random(4096) * 4e-4 + 4e-4).astype(np.float16)
+    fpW0 = (rng.standard_normal((4096, NUM_OUTLIERS)) * 0.02).astype(np.float16)
+    A0 = rng.standard_normal((32, 4096)).astype(np.float16)
+    reps = []
+    for _ in range(7):
+        t0 = time.perf_counter()
+        oracle.linear_prefill(A0, W0, sW0, fpW0, ind0)
+        reps.append(time.perf_counter() - t0)
+    cfg0_us = sorted(reps)[len(reps) // 2] * 1e6
     return {"value": tok_s, "unit": "tokens/s", "cores": oracle.num_threads(), "kind": "port",
             "sample": f"oracle.linear_prefill on 1 of 32 Llama-2-7B layers (qkv+gate+proj), M={M} tokens, "
-                      f"{t:.1f} s on {oracle.num_threads()} OpenMP threads; scaled x32 layers"}
+                      f"{t:.1f} s on {oracle.num_threads()} OpenMP threads; scaled x32 layers",
+            "config0_bs32_4096x4096": {"us_per_call": cfg0_us, "tokens_per_s": 32 / (cfg0_us * 1e-6),
+                                       "sample": "oracle.linear_prefill, one 4096x4096 MixQ linear, M=32, median of 7"}}
+
+
+class Model:
+    """Resident state of one rank: the packed weights of all 96 MixQ linears (or this rank's row shard of each),
+    rotating activation chunks, output buffers, the plugin workspace, and prepared ctypes argument blocks."""
+
+    def __init__(self, lib, TensorDesc, parallel, dev, gen, chunk, tp, tp_rank, acts=None):
+        self.lib, self.dev, self.chunk, self.tp = lib, dev, chunk, tp
+        self.calls, self.keep, self.outs, self.full = [], [], {}, {}
+        self.acts = acts if acts is not None else {}
+        max_ws = 0
+        for layer in range(LLAMA2_7B["layers"]):
+            for name, N, K in LLAMA2_7B["linears"]:
+                n0, n1 = parallel.shard_bounds(N, tp, tp_rank) if tp > 1 else (0, N)
+                t = synth_layer(N, K, dev, gen, n0, n1)
+                if K not in self.acts:  # 8 rotating chunks per K (>1 GB: never resident in the 256 MiB Infinity Cache)
+                    self.acts[K] = [synth_activation(chunk, K, t["ind_i32"], dev, gen) for _ in range(8)]
+                if (n1 - n0) not in self.outs:
+                    self.outs[n1 - n0] = torch.empty((chunk, n1 - n0), dtype=torch.float16, device=dev)
+                out = self.outs[n1 - n0]
+                ins = [self.acts[K][0], t["weight"], t["weights_scaling_factor"], t["fp_weight"], t["fp_ind"],
+                       t["qweight"], t["weights_scaling_factor"]]
+                in_desc = (TensorDesc * 7)(*[TensorDesc.make(x.shape) for x in ins])
+                out_desc = TensorDesc.make(out.shape)
+                in_ptrs = [(ctypes.c_void_p * 7)(*([a.data_ptr()] + [x.data_ptr() for x in ins[1:]]))
+                           for a in self.acts[K]]
+                out_ptrs = (ctypes.c_void_p * 1)(out.data_ptr())
+                h = lib.mixq_create(chunk, n1 - n0, K)
+                max_ws = max(max_ws, lib.mixq_workspace_size(h, chunk, n1 - n0, K))
+                self.calls.append((ctypes.c_void_p(h), in_desc, out_desc, in_ptrs, out_ptrs, n1 - n0, K, out, N))
+                self.keep.append((t, ins))
+        self.workspace = torch.empty(max_ws, dtype=torch.uint8, device=dev)
+        self.ws_ptr = ctypes.c_void_p(self.workspace.data_ptr())
+
+    def close(self):
+        for c in self.calls:
+            self.lib.mixq_destroy(c[0])
+        self.calls, self.keep = [], []
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30, help="timed steps (SURVEY 8d: >= 30; the median is reported too)")
+    ap.add_argument("--warmup", type=int, default=10, help="untimed warm-up steps (SURVEY 8d: 10)")
     ap.add_argument("--tokens", type=int, default=512 * 2048, help="tokens per step per DP replica")
     ap.add_argument("--chunk", type=int, default=65536,
                     help="M of each operator call.  65536 tokens = 32 sequences: 256 tile rows, so that the 256x256 tiles "
                          "of all three shapes (48 / 43 / 16 tile columns) fill the 256 CUs in whole rounds")
-    ap.add_argument("--tp", type=int, default=1, help="rows-of-W sharding degree (1 = pure DP, no collective)")
+    ap.add_argument("--tp", type=int, default=1,
+                    help="rows-of-W sharding degree of the MAIN measurement (1 = pure DP, no collective).  Whatever this "
+                         "is, a run on N > 1 GPUs also reports the north-star layout (tp = N) in the `tp` object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mid-m", action="store_true",
                     help="add the informational 1024 / 2048-token prefill points (K split over workgroups) to the JSON line")
     ap.add_argument("--order", choices=["layer", "chunk"], default="layer",
                     help="layer: each linear sees all tokens before the next one (batched prefill); chunk: chunked prefill")
-    ap.add_argument("--no-tp-leg", action="store_true", help="skip the informational TP (row-sharded W) leg at N > 1")
-    ap.add_argument("--force-tp-leg", action="store_true", help="run the TP leg even at N = 1 (code-path check)")
+    ap.add_argument("--no-tp-leg", action="store_true", help="skip the tp = N measurement at N > 1")
+    ap.add_argument("--tp-steps", type=int, default=3, help="timed steps of the tp = N measurement")
     ap.add_argument("--variant", type=int, default=0, help="GEMM schedule: 0 auto, 1 two-barrier, 2 ping-pong (A/B runs)")
     args = ap.parse_args()
 
@@ -221,20 +282,24 @@ def main():
     def emit(record):
         os.write(json_fd, (json.dumps(record) + "\n").encode())
     # MIXQ_BENCH_SINGLE_GPU_RANKS=1: control-flow check of the N > 1 path on a ONE-GPU box -- every rank runs on GPU 0 and
-    # the collectives of the harness (barrier, max over ranks) go through gloo; never used for reported numbers.
+    # the collectives (harness barrier / max over ranks AND the output all-gather) go through gloo; never used for
+    # reported numbers.
     shared_gpu = os.environ.get("MIXQ_BENCH_SINGLE_GPU_RANKS") == "1" and world > 1
     if shared_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     red_dev = torch.device("cpu") if shared_gpu else dev
-    if world > 1 or args.force_tp_leg:
+    backend = None
+    if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        backend = "gloo" if shared_gpu else "nccl"
         if shared_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        assert dist.get_world_size() == world and dist.get_backend() == backend
     tp = args.tp
     assert world % tp == 0
     dp = world // tp
@@ -257,69 +322,41 @@ def main():
     assert args.tokens % chunk == 0
     n_chunks = args.tokens // chunk
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-
-    # ---- resident state: packed weights of all 96 linears, activations, outputs, workspace -----------------
-    calls = []  # one entry per (layer, linear): prepared ctypes argument blocks
-    keep = []
-    acts, outs, gathered = {}, {}, {}
-    max_ws = 0
-    for layer in range(LLAMA2_7B["layers"]):
-        for name, N, K in LLAMA2_7B["linears"]:
-            n0, n1 = parallel.shard_bounds(N, tp, tp_rank) if tp > 1 else (0, N)
-            t = synth_layer(N, K, dev, gen, n0, n1)
-            if K not in acts:  # 8 rotating activation chunks per K (>1 GB: never resident in the 256 MiB Infinity Cache)
-                acts[K] = [synth_activation(chunk, K, t["ind_i32"], dev, gen) for _ in range(8)]
-            if (n1 - n0) not in outs:
-                outs[n1 - n0] = torch.empty((chunk, n1 - n0), dtype=torch.float16, device=dev)
-            A = acts[K][0]
-            out = outs[n1 - n0]
-            ins = [A, t["weight"], t["weights_scaling_factor"], t["fp_weight"], t["fp_ind"], t["qweight"],
-                   t["weights_scaling_factor"]]
-            in_desc = (TensorDesc * 7)(*[TensorDesc.make(x.shape) for x in ins])
-            out_desc = TensorDesc.make(out.shape)
-            in_ptrs = [(ctypes.c_void_p * 7)(*([a.data_ptr()] + [x.data_ptr() for x in ins[1:]])) for a in acts[K]]
-            out_ptrs = (ctypes.c_void_p * 1)(out.data_ptr())
-            h = lib.mixq_create(chunk, n1 - n0, K)
-            max_ws = max(max_ws, lib.mixq_workspace_size(h, chunk, n1 - n0, K))
-            calls.append((ctypes.c_void_p(h), in_desc, out_desc, in_ptrs, out_ptrs, n1 - n0, K, out))
-            keep.append((t, ins))
-    workspace = torch.empty(max_ws, dtype=torch.uint8, device=dev)
-    ws_ptr = ctypes.c_void_p(workspace.data_ptr())
     stream = torch.cuda.current_stream(dev)
     st_ptr = ctypes.c_void_p(stream.cuda_stream)
-    comm_stream = torch.cuda.Stream(dev) if tp > 1 else None
+    comm_stream = torch.cuda.Stream(dev) if world > 1 else None
 
-    def schedule():
+    def schedule(model):
         # "layer": batched-prefill order -- every linear consumes all bs x seq tokens (as M-chunks) before the next
         # linear runs, as an engine executing layer by layer over the whole batch does; its weights are fetched from
         # HBM once per step.  "chunk": each token chunk walks through all 96 linears (chunked-prefill serving order).
         if args.order == "layer":
-            for li, call in enumerate(calls):
+            for call in model.calls:
                 for c in range(n_chunks):
                     yield call, c
         else:
             for c in range(n_chunks):
-                for call in calls:
+                for call in model.calls:
                     yield call, c
 
-    def one_step(events=None):
+    def one_step(model, group, events=None):
         ei = 0
-        for (h, in_desc, out_desc, in_ptrs_list, out_ptrs, n_loc, K, out), c in schedule():
+        for (h, in_desc, out_desc, in_ptrs_list, out_ptrs, n_loc, K, out, N), c in schedule(model):
             in_ptrs = in_ptrs_list[c % len(in_ptrs_list)]   # rotate the activation buffers of this K
             e0 = e1 = None
             if events is not None:
                 e0, e1 = events[ei]
                 ei += 1
-            rc = lib.mixq_enqueue_profiled(h, in_desc, ctypes.byref(out_desc), in_ptrs, out_ptrs, ws_ptr, st_ptr,
+            rc = lib.mixq_enqueue_profiled(h, in_desc, ctypes.byref(out_desc), in_ptrs, out_ptrs, model.ws_ptr, st_ptr,
                                            e0, e1)
             if rc != 0:
                 raise _lib.MixQError(rc, "mixq_enqueue")
-            if tp > 1:
-                # the ONE collective of the path: all-gather the fp16 output columns (RCCL), overlapped with the
-                # next call's compute on a side stream; the operator's output buffer is consumed before reuse.
+            if model.tp > 1:
+                # the ONE collective of the path: all-gather the fp16 output columns, overlapped with the next call's
+                # compute on a side stream; the operator's output buffer is consumed before it is reused
                 comm_stream.wait_stream(stream)
                 with torch.cuda.stream(comm_stream):
-                    gathered[n_loc] = parallel.all_gather_columns(out, tp_group, tp)
+                    model.full[N] = parallel.all_gather_columns(out, group, model.tp)
                 stream.wait_stream(comm_stream)
 
     def sync_all():
@@ -328,21 +365,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        one_step()
-    launches_per_step = n_chunks * len(calls)
-    events = [[(hip.event(), hip.event()) for _ in range(launches_per_step)] for _ in range(args.steps)]
+    def timed_run(model, group, steps, warmup, with_gemm_events):
+        """W warm-up steps, then EXACTLY `steps` steps between barrier + synchronize brackets; max over ranks."""
+        for _ in range(warmup):
+            one_step(model, group)
+        launches = n_chunks * len(model.calls)
+        events = [[(hip.event(), hip.event()) for _ in range(launches)] for _ in range(steps)] if with_gemm_events else None
+        marks = [hip.event() for _ in range(steps + 1)]   # per-step boundaries on the compute stream (median)
+        sync_all()
+        t0 = time.perf_counter()
+        for s in range(steps):
+            hip.record(marks[s], st_ptr)
+            one_step(model, group, events[s] if events else None)
+        hip.record(marks[steps], st_ptr)
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        per_step = sorted(hip.elapsed_ms(marks[s], marks[s + 1]) for s in range(steps))
+        median = per_step[len(per_step) // 2] if steps % 2 else 0.5 * (per_step[steps // 2 - 1] + per_step[steps // 2])
+        return elapsed, median, events, launches
 
-    sync_all()
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        one_step(events[s])
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    # ---- main measurement ------------------------------------------------------------------------------------
+    model = Model(lib, TensorDesc, parallel, dev, gen, chunk, tp, tp_rank)
+    elapsed, median_ms, events, launches_per_step = timed_run(model, tp_group, args.steps, args.warmup, True)
 
     # ---- roofline of the dominant kernel (fused int8 GEMM), from the events recorded inside the timed region ----
     gemm_ms = 0.0
@@ -352,28 +400,33 @@ def main():
     n_launch = args.steps * launches_per_step
     avg_launch_s = gemm_ms / 1e3 / n_launch
     ops_per_launch = 0.0
-    for (_, _, _, _, _, n_loc, K, _) in calls:
-        ops_per_launch += 2.0 * chunk * n_loc * K + 2.0 * chunk * n_loc * NUM_OUTLIERS
-    ops_per_launch /= len(calls)
+    for c in model.calls:
+        ops_per_launch += 2.0 * chunk * c[5] * c[6] + 2.0 * chunk * c[5] * NUM_OUTLIERS
+    ops_per_launch /= len(model.calls)
     achieved_tops = ops_per_launch / avg_launch_s / 1e12
+    kernel_name = lib.mixq_debug_last_gemm_kernel().decode()   # what launch_gemm selected for the last (chunk, N, K)
 
     tokens_total = args.tokens * dp * args.steps
     value = tokens_total / elapsed
     ms_per_step = elapsed / args.steps * 1e3
     int8_gop_per_token = sum(2.0 * n * k for _, n, k in LLAMA2_7B["linears"]) * LLAMA2_7B["layers"] / 1e9
 
-    traffic = None
-    try:  # PMC-derived HBM-side bytes per GEMM launch, measured for exactly this mix (profiles/pmc_traffic.json)
+    traffic, traffic_source = None, None
+    try:  # PMC-derived HBM-side bytes per GEMM launch of exactly this mix: rocprofv3 --pmc passes of THIS command
+        # (tools/pmc_bench.sh), committed under profiles/ -- counters cannot be read from inside the run
         t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         if t.get("chunk") == chunk and tp == 1 and args.variant == 0:
             traffic = t["bytes_per_launch"]
+            traffic_source = "profiles/pmc_traffic.json (" + t.get("collected", "rocprofv3 --pmc, see profiles/README.md") + ")"
     except Exception:
         traffic = None
     res = None
     if rank == 0:
         res = {
             "metric": "prefill_tokens_per_sec", "value": value, "unit": "tokens/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "median_ms_per_step": median_ms, "value_at_median": args.tokens * dp / (median_ms / 1e3),
+            "higher_is_better": True,
             "scaling": "weak" if tp == 1 else "strong", "vs_baseline": None, "dtype": "int8",
             "data": "synthetic",
             "config": {"workload": "Llama-2-7B W8A8O16 (int8_mix) prefill, bs=512 seq=2048: all 96 MixQ linears "
@@ -384,8 +437,8 @@ def main():
             "gemm_tops_end_to_end": value * int8_gop_per_token / 1e3 / world,
             "roofline": {"bound": "mfma", "achieved": achieved_tops, "peak": INT8_MFMA_PEAK_TOPS, "unit": "TOP/s",
                          "frac": achieved_tops / INT8_MFMA_PEAK_TOPS, "traffic": traffic,
-                         "kernel": "gemm_w8a8o16_kernel<256,256,2,4,0>" if args.variant == 1
-                         else "gemm_w8a8o16_pp_kernel<0>",
+                         "traffic_source": traffic_source,
+                         "kernel": kernel_name,
                          "avg_launch_ms": avg_launch_s * 1e3, "launches": n_launch,
                          "ops_per_launch": ops_per_launch,
                          "gemm_share_of_wall": gemm_ms / 1e3 / elapsed},
@@ -414,103 +467,52 @@ def main():
             except Exception as e:  # the checker failing must not hide the measurement
                 res["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {e}"}
-    # ---- N > 1, DP run: an extra, UNTIMED-for-`value` leg that exercises the north-star TP layout on the same GPUs
-    # (rows of W sharded `world` ways + one RCCL all-gather of the fp16 output) and reports what xGMI delivers.
-    # A watchdog prints the main result and exits if the collective does not come back.
-    if (world > 1 or args.force_tp_leg) and tp == 1 and not args.no_tp_leg and not shared_gpu:
+    # ---- the north-star layout as a first-class object: rows of W sharded over ALL N ranks (tp = N) + one all-gather of
+    # every fp16 output, the whole model, timed between the same barrier + synchronize brackets.  At N = 1 it is the main
+    # measurement itself.  A watchdog emits the main result and exits if the collective never comes back.
+    tp_obj = None
+    if world == 1 or tp == world:
+        tp_obj = {"tp": tp, "world_size": world, "value": value, "unit": "tokens/s", "ms_per_step": ms_per_step,
+                  "steps": args.steps, "scaling": "strong", "collective": None if world == 1 else "all_gather",
+                  "note": "identical to the main measurement" + (" (no collective at tp = 1)" if world == 1 else "")}
+    elif not args.no_tp_leg:
         import threading
 
         def bail():
             if rank == 0:
-                res["tp_leg"] = {"error": "watchdog: TP leg did not finish in 120 s"}
+                res["tp"] = {"tp": world, "error": "watchdog: the tp = N measurement did not finish in 600 s"}
                 emit(res)
             os._exit(0)
 
-        wd = threading.Timer(120.0, bail)
+        wd = threading.Timer(600.0, bail)
         wd.daemon = True
         wd.start()
         try:
-            leg = tp_leg(lib, hip, parallel, TensorDesc, dev, rank, world, chunk, gen, st_ptr, stream)
-            if rank == 0:
-                res["tp_leg"] = leg
+            acts = model.acts
+            model.close()
+            del model
+            torch.cuda.empty_cache()
+            assert dist.get_world_size() == world, "RCCL world size"
+            tmodel = Model(lib, TensorDesc, parallel, dev, gen, chunk, world, rank, acts=acts)
+            t_el, t_med, _, _ = timed_run(tmodel, None, args.tp_steps, 1, False)
+            recv = sum((world - 1) * args.tokens * (c[8] // world) * 2 for c in tmodel.calls)
+            tp_obj = {"tp": world, "world_size": world, "backend": backend,
+                      "value": args.tokens * args.tp_steps / t_el, "unit": "tokens/s",
+                      "ms_per_step": t_el / args.tp_steps * 1e3, "median_ms_per_step": t_med, "steps": args.tp_steps,
+                      "warmup": 1, "scaling": "strong", "collective": "all_gather_into_tensor + column placement "
+                      "(parallel.all_gather_columns), one per linear per chunk, on a side stream",
+                      "allgather_recv_GB_per_gpu_per_step": recv / 1e9,
+                      "tokens_per_step": args.tokens}
         except Exception as e:  # noqa: BLE001 -- the main measurement must survive
-            if rank == 0:
-                res["tp_leg"] = {"error": repr(e)}
+            tp_obj = {"tp": world, "error": repr(e)}
         wd.cancel()
-    if world > 1 or args.force_tp_leg:
+    if rank == 0 and tp_obj is not None:
+        res["tp"] = tp_obj
+    if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         emit(res)
-
-
-def tp_leg(lib, hip, parallel, TensorDesc, dev, rank, world, chunk, gen, st_ptr, stream, iters=10):
-    """One Llama-2-7B layer (qkv, gate, proj) with W row-sharded over all ranks: per call enqueue on the shard, then one
-    all_gather of the [chunk, N/world] fp16 output.  Reports compute-only, gather-only and overlapped times."""
-    tp = world
-    calls, keep, outs = [], [], []
-    max_ws = 0
-    for name, N, K in LLAMA2_7B["linears"]:
-        n0, n1 = parallel.shard_bounds(N, tp, rank)
-        t = synth_layer(N, K, dev, gen, n0, n1)
-        A = synth_activation(chunk, K, t["ind_i32"], dev, gen)
-        out = torch.empty((chunk, n1 - n0), dtype=torch.float16, device=dev)
-        ins = [A, t["weight"], t["weights_scaling_factor"], t["fp_weight"], t["fp_ind"], t["qweight"],
-               t["weights_scaling_factor"]]
-        in_desc = (TensorDesc * 7)(*[TensorDesc.make(x.shape) for x in ins])
-        out_desc = TensorDesc.make(out.shape)
-        in_ptrs = (ctypes.c_void_p * 7)(*[x.data_ptr() for x in ins])
-        out_ptrs = (ctypes.c_void_p * 1)(out.data_ptr())
-        h = lib.mixq_create(chunk, n1 - n0, K)
-        max_ws = max(max_ws, lib.mixq_workspace_size(h, chunk, n1 - n0, K))
-        calls.append((ctypes.c_void_p(h), in_desc, out_desc, in_ptrs, out_ptrs))
-        keep.append((t, ins))
-        outs.append(out)
-    ws = torch.empty(max_ws, dtype=torch.uint8, device=dev)
-    ws_ptr = ctypes.c_void_p(ws.data_ptr())
-    gath = [torch.empty((world * chunk, o.shape[1]), dtype=torch.float16, device=dev) for o in outs]
-    comm = torch.cuda.Stream(dev)
-
-    def compute():
-        for (h, in_desc, out_desc, in_ptrs, out_ptrs) in calls:
-            rc = lib.mixq_enqueue(h, in_desc, ctypes.byref(out_desc), in_ptrs, out_ptrs, ws_ptr, st_ptr)
-            assert rc == 0
-
-    def gather():
-        for o, g in zip(outs, gath):
-            dist.all_gather_into_tensor(g, o)
-
-    def both():  # gather of call i overlaps the GEMM of call i+1 (side stream)
-        for (h, in_desc, out_desc, in_ptrs, out_ptrs), o, g in zip(calls, outs, gath):
-            rc = lib.mixq_enqueue(h, in_desc, ctypes.byref(out_desc), in_ptrs, out_ptrs, ws_ptr, st_ptr)
-            assert rc == 0
-            comm.wait_stream(stream)
-            with torch.cuda.stream(comm):
-                dist.all_gather_into_tensor(g, o)
-        stream.wait_stream(comm)
-
-    def timed(fn):
-        for _ in range(2):
-            fn()
-        torch.cuda.synchronize(dev)
-        dist.barrier()
-        t0 = time.perf_counter()
-        for _ in range(iters):
-            fn()
-        torch.cuda.synchronize(dev)
-        dist.barrier()
-        t = torch.tensor([(time.perf_counter() - t0) / iters], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
-
-    t_c, t_g, t_b = timed(compute), timed(gather), timed(both)
-    recv_bytes = sum((world - 1) * chunk * o.shape[1] * 2 for o in outs)  # bytes each GPU receives per layer pass
-    return {"tp": tp, "layer_ms": {"compute_only": t_c * 1e3, "allgather_only": t_g * 1e3, "overlapped": t_b * 1e3},
-            "allgather_recv_GBps_per_gpu": recv_bytes / t_g / 1e9,
-            "tokens_per_s_if_all_32_layers": chunk / (t_b * LLAMA2_7B["layers"]),
-            "note": "untimed for `value`: rows of W sharded over all ranks + one RCCL all-gather of each fp16 output"}
-
-
 
 
 if __name__ == "__main__":

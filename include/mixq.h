@@ -176,6 +176,9 @@ MIXQ_API int mixq_gemm_mixed(const int8_t* qA, const int8_t* W, const void* sA, 
  * 16 ways / automatic.
  * mixq_debug_set_gemm_variant(70) switches the split form off, 72 / 74 / 78 force a factor, 79 = automatic (default). */
 MIXQ_API size_t mixq_gemm_scratch_size(int M, int N, int K);
+/* Upper bound of mixq_gemm_scratch_size over all shapes on the current device (~56 MiB on MI355X): allocate the
+ * per-stream scratch ONCE at this size and its address never changes -- which a captured HIP graph relies on. */
+MIXQ_API size_t mixq_gemm_scratch_bound(void);
 MIXQ_API int mixq_gemm_mixed_scratch(const int8_t* qA, const int8_t* W, const void* sA, const void* sW, const void* fpA,
                                      const void* fpW, void* Out, int M, int N, int K, int O, void* scratch,
                                      size_t scratch_bytes, void* stream);
@@ -186,6 +189,11 @@ MIXQ_API int mixq_gemm_fp16(const void* fpA, const void* fpW, void* Out, int M, 
 /* dequantizationCUDA (kernel/i8gemm.cu:258-300): out = hadd(fp16((float(x)*sRow[m])*sCol[n]), out). */
 MIXQ_API int mixq_dequantization(void* out_f16, const int32_t* x, const void* scaleRow, const void* scaleCol, int M,
                                  int N, void* stream);
+/* dequantizationCUDASilu (quantkernel/mix_cuda/cult.cu:2305-2348, mixlib dequantizeInt8Silu, the P-flavour's sm90 route
+ * MixQ/src/mixquant/modules/linear.py:321-324): out = fp16( silu( (float(x)*sRow[m])*sCol[n] + float(y) ) ), fp32 math,
+ * one rounding.  out may alias y. */
+MIXQ_API int mixq_dequantization_silu(void* out_f16, const int32_t* x, const void* scaleRow, const void* scaleCol,
+                                      const void* y_f16, int M, int N, void* stream);
 /* w8_a16_gemm_forward_cuda (weightonlykernel/fpA_intB_gemm_wrapper.cu:29-70): Out = A . dequant(qweight).
  * weight = EETQ-interleaved uint8 [K,N], scale fp16 [N]. */
 MIXQ_API int mixq_w8a16_gemm_forward(const void* input_f16, const uint8_t* weight, const void* scale_f16,
@@ -254,6 +262,8 @@ MIXQ_API void mixq_debug_set_gemm_variant(int variant);
  * shader-clock stamps (start, prologue done, main loop done, outlier operands staged, dequant math done, tile staged,
  * stores issued, stores drained) to buffer[block*8 ..].  NULL (default) disables it. */
 MIXQ_API void mixq_debug_set_stamp_buffer(void* device_u64_8_per_block);
+/* Reporting only: name of the kernel family the fused GEMM selected on its most recent launch in this process. */
+MIXQ_API const char* mixq_debug_last_gemm_kernel(void);
 MIXQ_API const char* mixq_version(void);
 MIXQ_API const char* mixq_error_string(int code);
 

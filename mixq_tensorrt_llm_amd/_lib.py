@@ -99,17 +99,20 @@ SIGNATURES = {
     "mixq_int8_fused_dequantize": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "mixq_int8_fused_dequantize_silu": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "mixq_gemm_scratch_size": (ctypes.c_size_t, [_i, _i, _i]),
+    "mixq_gemm_scratch_bound": (ctypes.c_size_t, []),
     "mixq_gemm_mixed_scratch": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, ctypes.c_size_t, _vp]),
     "mixq_int8_fused_dequantize_silu_mul": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "mixq_gemm_mixed": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mixq_gemm_s8s8s32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "mixq_gemm_fp16": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "mixq_dequantization": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "mixq_dequantization_silu": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "mixq_w8a16_gemm_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "mixq_preprocess_weights_int8": (_i, [_vp, _vp, _sz, _sz]),
     "mixq_unprocess_weights_int8": (_i, [_vp, _vp, _sz, _sz]),
     "mixq_debug_set_gemm_variant": (None, [_i]),
     "mixq_debug_set_stamp_buffer": (None, [_vp]),
+    "mixq_debug_last_gemm_kernel": (ctypes.c_char_p, []),
     "mixq_version": (ctypes.c_char_p, []),
     "mixq_error_string": (ctypes.c_char_p, [_i]),
 }

@@ -110,6 +110,8 @@ def load_linear(layer, tensors: Dict[str, torch.Tensor]):
         assert want == got, f"{name}: checkpoint {got} vs module {want}"
         setattr(layer, name, tensors[name].to(dev))
     if layer.bias is not None and "bias" in tensors:
+        want, got = tuple(layer.bias.shape), tuple(tensors["bias"].shape)
+        assert want == got, f"bias: checkpoint {got} vs module {want} (row-sharded layers hold their [N/tp] slice)"
         layer.bias = tensors["bias"].to(dev)
     return layer
 

@@ -369,7 +369,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KG * 64) void gemm_w8a8o16_kernel
                             // addend: the fp16-rounded outlier product (cuBLAS writes fp16) or the caller's y
                             const float c = has_outliers ? h2f(f2h_bits_of_f32_result(P[4 * g + e])) : h2f(yh[e]);
                             float v = __builtin_fmaf((float)acc[i][j][4 * g + e], h2f(swh[e]) * sa, c);
-                            if (epi_has_silu(EPI)) v = v / (1.f + __expf(-v));
+                            if (epi_has_silu(EPI)) v = silu_f32(v);
                             oh[e] = f2h_bits_of_f32_result(v);
                         }
                         if (EPI == EPI_DEQUANT_SILU_MUL) { // gate * up: one fp16 multiply of the rounded result
@@ -397,13 +397,8 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t st)
     constexpr size_t lds = (size_t)KG * NSTAGE * (size_t)(BM + BN) * KSLICE + (PREO ? (size_t)(BM + BN) * OSLICE : 0);
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = gemm_w8a8o16_kernel<BM, BN, WAVES_M, WAVES_N, EPI, NSTAGE, KG, PREO, XSP>;
-    static bool attr_done = false; // benign race: idempotent
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static DeviceOnce once;
+    if (hipError_t e = ensure_dynamic_lds(kern, lds, once); e != hipSuccess) return e;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * (XSP ? p.xsplit : 1))), dim3(T), lds, st, p);
     return hipGetLastError();
@@ -520,8 +515,8 @@ static hipError_t launch_epi(const GemmParams& p, hipStream_t st)
 }
 
 // Schedule selection.  0 = auto (ping-pong 256x256 kernel when the problem fills the chip with 256x256 tiles, else the
-// 2-barrier kernel in a smaller tile), 1 = always the 2-barrier kernel, 2 = ping-pong whenever M > 4,
-// 3 = persistent ping-pong (gemm_pp2_kernels.hip) whenever it applies.
+// 2-barrier kernel in a smaller tile), 1 = always the 2-barrier kernel, 2 = ping-pong whenever M > 4.
+// (The persistent ping-pong experiment of round 1 -- measured to lose -- lives in tools/experimental/, not in the library.)
 // Set through mixq_debug_set_gemm_variant() (tests, A/B measurements) or MIXQ_GEMM_VARIANT=v1|pp in the environment.
 static std::atomic<int> g_variant{-1};
 
@@ -567,24 +562,35 @@ static int gemm_variant()
     return v;
 }
 
+static std::atomic<const char*> g_last_kernel{"none"}; // reporting only (bench.py's roofline.kernel)
+const char* last_gemm_kernel() { return g_last_kernel.load(std::memory_order_relaxed); }
+
 hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st)
 {
     if (p.M <= 0 || p.N <= 0) return hipSuccess;
     const int variant = gemm_variant();
+    auto chose = [](const char* name) { g_last_kernel.store(name, std::memory_order_relaxed); };
     // M <= 16, and M <= 32 on narrow outputs: the weight-streaming GEMV-like kernel (measured against the split-K tiles)
     // ... unless K is long and the tiles are few: then the small tiles with K split over workgroups win (M = 24 / 32 on
     // 4096 x 11008: 14 vs 18 us; on 1024 x 28672: 17 vs 39 us)
     const bool xsplit_wins = epi != EPI_INT32 && p.splitk_ws != nullptr && p.K >= 8192 &&
                              gemm_xsplit_factor(p.M, p.N, p.K) != 0;
-    if (variant != 1 && !xsplit_wins && gemm_skinny_supported(p) && (p.M <= 16 || (p.M <= 32 && p.N < 8192)))
+    if (variant != 1 && !xsplit_wins && gemm_skinny_supported(p) && (p.M <= 16 || (p.M <= 32 && p.N < 8192))) {
+        chose("gemm_skinny_kernel");
         return launch_gemm_skinny(p, epi, st);
+    }
     const int64_t tiles256 = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256);
     if (variant >= 100) return launch_gemm_pp_ablate(p, variant - 100, st); // measurement-only ablations
-    if (variant == 3 && gemm_pp2_supported(p, epi)) return launch_gemm_pp2(p, epi, st);
     const int64_t wg64 = (int64_t)((p.M + 63) / 64) * ((p.N + 63) / 64);
-    if (variant == 0 && epi != EPI_INT32 && p.splitk_ws != nullptr && gemm_splitk_factor(p.M, p.N, p.K) != 0)
-        return launch_gemm_pp_splitk(p, epi, st); // 2 / 4 workgroups per tile
-    if (variant == 2 || (variant == 0 && p.M > 128 && tiles256 >= 96 && wg64 > 768)) return launch_gemm_pp(p, epi, st);
+    if (variant == 0 && epi != EPI_INT32 && p.splitk_ws != nullptr && gemm_splitk_factor(p.M, p.N, p.K) != 0) {
+        chose("gemm_w8a8o16_pp_kernel<SPLITK> (256x256 ping-pong, K split over workgroups)");
+        return launch_gemm_pp_splitk(p, epi, st); // 2 / 4 / 8 workgroups per tile
+    }
+    if (variant == 2 || (variant == 0 && p.M > 128 && tiles256 >= 96 && wg64 > 768)) {
+        chose("gemm_w8a8o16_pp_kernel (256x256 ping-pong)");
+        return launch_gemm_pp(p, epi, st);
+    }
+    chose("gemm_w8a8o16_kernel (two-barrier tiles)");
     switch (epi) {
     case EPI_DEQUANT: return launch_epi<EPI_DEQUANT>(p, st);
     case EPI_DEQUANT_SILU: return launch_epi<EPI_DEQUANT_SILU>(p, st);
@@ -681,6 +687,37 @@ hipError_t launch_dequantization(void* out, const int32_t* x, const void* sRow, 
     const unsigned grid = (unsigned)(want < 2048 ? want : 2048);
     hipLaunchKernelGGL(dequantization_kernel, dim3(grid), dim3(256), 0, st, static_cast<uint16_t*>(out), x,
                        static_cast<const uint16_t*>(sRow), static_cast<const uint16_t*>(sCol), M, N);
+    return hipGetLastError();
+}
+
+// dequantizationKernelSilu (quantkernel/mix_cuda/cult.cu:2305-2324, called by dequantizeInt8Silu :2341-2348 on the
+// P-flavour's sm90 route, MixQ/src/mixquant/modules/linear.py:321-324):
+//   out = fp16( silu( (float(x) * sRow[m]) * sCol[n] + float(y) ) )      -- fp32 throughout, ONE rounding to fp16
+// (unlike dequantizationKernel above, which rounds the product to fp16 before an fp16 add).
+__global__ __launch_bounds__(256) void dequantization_silu_kernel(uint16_t* __restrict__ out,
+                                                                   const int32_t* __restrict__ x,
+                                                                   const uint16_t* __restrict__ sRow,
+                                                                   const uint16_t* __restrict__ sCol,
+                                                                   const uint16_t* __restrict__ y, int M, int N)
+{
+    const int64_t total = (int64_t)M * N;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int m = (int)(i / N), n = (int)(i % N);
+        float t = ((float)x[i] * h2f(sRow[m])) * h2f(sCol[n]); // two separate fp32 roundings (no FMA: nvcc contracts
+        asm("" : "+v"(t));                                        //  only mul+add pairs, and the add below is that pair)
+        out[i] = f2h_bits_of_f32_result(silu_f32(t + h2f(y[i])));
+    }
+}
+
+hipError_t launch_dequantization_silu(void* out, const int32_t* x, const void* sRow, const void* sCol, const void* y,
+                                      int M, int N, hipStream_t st)
+{
+    if (M <= 0 || N <= 0) return hipSuccess;
+    const int64_t want = ((int64_t)M * N + 255) / 256;
+    const unsigned grid = (unsigned)(want < 2048 ? want : 2048);
+    hipLaunchKernelGGL(dequantization_silu_kernel, dim3(grid), dim3(256), 0, st, static_cast<uint16_t*>(out), x,
+                       static_cast<const uint16_t*>(sRow), static_cast<const uint16_t*>(sCol),
+                       static_cast<const uint16_t*>(y), M, N);
     return hipGetLastError();
 }
 

@@ -561,8 +561,8 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
                 float v0 = __builtin_fmaf((float)acc[i][j][4 * g + e2], s2[0], c2[0]);
                 float v1 = __builtin_fmaf((float)acc[i][j][4 * g + e2 + 1], s2[1], c2[1]);
                 if (epi_has_silu(EPI)) {
-                    v0 = v0 / (1.f + __expf(-v0));
-                    v1 = v1 / (1.f + __expf(-v1));
+                    v0 = silu_f32(v0);
+                    v1 = silu_f32(v1);
                 }
                 v2h o16 = f2h2_of_f32_results(v0, v1);
                 if (EPI == EPI_DEQUANT_SILU_MUL) o16 = o16 * __builtin_bit_cast(v2h, e2 ? mulq.y : mulq.x); // gate * up
@@ -640,13 +640,8 @@ static hipError_t launch_pp_cfg(const GemmParams& p, hipStream_t st)
 {
     constexpr size_t lds = 2 * (size_t)pp::BUF + 32768; // slice buffers + 8 x 4-KiB store windows
     auto kern = gemm_w8a8o16_pp_kernel<EPI, HAS_O, HAS_Y, ABL>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static DeviceOnce once;
+    if (hipError_t e = ensure_dynamic_lds(kern, lds, once); e != hipSuccess) return e;
     const int tiles = ((p.M + pp::BM - 1) / pp::BM) * ((p.N + pp::BN - 1) / pp::BN);
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(pp::T), lds, st, p);
     return hipGetLastError();
@@ -662,14 +657,15 @@ static hipError_t launch_pp_epi(const GemmParams& p, hipStream_t st)
 }
 
 // ---- K split over 2 / 4 workgroups per tile (see the kernel header) ---------------------------------------------------
-static int num_cus()
+int num_cus()
 {
-    static int n = 0;
+    static std::atomic<int> cache[64];
+    const int dev = current_device();
+    int n = dev < 64 ? cache[dev].load(std::memory_order_relaxed) : 0;
     if (n == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-             prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        int v = 0;
+        n = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+        if (dev < 64) cache[dev].store(n, std::memory_order_relaxed);
     }
     return n;
 }
@@ -742,13 +738,8 @@ static hipError_t launch_pp_splitk_cfg(const GemmParams& p, hipStream_t st)
 {
     constexpr size_t lds = 2 * (size_t)pp::BUF + 32768;
     auto kern = gemm_w8a8o16_pp_kernel<EPI, HAS_O, HAS_Y, 0, SPLITK>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static DeviceOnce once;
+    if (hipError_t e = ensure_dynamic_lds(kern, lds, once); e != hipSuccess) return e;
     const int tail = ((p.M + pp::BM - 1) / pp::BM) * ((p.N + pp::BN - 1) / pp::BN) - p.splitk_solo;
     constexpr int G = 8 / SPLITK;
     hipLaunchKernelGGL(kern, dim3((unsigned)(p.splitk_solo + 8 * ((tail + G - 1) / G))), dim3(pp::T), lds, st, p);

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
             for (int e = 0; e < 4; ++e) {
                 const float c = p.O > 0 ? h2f(f2h_bits_of_f32_result(P[e])) : h2f(yh[e]);
                 float v = __builtin_fmaf((float)a[e], h2f(swh[e]) * sa, c);
-                if (epi_has_silu(EPI)) v = v / (1.f + __expf(-v));
+                if (epi_has_silu(EPI)) v = silu_f32(v);
                 oh[e] = f2h_bits_of_f32_result(v);
             }
             if (EPI == EPI_DEQUANT_SILU_MUL) { // gate * up

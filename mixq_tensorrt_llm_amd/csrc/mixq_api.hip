@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -18,13 +19,17 @@ namespace mixq {
 // 256 bytes of device zeros: source of the K / O tail chunks of the staging loads (never written).
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
 
-static const void* zero_page()
+static const void* zero_page() // address of the symbol on the CURRENT device (a process may drive several GPUs)
 {
-    static const void* ptr = [] {
+    static std::atomic<const void*> cache[64];
+    const int dev = current_device();
+    const void* ptr = dev < 64 ? cache[dev].load(std::memory_order_relaxed) : nullptr;
+    if (!ptr) {
         void* p = nullptr;
         if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_zero_page)) != hipSuccess) p = nullptr;
-        return static_cast<const void*>(p);
-    }();
+        ptr = p;
+        if (dev < 64) cache[dev].store(ptr, std::memory_order_relaxed);
+    }
     return ptr;
 }
 } // namespace mixq
@@ -105,7 +110,9 @@ void mixq_debug_set_stamp_buffer(void* device_u64_8_per_block) { g_dbg_stamps = 
 
 void mixq_debug_set_gemm_variant(int variant) { mixq::set_gemm_variant(variant < 0 ? 0 : variant); }
 
-const char* mixq_version(void) { return "mixq-mi355x 0.1 (gfx950)"; }
+const char* mixq_debug_last_gemm_kernel(void) { return mixq::last_gemm_kernel(); }
+
+const char* mixq_version(void) { return "mixq-mi355x 0.2 (gfx950)"; }
 
 const char* mixq_error_string(int code)
 {
@@ -231,16 +238,48 @@ int mixq_supports_format_combination(const mixq_handle*, int pos, const mixq_ten
 int mixq_get_output_data_type(const mixq_handle*, int) { return MIXQ_TYPE_HALF; }
 
 // ------------------------------------------------------------------------------------------ workspace ---
-size_t mixq_workspace_size(const mixq_handle*, int64_t maxM, int64_t /*N*/, int64_t K)
+static size_t gemm_scratch_bytes_fwd(int M, int N, int K)
+{
+    const size_t a = mixq::gemm_splitk_workspace_size(M, N, K);
+    return a ? a : mixq::gemm_xsplit_workspace_size(M, N, K);
+}
+// Largest exchange scratch mixq_enqueue can ask for with these N, K and any M <= maxM (the plan depends on M only through
+// the tile counts, so one probe per 256-row / 32-row step covers it); N <= 0: the shape-independent bound.
+static size_t enqueue_scratch_bound(int64_t maxM, int64_t N, int64_t K)
+{
+    if (maxM <= 4) return 0;
+    if (N <= 0 || N > INT32_MAX || K > INT32_MAX || maxM > INT32_MAX)
+        return maxM >= 256 ? mixq::gemm_splitk_workspace_bound() : mixq::gemm_xsplit_workspace_bound();
+    size_t best = 0;
+    auto probe = [&](int64_t m) {
+        if (m < 5 || m > maxM) return;
+        const size_t b = m >= 256 ? gemm_scratch_bytes_fwd((int)m, (int)N, (int)K)
+                                  : mixq::gemm_xsplit_workspace_size((int)m, (int)N, (int)K);
+        if (b > best) best = b;
+    };
+    for (int64_t m = 32; m < 256 && m <= maxM + 31; m += 32) probe(m < maxM ? m : maxM);
+    const int64_t steps = (maxM + 255) / 256;
+    if (steps <= 4096) {
+        for (int64_t t = 1; t <= steps; ++t) probe(t * 256 < maxM ? t * 256 : maxM);
+    } else {
+        const size_t b = mixq::gemm_splitk_workspace_bound();
+        if (b > best) best = b;
+    }
+    probe(maxM);
+    return best;
+}
+
+size_t mixq_workspace_size(const mixq_handle*, int64_t maxM, int64_t N, int64_t K)
 {
     if (maxM <= 0 || K <= 0) return kWorkspaceAlign;
     size_t s = kWorkspaceAlign; // slack for aligning the base like nextWorkspacePtr(ptr, 0)
     s += align_up((size_t)maxM * (size_t)K, kWorkspaceAlign);                                 // qA
     s += align_up((size_t)maxM * sizeof(uint16_t), kWorkspaceAlign);                          // sA
     s += align_up((size_t)maxM * (size_t)kNumOutliers * sizeof(uint16_t), kWorkspaceAlign);   // fpA
-    // exchange scratch of the K splits over workgroups: the 256x256 form from 256 rows, the small-tile form below that
-    if (maxM >= 256) s += align_up(mixq::gemm_splitk_workspace_bound(), kWorkspaceAlign);
-    else if (maxM > 4) s += align_up(mixq::gemm_xsplit_workspace_bound(), kWorkspaceAlign);
+    // exchange scratch of the K splits over workgroups (csrc/gemm_pp_kernels.hip, gemm_kernels.hip): only what a call
+    // with this N, K and at most maxM rows can actually use -- 0 for most shapes
+    const size_t scratch = enqueue_scratch_bound(maxM, N, K);
+    if (scratch) s += align_up(scratch, kWorkspaceAlign);
     return s;
 }
 
@@ -464,6 +503,12 @@ static size_t gemm_scratch_bytes(int M, int N, int K)
 
 size_t mixq_gemm_scratch_size(int M, int N, int K) { return gemm_scratch_bytes(M, N, K); }
 
+size_t mixq_gemm_scratch_bound(void)
+{
+    const size_t a = mixq::gemm_splitk_workspace_bound(), b = mixq::gemm_xsplit_workspace_bound();
+    return a > b ? a : b;
+}
+
 int mixq_gemm_mixed(const int8_t* qA, const int8_t* W, const void* sA, const void* sW, const void* fpA,
                     const void* fpW, void* Out, int M, int N, int K, int O, void* stream)
 {
@@ -534,6 +579,16 @@ int mixq_dequantization(void* out, const int32_t* x, const void* scaleRow, const
     if (M == 0 || N == 0) return MIXQ_OK;
     if (!out || !x || !scaleRow || !scaleCol) return MIXQ_E_BADARG;
     return hip_rc(mixq::launch_dequantization(out, x, scaleRow, scaleCol, M, N, static_cast<hipStream_t>(stream)));
+}
+
+int mixq_dequantization_silu(void* out, const int32_t* x, const void* scaleRow, const void* scaleCol, const void* y, int M,
+                             int N, void* stream)
+{
+    if (M < 0 || N < 0) return MIXQ_E_BADARG;
+    if (M == 0 || N == 0) return MIXQ_OK;
+    if (!out || !x || !scaleRow || !scaleCol || !y) return MIXQ_E_BADARG;
+    return hip_rc(mixq::launch_dequantization_silu(out, x, scaleRow, scaleCol, y, M, N,
+                                                   static_cast<hipStream_t>(stream)));
 }
 
 int mixq_w8a16_gemm_forward(const void* input, const uint8_t* weight, const void* scale, void* output, int m, int n,

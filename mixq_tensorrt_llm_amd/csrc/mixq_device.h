@@ -30,6 +30,11 @@ __device__ __forceinline__ uint16_t f2h_bits(float f)
     return b;
 }
 
+// SiLU as the reference writes it (linear_combination_dequant.h:167-170, cult.cu:2301-2304): x / (1 + expf(-x)) with the
+// accurate library expf (<= 1 ulp, like CUDA's expf without -use_fast_math) and an IEEE division -- not the
+// hardware v_exp_f32 approximation (__expf).
+__device__ __forceinline__ float silu_f32(float x) { return x / (1.f + expf(-x)); }
+
 // fp32 -> fp16 with the fp32 value pinned in a VGPR first.  Without the (empty) asm hipcc folds
 // "fptrunc(fma(...))" into v_fma_mixlo/mixhi_f16, whose result is not the twice-rounded value
 // fp16(fp32(fma)) the reference computes (__float2half of an fp32 FMA) -- measured: rare 1-ulp differences.

@@ -3,7 +3,37 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace mixq {
+
+// Per-device once-flags: attributes set with hipFuncSetAttribute (and device symbol addresses, CU counts) belong to the
+// CURRENT device, and a process may drive several GPUs.  One bit per device ordinal (ordinals >= 64 are simply redone).
+inline int current_device()
+{
+    int d = 0;
+    return hipGetDevice(&d) == hipSuccess && d >= 0 ? d : 0;
+}
+struct DeviceOnce {
+    std::atomic<uint64_t> mask{0};
+    bool done(int dev) const { return dev < 64 && ((mask.load(std::memory_order_acquire) >> dev) & 1u); }
+    void set(int dev)
+    {
+        if (dev < 64) mask.fetch_or(uint64_t{1} << dev, std::memory_order_release);
+    }
+};
+// hipFuncAttributeMaxDynamicSharedMemorySize for `kern` on the current device, once per device (idempotent if raced).
+template <class Kern>
+inline hipError_t ensure_dynamic_lds(Kern kern, size_t bytes, DeviceOnce& once)
+{
+    const int dev = current_device();
+    if (once.done(dev)) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)bytes);
+    if (e == hipSuccess) once.set(dev);
+    return e;
+}
+int num_cus(); // of the current device (cached per device)
 
 enum { EPI_DEQUANT = 0, EPI_DEQUANT_SILU = 1, EPI_INT32 = 2, EPI_DEQUANT_SILU_MUL = 3 };
 constexpr bool epi_has_silu(int epi) { return epi == EPI_DEQUANT_SILU || epi == EPI_DEQUANT_SILU_MUL; }
@@ -48,14 +78,15 @@ size_t gemm_xsplit_workspace_bound();
 void set_xsplit_force(int v); // -1 automatic (default), 0 off, 2 / 4 / 8 / 16 forced
 bool gemm_skinny_supported(const GemmParams& p);
 hipError_t launch_gemm_skinny(const GemmParams& p, int epi, hipStream_t st); // M <= 64: GEMV-like, HBM-bound on W
-bool gemm_pp2_supported(const GemmParams& p, int epi);
-hipError_t launch_gemm_pp2(const GemmParams& p, int epi, hipStream_t st); // persistent ping-pong schedule
 hipError_t launch_gemm_pp_ablate(const GemmParams& p, int abl, hipStream_t st);  // timing experiments only
 void set_gemm_variant(int v);
+const char* last_gemm_kernel(); // kernel family launch_gemm chose last (reporting only)
 void set_skinny_kw(int kw); // measurement knob: K-split width of the skinny kernel (0 = auto)
 hipError_t launch_gemm_fp16(const void* fpA, const void* fpW, void* Out, int M, int N, int O, hipStream_t st);
 hipError_t launch_dequantization(void* out, const int32_t* x, const void* sRow, const void* sCol, int M, int N,
                                  hipStream_t st);
+hipError_t launch_dequantization_silu(void* out, const int32_t* x, const void* sRow, const void* sCol, const void* y,
+                                      int M, int N, hipStream_t st);
 hipError_t launch_quant_extract(void* A, int8_t* qA, void* sA, void* fpA, const int32_t* ind, int M, int K, int O,
                                 bool zero, hipStream_t st,
                                 void* zero_words = nullptr); // (kSplitkWordsBytes to clear on the way, or null)

@@ -217,16 +217,12 @@ static hipError_t launch_norm(const uint16_t* X, const uint16_t* gamma, uint16_t
     const dim3 grid((unsigned)((M + RPB - 1) / RPB)), block(NBLOCK);
     if (quant) {
         const size_t lds = (size_t)((K + 127) / 128) * 16 + (size_t)RPB * K * 2;
-        static bool attr_done = false; // rows of 8192 x 4 waves need more than the default 64 KiB of dynamic LDS
-        if (!attr_done) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rmsnorm_quant_kernel<TPR, MAXV, 8>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-            if (e == hipSuccess)
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(rmsnorm_quant_kernel<TPR, MAXV, 4>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-            if (e != hipSuccess) return e;
-            attr_done = true;
-        }
+        // rows of 8192 x 4 waves need more than the default 64 KiB of dynamic LDS
+        static DeviceOnce once8, once4;
+        if (hipError_t e = ensure_dynamic_lds(rmsnorm_quant_kernel<TPR, MAXV, 8>, 160 * 1024 - 64, once8); e != hipSuccess)
+            return e;
+        if (hipError_t e = ensure_dynamic_lds(rmsnorm_quant_kernel<TPR, MAXV, 4>, 160 * 1024 - 64, once4); e != hipSuccess)
+            return e;
         if (quant == 4)
             hipLaunchKernelGGL((rmsnorm_quant_kernel<TPR, MAXV, 4>), grid, block, lds, st, X, gamma, out, outl, ind, q,
                                scale, eps, M, K, O);

@@ -5,6 +5,7 @@ Same op names, argument order and return conventions as the reference's PyTorch 
 tensors are only carriers of device pointers.  No op has a CPU implementation.
 """
 import ctypes
+import functools
 
 import torch
 
@@ -15,7 +16,7 @@ __all__ = ["FindRowScale", "ExtractOutliersAndSetToZeros", "int8FusedDequantize"
            "layernorm_forward_cuda_extract_outliers", "int_to_half", "int_matrix_to_half",
            "int8_matrix_to_half", "w8_a16_gemm", "preprocess_weights", "mixq_linear", "int4FusedDequantize",
            "int4FusedDequantizeSilu", "unpack_int4_to_fp16", "int8FusedDequantizeSiluMul",
-           "layernorm_forward_cuda_extract_outliers_int4", "ExtractOutliers"]
+           "layernorm_forward_cuda_extract_outliers_int4", "ExtractOutliers", "dequantizeInt8Silu"]
 
 
 def _st(t):
@@ -26,6 +27,26 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+def _on_tensor_device(fn):
+    """Run the op with the CUDA/HIP current device set to the device of its first tensor argument: the library caches
+    per-device state under hipGetDevice() and launches on that tensor's current stream."""
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        for a in args:
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                if a.device.index != torch.cuda.current_device():
+                    with torch.cuda.device(a.device):
+                        return fn(*args, **kwargs)
+                break
+        return fn(*args, **kwargs)
+    return wrapper
+
+
+def _rows_fit(scaleRow, rows, what):
+    # the reference preallocates x_scale [inputdim, 1] (MixQ/src/mixquant/Cache.py:8) and never checks it
+    assert scaleRow.numel() >= rows, f"{what}: scaleRow holds {scaleRow.numel()} rows, {rows} needed"
+
+
 def _dev(*ts):
     for t in ts:
         if not t.is_cuda:
@@ -33,9 +54,11 @@ def _dev(*ts):
         assert t.is_contiguous(), "mixlib ops need contiguous tensors"
 
 
+@_on_tensor_device
 def FindRowScale(x, scaleRow, rows, cols, bit=8):
     """cult.cu:2569-2608.  Writes the per-row fp16 scale into ``scaleRow`` and returns the int8 rows."""
     _dev(x, scaleRow)
+    _rows_fit(scaleRow, rows, "FindRowScale")
     if bit == 4:  # cult.cu:2588-2606: packed int4 pairs, scale = amax / 7
         assert cols % 2 == 0
         out = torch.empty((rows, cols // 2), dtype=torch.uint8, device=x.device)
@@ -47,6 +70,7 @@ def FindRowScale(x, scaleRow, rows, cols, bit=8):
     return out
 
 
+@_on_tensor_device
 def ExtractOutliersAndSetToZeros(ind, input):
     """cult.cu:1433-1465.  Returns input[:, ind] (fp16 [M, len]) and ZEROES those columns of ``input`` in place."""
     _dev(ind, input)
@@ -60,6 +84,7 @@ def ExtractOutliersAndSetToZeros(ind, input):
 
 
 _GEMM_SCRATCH = {}
+_GEMM_SCRATCH_RETIRED = []  # superseded buffers stay alive: a HIP graph captured earlier still holds their pointers
 
 
 def gemm_scratch(t, M, N, K):
@@ -74,6 +99,10 @@ def gemm_scratch(t, M, N, K):
     if buf is None or buf.numel() < n:
         if torch.cuda.is_current_stream_capturing():
             return None
+        if buf is not None:
+            _GEMM_SCRATCH_RETIRED.append(buf)
+        # sized once for every shape where that is affordable (the bound is ~56 MiB), so growth is the exception
+        n = max(n, int(_lib.load().mixq_gemm_scratch_bound()))
         buf = torch.zeros(n, dtype=torch.uint8, device=t.device)
         _GEMM_SCRATCH[key] = buf
     return buf
@@ -88,11 +117,13 @@ def _fused(name, A, B, scale_row, scale_col, y, M, N, K):
     return D
 
 
+@_on_tensor_device
 def int8FusedDequantize(A, B, scale_row, scale_col, y, M, N, K):
     """cult.cu:1937-2000: D = fp16(float(A.B^T) * (scale_col[n]*scale_row[m]) + y), new tensor D."""
     return _fused("mixq_int8_fused_dequantize", A, B, scale_row, scale_col, y, M, N, K)
 
 
+@_on_tensor_device
 def int8FusedDequantizeSilu(A, B, scale_row, scale_col, y, M, N, K):
     """cult.cu:2067-2117: same with SiLU applied before the fp16 rounding."""
     return _fused("mixq_int8_fused_dequantize_silu", A, B, scale_row, scale_col, y, M, N, K)
@@ -108,17 +139,20 @@ def _fused4(name, A, B, scale_row, scale_col, y, M, N, K):
     return D
 
 
+@_on_tensor_device
 def int4FusedDequantize(A, B, scale_row, scale_col, y, M, N, K):
     """cult.cu:2005-2060: packed-int4 A [M,K] / B [N,K] (K = packed bytes per row = in_features // 2, as the reference
     passes it).  No int4 MFMA on gfx950: operands are sign-extended to int8 and run on the int8 kernels (same int32)."""
     return _fused4("mixq_int4_fused_dequantize", A, B, scale_row, scale_col, y, M, N, K)
 
 
+@_on_tensor_device
 def int4FusedDequantizeSilu(A, B, scale_row, scale_col, y, M, N, K):
     """cult.cu:2119-2181."""
     return _fused4("mixq_int4_fused_dequantize_silu", A, B, scale_row, scale_col, y, M, N, K)
 
 
+@_on_tensor_device
 def unpack_int4_to_fp16(weight, ind):
     """cult.cu:3088-3118: fp16 [rows, len(ind)] = the int4 values of columns `ind` of packed `weight` [rows, cols/2]."""
     _dev(weight, ind)
@@ -131,6 +165,7 @@ def unpack_int4_to_fp16(weight, ind):
     return out
 
 
+@_on_tensor_device
 def int8FusedDequantizeSiluMul(A, B, scale_row, scale_col, y, mul, M, N, K):
     """MI355X extension (no reference op): int8FusedDequantizeSilu followed by ``*= mul`` (fused/mlp.py:61-63) in ONE
     kernel: D = fp16(fp16(silu(...)) * mul), the same bits as the two-step sequence."""
@@ -142,6 +177,7 @@ def int8FusedDequantizeSiluMul(A, B, scale_row, scale_col, y, mul, M, N, K):
     return D
 
 
+@_on_tensor_device
 def gemm(mat1, mat2, m, n, k):
     """cult.cu:180-220 (cuBLAS s8 x s8 -> s32): int32 [m,n] = mat1[m,k] . mat2[n,k]^T."""
     _dev(mat1, mat2)
@@ -150,6 +186,7 @@ def gemm(mat1, mat2, m, n, k):
     return out
 
 
+@_on_tensor_device
 def dequantizeInt8(x, scaleRow, scaleCol, y, bits, M, N):
     """cult.cu:2258-2288: out = hadd(fp16((float(x)*scaleRow[m])*scaleCol[n]), y), new tensor."""
     _dev(x, scaleRow, scaleCol, y)
@@ -159,6 +196,18 @@ def dequantizeInt8(x, scaleRow, scaleCol, y, bits, M, N):
     return out
 
 
+@_on_tensor_device
+def dequantizeInt8Silu(x, scaleRow, scaleCol, y, bits, M, N):
+    """cult.cu:2341-2348 (-> dequantizationKernelSilu :2305-2324): fp16(silu((float(x)*scaleRow[m])*scaleCol[n] + y)),
+    new tensor.  The P-flavour's sm90 route calls it after mixlib.gemm (linear.py:321-324)."""
+    _dev(x, scaleRow, scaleCol, y)
+    out = torch.empty((M, N), dtype=torch.float16, device=x.device)
+    _lib.check(_lib.load().mixq_dequantization_silu(_p(out), _p(x), _p(scaleRow), _p(scaleCol), _p(y), M, N, _st(x)),
+               "dequantizeInt8Silu")
+    return out
+
+
+@_on_tensor_device
 def Int8quantize(src, scale):
     """cult.cu:1732-1771: dst = (int8) half2int_rn(hdiv(src, scale[row])) with a caller-supplied per-row scale."""
     _dev(src, scale)
@@ -169,9 +218,11 @@ def Int8quantize(src, scale):
     return dst
 
 
+@_on_tensor_device
 def FindRowScaleFusedExtracOutliers(x, scaleRow, ind, len_ind, rows, cols):
     """cult.cu:2671-2709: returns [int8 rows, outliers fp16 [rows,len_ind]]; zeroes the outlier columns of x."""
     _dev(x, scaleRow)
+    _rows_fit(scaleRow, rows, "FindRowScaleFusedExtracOutliers")
     q = torch.empty((rows, cols), dtype=torch.int8, device=x.device)
     outl = torch.zeros((rows, len_ind), dtype=torch.float16, device=x.device)
     _lib.check(_lib.load().mixq_quant_extract(rows, cols, _p(x), _p(q), _p(scaleRow), _p(outl),
@@ -180,6 +231,7 @@ def FindRowScaleFusedExtracOutliers(x, scaleRow, ind, len_ind, rows, cols):
     return [q, outl]
 
 
+@_on_tensor_device
 def layernorm_forward_cuda(_input, _gamma, _out, eps):
     """layernorm.cu:100-117: T5-style RMSNorm of _input [b, n, c] (or [m, c]) into _out."""
     _dev(_input, _gamma, _out)
@@ -189,12 +241,14 @@ def layernorm_forward_cuda(_input, _gamma, _out, eps):
                "layernorm_forward_cuda")
 
 
+@_on_tensor_device
 def layernorm_forward_cuda_extract_outliers(_input, _gamma, _out, eps, _ind, scaleRow):
     """layernorm.cu:316-346: fused RMSNorm -> extract(+zero) outliers -> per-row int8 quantisation.
     Fills _out (normalised, outlier columns zeroed) and scaleRow; returns [outliers fp16 [m,len], quant int8 [m,c]]."""
     _dev(_input, _gamma, _out, _ind, scaleRow)
     c = _input.shape[-1]
     m = _input.numel() // c
+    _rows_fit(scaleRow, m, "layernorm_forward_cuda_extract_outliers")
     n = _ind.shape[0]
     outl = torch.zeros((m, n), dtype=torch.float16, device=_input.device)
     q = torch.empty((m, c), dtype=torch.int8, device=_input.device)
@@ -204,12 +258,14 @@ def layernorm_forward_cuda_extract_outliers(_input, _gamma, _out, eps, _ind, sca
     return [outl, q]
 
 
+@_on_tensor_device
 def layernorm_forward_cuda_extract_outliers_int4(_input, _gamma, _out, eps, _ind, scaleRow):
     """layernorm.cu:379-414: the same fused producer with packed 4-bit rows (scale = amax / 7).
     Returns [outliers fp16 [m,len], quant uint8 [m, c/2]]."""
     _dev(_input, _gamma, _out, _ind, scaleRow)
     c = _input.shape[-1]
     m = _input.numel() // c
+    _rows_fit(scaleRow, m, "layernorm_forward_cuda_extract_outliers_int4")
     n = _ind.shape[0]
     outl = torch.zeros((m, n), dtype=torch.float16, device=_input.device)
     q = torch.empty((m, c // 2), dtype=torch.uint8, device=_input.device)
@@ -219,6 +275,7 @@ def layernorm_forward_cuda_extract_outliers_int4(_input, _gamma, _out, eps, _ind
     return [outl, q]
 
 
+@_on_tensor_device
 def ExtractOutliers(ind, input):
     """cult.cu ExtractOutliers: input[:, ind] as fp16 [M, len]; `input` is left untouched (T-flavour gather)."""
     _dev(ind, input)
@@ -244,6 +301,7 @@ def int8_matrix_to_half(int_ind):
     return int_ind.contiguous().view(torch.float16).clone()
 
 
+@_on_tensor_device
 def w8_a16_gemm(input, weight, scale):
     """EETQ/csrc/eetpy.cpp:7-19 w8_a16_gemm: fp16 [m,k] x interleaved uint8 [k,n] -> fp16 [m,n]."""
     _dev(input, weight, scale)
@@ -266,6 +324,7 @@ def preprocess_weights(row_major_int8):
     return out
 
 
+@_on_tensor_device
 def mixq_linear(A, W_int8, sW, fp_weight, ind, out=None, workspace=None):
     """The fused two-launch prefill path used inside enqueue, on plain tensors:
     A fp16 [M,K], W int8 [N,K], sW fp16 [N], fp_weight fp16 [N,O], ind int32 [O] -> fp16 [M,N]."""

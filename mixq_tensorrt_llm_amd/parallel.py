@@ -40,14 +40,26 @@ def shard_packed(packed: Dict[str, np.ndarray], tp_size: int, rank: int) -> Dict
     out["qweight"] = qw[n0 * K:n1 * K].reshape(K, n1 - n0).copy()
     if "scales" in packed:
         out["scales"] = np.ascontiguousarray(packed["scales"][n0:n1])
+    if packed.get("bias") is not None:  # per output feature like sW: each rank adds its slice before the gather
+        assert packed["bias"].shape == (N,), f"bias {packed['bias'].shape} vs N={N}"
+        out["bias"] = np.ascontiguousarray(packed["bias"][n0:n1])
     return out
+
+
+def _is_gloo(group) -> bool:
+    try:
+        return dist.get_backend(group) == "gloo"
+    except Exception:  # noqa: BLE001
+        return False
 
 
 def all_gather_columns(x_local: torch.Tensor, group=None, tp_size: int = None) -> torch.Tensor:
     """[.., N/tp] per rank -> [.., N] on every rank with ONE collective (ncclAllGather under RCCL).
 
     RCCL moves contiguous buffers, so the gather lands rank-major ([tp, M, N/tp]); one strided copy puts the column
-    blocks side by side.  Message per rank per call = M * N/tp * 2 bytes to each of the tp-1 peers."""
+    blocks side by side (csrc/tp_kernels.hip's peer writes -- parallel.PeerGather -- avoid that pass where the ranks can
+    map each other's output buffers).  Message per rank per call = M * N/tp * 2 bytes to each of the tp-1 peers.
+    A gloo group (CPU tests, and the 2-ranks-on-one-GPU test) is served through host staging."""
     if tp_size is None:
         tp_size = dist.get_world_size(group)
     if tp_size == 1:
@@ -55,7 +67,10 @@ def all_gather_columns(x_local: torch.Tensor, group=None, tp_size: int = None) -
     lead = x_local.shape[:-1]
     n_loc = x_local.shape[-1]
     x2 = x_local.reshape(-1, n_loc).contiguous()
+    dev = x2.device
+    if x2.is_cuda and _is_gloo(group):
+        x2 = x2.cpu()
     gathered = torch.empty((tp_size * x2.shape[0], n_loc), dtype=x2.dtype, device=x2.device)
     dist.all_gather_into_tensor(gathered, x2, group=group)  # rank-major concatenation along dim 0
     full = gathered.view(tp_size, x2.shape[0], n_loc).permute(1, 0, 2).reshape(x2.shape[0], tp_size * n_loc)
-    return full.reshape(*lead, tp_size * n_loc)
+    return full.reshape(*lead, tp_size * n_loc).to(dev)

@@ -44,6 +44,7 @@ class MixQPlugin:
         self._h = ctypes.c_void_p(handle)
         self._lib = _lib.load()
         self._ws = {}
+        self._retired = []
 
     # -- creator path (MixQPluginCreator::createPlugin / deserializePlugin) --
     @classmethod
@@ -98,6 +99,10 @@ class MixQPlugin:
         key = (device.type, device.index)
         ws = self._ws.get(key)
         if ws is None or ws.numel() < nbytes:
+            if ws is not None:
+                # a HIP graph captured earlier holds the old pointer (and the library parks split-K partial sums in it
+                # on replay): superseded buffers stay alive for the life of the plugin, they are never handed back
+                self._retired.append(ws)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
             self._ws[key] = ws
         return ws
@@ -130,8 +135,9 @@ class MixQPlugin:
             workspace = self._workspace(A.device, self.workspace_size(max(M, 1), N, K))
         in_ptrs = (ctypes.c_void_p * 7)(*[t.data_ptr() for t in inputs])
         out_ptrs = (ctypes.c_void_p * 1)(output.data_ptr())
-        rc = self._lib.mixq_enqueue(self._h, in_desc, ctypes.byref(out_desc), in_ptrs, out_ptrs,
-                                    ctypes.c_void_p(workspace.data_ptr()), _stream_ptr(A.device))
+        with torch.cuda.device(A.device):  # the library keys its per-device state on the CURRENT device
+            rc = self._lib.mixq_enqueue(self._h, in_desc, ctypes.byref(out_desc), in_ptrs, out_ptrs,
+                                        ctypes.c_void_p(workspace.data_ptr()), _stream_ptr(A.device))
         _lib.check(rc, "MixQPlugin::enqueue")
         return output
 
@@ -178,6 +184,10 @@ class MixQLinear:
         self.fp_ind = carrier(packed["fp_ind"].astype(np.int32), (NUM_OUTLIERS * 2,))
         self.qweight = carrier(packed["qweight"], (K, N // 2))
         self.weights_scaling_factor = carrier(packed["weights_scaling_factor"], (N,))
+        if self.bias is not None and packed.get("bias") is not None:
+            b = torch.from_numpy(np.ascontiguousarray(packed["bias"])).to(dev)
+            assert tuple(b.shape) == (N,), f"bias {tuple(b.shape)} vs this rank's {N} output features"
+            self.bias = b.to(self.bias.dtype)
         return self
 
     def forward(self, A: torch.Tensor) -> torch.Tensor:
@@ -185,13 +195,16 @@ class MixQLinear:
             self._plugin = MixQPlugin.create(A.shape[0], self.out_features, self.in_features)
         x = self._plugin.enqueue([A, self.weight, self.weights_scaling_factor, self.fp_weight, self.fp_ind,
                                   self.qweight, self.weights_scaling_factor])   # plugin.py:141-151
-        if self.tp_size > 1 and self.tp_group is not None and self.gather_output:
+        if self.bias is not None:
+            # plugin.py:158-160 adds the bias after its collective; the bias of a row-sharded layer is this rank's
+            # [N/tp] slice (parallel.shard_packed), so it is added to the shard BEFORE the gather -- the same fp16
+            # additions, element for element, as adding the full bias to the gathered output
+            x = x + self.bias.to(x.dtype)
+        if self.tp_size > 1 and self.gather_output:
             # The reference calls allreduce here (plugin.py:155-156), which is shape-wrong for an N-split and is
             # guarded by assert tp_size==1 upstream; the row-sharded operator needs ONE all-gather of the fp16 output.
             from .parallel import all_gather_columns
             x = all_gather_columns(x, self.tp_group, self.tp_size)
-        if self.bias is not None:
-            x = x + self.bias.to(x.dtype)                                        # plugin.py:158-160
         return x
 
     __call__ = forward

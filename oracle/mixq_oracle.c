@@ -468,6 +468,123 @@ ORACLE_API void mixq_oracle_w8a16_gemv(int64_t M, int64_t N, int64_t K, const ui
     }
 }
 
+/*
+ * The SAME decode path with the reference kernel's own summation order, for M <= 4 (the only M the CUDA kernel
+ * serves, kernelLauncher.cu:166-199: Int8b per-channel = <NPerBlock 2, Batch m, BlockSize 256>, kInterleave 2):
+ *   block b -> columns 4b .. 4b+3 (kernel.h:312: n_start = bid * NPerBlock * Interleave); thread tid takes column
+ *   2*idx + (tid/4)%2 of that group (:315, idx = 0,1) and, per trip `it` of the k loop (:332-333, 4096 interleaved
+ *   bytes per trip), the 16 consecutive k starting at (tid/8)*64 + (tid%4)*16 + it*2048 (WeightOnlyScaleLoader
+ *   offset/advance, :263-264, :288-291), while tid*16 + it*4096 < 2K;
+ *   w16 = hfma2(fp16(q), scale, 0) (:367-369); the thread's partial sum is an fp16 FMA chain over y = 0..15 and over
+ *   trips, acc = fp16(w16*a + acc) (:425-433, "we use fp16 for accumulation within threads"); then fp32: warp butterfly
+ *   xor 16, 8, 2, 1 (Int8b Layout::sync, :150-158), lanes 0 / 4 -> shared memory, 8 warps summed in order j = 0..7 from
+ *   0.f (:452-457), out = fp16(v) (:464).
+ * Deterministic; the fp16 chain is evaluated exactly (product and sum formed in double with round-to-odd, then one
+ * RNE to fp16).  Wq_rm is the un-interleaved signed int8 [K,N].
+ */
+static uint16_t d2h_rne(double d)
+{
+    /* double -> fp16, round to nearest even, via float only when exact: do it directly on the value */
+    if (d != d) return 0x7e00u;
+    uint16_t sign = 0;
+    if (d < 0 || (d == 0 && 1.0 / d < 0)) {
+        sign = 0x8000u;
+        d = -d;
+    }
+    if (d >= 65520.0) return (uint16_t)(sign | 0x7c00u); /* rounds to inf */
+    if (d == 0.0) return sign;
+    int e;
+    (void)frexp(d, &e);   /* d = f * 2^e, f in [0.5, 1) */
+    int q = e - 11;       /* ulp exponent for 11 significant bits */
+    if (q < -24) q = -24; /* subnormal range: ulp = 2^-24 */
+    double scaled = ldexp(d, -q);
+    double r = nearbyint(scaled); /* RNE (default rounding mode) */
+    double v = ldexp(r, q);
+    return (uint16_t)(sign | f2h((float)v)); /* v is exactly representable in fp16 (or the next power of two) */
+}
+
+static uint16_t hfma_exact(uint16_t a, uint16_t b, uint16_t c)
+{
+    const double p = (double)h2f(a) * (double)h2f(b); /* exact: 22 significant bits */
+    const double cc = (double)h2f(c);
+    double s = p + cc;
+    /* TwoSum error term; if the double sum was inexact make it odd (round-to-odd) so the final RNE is the true one */
+    const double bb = s - p;
+    const double err = (p - (s - bb)) + (cc - bb);
+    if (err != 0.0 && s == s && s - s == 0.0) {
+        uint64_t bits;
+        memcpy(&bits, &s, 8);
+        if ((bits & 1u) == 0) {
+            const int up = (err > 0) == (s > 0); /* true value is farther from zero than s */
+            bits = up ? bits + 1 : bits - 1;
+            memcpy(&s, &bits, 8);
+        }
+    }
+    return d2h_rne(s);
+}
+
+ORACLE_API void mixq_oracle_w8a16_gemv_reforder(int64_t M, int64_t N, int64_t K, const uint16_t* A,
+                                                const int8_t* Wq_rm, const uint16_t* scale, uint16_t* Out)
+{
+    if (M > 4 || (N % 4) != 0 || (K % 64) != 0) return; /* the CUDA kernel's own domain */
+#pragma omp parallel for schedule(static)
+    for (int64_t nb = 0; nb < N / 4; ++nb) {
+        for (int nid = 0; nid < 4; ++nid) {
+            const int64_t n = nb * 4 + nid;
+            const int inter = nid & 1;
+            const uint16_t sc = scale[n];
+            for (int64_t m = 0; m < M; ++m) {
+                float warp_sum[8];
+                for (int w = 0; w < 8; ++w) {
+                    float lane[32];
+                    for (int l = 0; l < 32; ++l) {
+                        const int tid = w * 32 + l;
+                        uint16_t acc = 0; /* fp16 accumulator of this thread for (m, column n) */
+                        if (((tid / 4) & 1) == inter) {
+                            for (int64_t it = 0; (int64_t)tid * 16 + it * 4096 < 2 * K; ++it) {
+                                const int64_t k0 = (int64_t)(tid / 8) * 64 + (tid % 4) * 16 + it * 2048;
+                                for (int y = 0; y < 16; ++y) {
+                                    const uint16_t w16 = f2h((float)Wq_rm[(k0 + y) * N + n] * h2f(sc)); /* hfma2(q, s, 0) */
+                                    acc = hfma_exact(w16, A[m * K + k0 + y], acc);
+                                }
+                            }
+                        }
+                        lane[l] = h2f(acc);
+                    }
+                    /* threads of the other column of the pair hold ITS sums in the same register; the butterfly below only
+                     * mixes lanes with equal (l/4)%2, so zero-filling them here is equivalent for lanes 0 / 4 */
+                    const int steps[4] = {16, 8, 2, 1};
+                    for (int si = 0; si < 4; ++si) {
+                        float nxt[32];
+                        for (int l = 0; l < 32; ++l) nxt[l] = lane[l] + lane[l ^ steps[si]];
+                        memcpy(lane, nxt, sizeof(lane));
+                    }
+                    warp_sum[w] = lane[inter ? 4 : 0];
+                }
+                float v = 0.f;
+                for (int w = 0; w < 8; ++w) v += warp_sum[w];
+                Out[m * N + n] = f2h(v);
+            }
+        }
+    }
+}
+
+/*
+ * quantkernel/mix_cuda/cult.cu:2301-2324 dequantizationKernelSilu (mixlib dequantizeInt8Silu, :2341-2348):
+ *   out = fp16( silu( (float(x) * sRow[m]) * sCol[n] + float(y) ) ),  silu(v) = v / (1 + expf(-v))
+ * fp32 throughout; nvcc contracts the last multiply-add into one fma (default -fmad=true).
+ */
+ORACLE_API void mixq_oracle_dequantization_silu(int64_t M, int64_t N, const int32_t* x, const uint16_t* sA,
+                                                const uint16_t* sW, const uint16_t* y, uint16_t* out)
+{
+    for (int64_t m = 0; m < M; ++m)
+        for (int64_t n = 0; n < N; ++n) {
+            const float t = (float)x[m * N + n] * h2f(sA[m]);
+            const float v = fmaf(t, h2f(sW[n]), h2f(y[m * N + n]));
+            out[m * N + n] = f2h(v / (1.f + expf(-v)));
+        }
+}
+
 ORACLE_API int mixq_oracle_num_threads(void)
 {
 #ifdef _OPENMP

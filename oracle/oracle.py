@@ -14,7 +14,7 @@ _LIB_PATH = os.path.join(_HERE, "libmixq_oracle.so")
 
 __all__ = [
     "build", "lib", "num_threads", "quant_rows", "extract_outliers", "gemm_s8s8s32", "gemm_fp16",
-    "dequant_epilogue", "dequantization", "linear_prefill", "weight_scales", "quantize_weight",
+    "dequant_epilogue", "dequantization", "dequantization_silu", "w8a16_gemv_reforder", "linear_prefill", "weight_scales", "quantize_weight",
     "select_outliers", "pack_linear_weights", "eetq_symmetric_quantize", "eetq_preprocess", "w8a16_gemv",
     "int_to_half", "int8_matrix_to_half", "rmsnorm_extract_quant", "find_outliers", "dequant_weight_columns",
     "MixLinearState", "mixlinear_forward", "quant4_rows", "unpack_i4", "pack_i4", "mixlinear4_from_linear",
@@ -209,6 +209,29 @@ def w8a16_gemv(A, Wq_rm, scale):
     Out = np.empty((M, N), np.float16)
     lib().mixq_oracle_w8a16_gemv(_i64(M), _i64(N), _i64(K), _p(A), _p(Wq), _p(scale), _p(Out))
     return Out
+
+
+def w8a16_gemv_reforder(A, Wq_rm, scale):
+    """The decode GEMV in the CUDA kernel's own summation order (fp16 per-thread FMA chains, kernel.h:425-470); M <= 4."""
+    A, scale = _h(A), _h(scale).reshape(-1)
+    Wq = np.ascontiguousarray(Wq_rm, np.int8)
+    M, K = A.shape
+    N = Wq.shape[1]
+    assert M <= 4 and N % 4 == 0 and K % 64 == 0
+    Out = np.empty((M, N), np.float16)
+    lib().mixq_oracle_w8a16_gemv_reforder(_i64(M), _i64(N), _i64(K), _p(A), _p(Wq), _p(scale), _p(Out))
+    return Out
+
+
+def dequantization_silu(x, sA, sW, y):
+    """cult.cu:2305-2324 (mixlib dequantizeInt8Silu): fp16(silu((x*sA)*sW + y)), new array."""
+    x = np.ascontiguousarray(x, np.int32)
+    M, N = x.shape
+    y = _h(y)
+    res = np.empty((M, N), np.float16)
+    lib().mixq_oracle_dequantization_silu(_i64(M), _i64(N), _p(x), _p(_h(sA).reshape(-1)), _p(_h(sW).reshape(-1)),
+                                          _p(y), _p(res))
+    return res
 
 
 def pack_linear_weights(W, act_scale, num_outliers=128):

@@ -96,8 +96,14 @@ def test_workspace_sizes_are_size_t_clean(lib):
     M, N, K = 8192, 12288, 4096
     ws = lib.mixq_workspace_size(h, M, N, K)
     need = M * K + 2 * M + 2 * 128 * M
-    splitk = 256 * 7 * 32768 + 16384              # K-split exchange scratch: one 224-KiB slot per CU + the hand-over words
-    assert need + splitk <= ws <= need + splitk + 5 * 128 + 128
+    # the K-split exchange scratch is sized for THIS N, K and every M <= maxM (it was a flat 56 MiB in round 1):
+    # at most one 224-KiB slot per CU + the hand-over words, and nothing at all for most shapes
+    bound = lib.mixq_gemm_scratch_bound()
+    assert bound == 256 * 7 * 32768 + 16384
+    worst = max(lib.mixq_gemm_scratch_size(m, N, K) for m in range(256, M + 1, 256))
+    assert need + worst <= ws <= need + worst + 5 * 128 + 128 and worst <= bound
+    assert lib.mixq_workspace_size(h, 64, 4096, 4096) <= 64 * 4096 + 2 * 64 + 2 * 64 * 128 + 5 * 128  # no split form: no scratch
+    assert lib.mixq_workspace_size(h, M, 0, K) >= need + bound           # N unknown: the shape-independent bound
     xsplit = 16384 + 256 * 64 * 64 * 4            # below 256 rows: the small-tile form's scratch (256 workgroups x 16 KiB)
     assert lib.mixq_workspace_size(h, 128, N, K) <= 128 * K + 2 * 128 + 2 * 128 * 128 + xsplit + 5 * 128 + 128
     assert lib.mixq_workspace_size(h, 4, N, K) <= 4 * K + 8 + 8 * 128 + 4 * 128 + 128     # decode: none
@@ -200,5 +206,9 @@ def test_scratch_of_any_shape_fits_the_plugin_workspace(lib):
             continue     # decode path: no quantised operand, no scratch
         assert carved + need <= ws, (M, N, K, need, ws)
         used += need > 0
+        # a workspace sized for maxM also serves every smaller call of the same layer
+        for m in {max(5, M // 2), max(5, M - 1), min(M, 300), min(M, 129)}:
+            carved_m = 128 + al(m * K) + al(2 * m) + al(2 * 128 * m)
+            assert carved_m + lib.mixq_gemm_scratch_size(m, N, K) <= ws, (m, M, N, K)
     assert used > 20
     lib.mixq_destroy(h)

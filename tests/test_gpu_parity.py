@@ -176,7 +176,7 @@ def variant():
     lib.mixq_debug_set_gemm_variant(0)
 
 
-@pytest.mark.parametrize("which", [1, 2, 3])
+@pytest.mark.parametrize("which", [1, 2])
 @pytest.mark.parametrize("M,N,K", [(5, 16, 16), (33, 144, 272), (129, 256, 384), (256, 512, 128), (300, 768, 640),
                                    (513, 1280, 896), (700, 528, 2064), (1024, 1024, 4096)])
 def test_every_schedule_gives_identical_int32(oracle, variant, which, M, N, K):
@@ -211,9 +211,9 @@ def test_every_tile_configuration_of_the_two_barrier_kernel(oracle, variant, cfg
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 768, 1280), (700, 528, 2112), (520, 1024, 512), (257, 272, 704)])
-@pytest.mark.parametrize("which", [1, 2, 3])
+@pytest.mark.parametrize("which", [1, 2])
 def test_every_schedule_full_operator(oracle, variant, which, M, N, K):
-    """which = 3 (persistent kernel): ragged M/N, partial last K slice, odd slice counts, several tiles per block."""
+    """Both schedules on ragged M/N, a partial last K slice, odd slice counts."""
     variant(which)
     A, W, act = make_layer(M, N, K, seed=31)
     p = oracle.pack_linear_weights(W, act)
@@ -232,11 +232,11 @@ def test_schedules_agree_bitwise_on_the_full_operator(variant):
     fpw = (torch.randn((N, 128), generator=g) * 0.02).to(torch.float16).to(dev())
     ind = torch.randperm(K, generator=g)[:128].to(torch.int32).to(dev())
     outs = []
-    for which in (1, 2, 3):
+    for which in (1, 2):
         variant(which)
         outs.append(mixlib.mixq_linear(A, W, sW, fpw, ind))
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
-    # many tiles per persistent block (tile seams, buffer parity flips with an odd slice count)
+    assert torch.equal(outs[0], outs[1])
+    # more tiles than CUs, odd slice count
     M2, N2, K2 = 4200, 5136, 1152 + 128
     A2 = torch.randn((M2, K2), generator=g).to(torch.float16).to(dev())
     W2 = torch.randint(-127, 128, (N2, K2), dtype=torch.int8, generator=g).to(dev())
@@ -244,7 +244,7 @@ def test_schedules_agree_bitwise_on_the_full_operator(variant):
     fpw2 = (torch.randn((N2, 128), generator=g) * 0.02).to(torch.float16).to(dev())
     ind2 = torch.randperm(K2, generator=g)[:128].to(torch.int32).to(dev())
     outs = []
-    for which in (2, 3):
+    for which in (1, 2):
         variant(which)
         outs.append(mixlib.mixq_linear(A2, W2, sW2, fpw2, ind2))
     assert torch.equal(outs[0], outs[1])
@@ -276,7 +276,13 @@ def test_fused_dequant_epilogue(oracle, M, N, K, silu):
     got = fn(to_dev(a), to_dev(b), to_dev(sa), to_dev(sb), to_dev(y), M, N, K).cpu().numpy()
     want = oracle.dequant_epilogue(oracle.gemm_s8s8s32(a, b), sa, sb, y, silu=silu)
     if silu:
+        # accurate expf + IEEE division on both sides (the product no longer uses the hardware v_exp_f32 shortcut); the
+        # two libm's may still differ in the last ulp of expf, which survives the fp16 rounding only next to a breakpoint:
+        # at most one fp16 ulp, in well under 0.1 % of the elements
         assert rel_err(got, want) < REL_TOL
+        gb, wb = bits(got).astype(np.int32), bits(want).astype(np.int32)
+        assert np.abs(gb - wb).max() <= 1, "SiLU epilogue: more than one fp16 ulp from the expf oracle"
+        assert (gb != wb).mean() < 1e-3, f"SiLU epilogue: {(gb != wb).mean():.2e} of the outputs differ from the expf oracle"
     else:
         assert_bits_equal(got, want, "int8FusedDequantize")
 
@@ -295,6 +301,27 @@ def test_unfused_pair_matches_reference_rounding(oracle):
     got = mixlib.dequantizeInt8(acc, to_dev(sa), to_dev(sb), to_dev(y), 8, M, N).cpu().numpy()
     want = oracle.dequantization(oracle.gemm_s8s8s32(a, b), sa, sb, y)
     assert_bits_equal(got, want, "gemm + dequantizeInt8")
+
+
+def test_unfused_silu_twin(oracle):
+    """mixlib.gemm + dequantizeInt8Silu (cult.cu:2341-2348, P-flavour sm90 route linear.py:321-324): fp32 math, one
+    rounding; equal to the oracle's expf form up to the last ulp of expf (<= 1 fp16 ulp, < 0.1 % of the elements)."""
+    from mixq_tensorrt_llm_amd import mixlib
+    rng = np.random.default_rng(11)
+    M, N, K = 45, 96, 256
+    a = rng.integers(-127, 128, size=(M, K), dtype=np.int8)
+    b = rng.integers(-127, 128, size=(N, K), dtype=np.int8)
+    sa = (np.abs(rng.standard_normal(M)) * 0.05).astype(np.float16)
+    sb = (np.abs(rng.standard_normal(N)) * 1e-3).astype(np.float16)
+    y = rng.standard_normal((M, N)).astype(np.float16)
+    acc = mixlib.gemm(to_dev(a), to_dev(b), M, N, K)
+    got = mixlib.dequantizeInt8Silu(acc, to_dev(sa), to_dev(sb), to_dev(y), 8, M, N).cpu().numpy()
+    want = oracle.dequantization_silu(oracle.gemm_s8s8s32(a, b), sa, sb, y)
+    gb, wb = bits(got).astype(np.int32), bits(want).astype(np.int32)
+    assert np.abs(gb - wb).max() <= 1 and (gb != wb).mean() < 1e-3
+    # and it is NOT the fused epilogue's rounding (that one multiplies the two scales first): keep them apart
+    fused = oracle.dequant_epilogue(oracle.gemm_s8s8s32(a, b), sa, sb, y, silu=True)
+    assert rel_err(got, fused) < REL_TOL
 
 
 def test_fp16_side_gemm(oracle):
@@ -394,14 +421,21 @@ def test_enqueue_edge_rows(oracle):
 @pytest.mark.parametrize("N,K", [(128, 256), (512, 1024), (384, 4096)])
 def test_enqueue_decode_path(oracle, M, N, K):
     """M <= 4 routes to the W8A16 path on the EETQ-interleaved qweight (TsinghuaMixQPlugin.cpp:641-647).
-    Tolerance 5e-3: the reference accumulates per-thread partial sums in fp16 (kernel.h:425-433), an artefact of its
-    launch shape; both the oracle and the HIP kernel keep fp32 sums of fp16-rounded weights."""
+    Two oracles: `w8a16_gemv` (fp16-rounded weights, fp32 sums -- what the HIP kernel computes, and what the
+    reference's tensor-core route for M > 4 computes) and `w8a16_gemv_reforder` (the CUDA GEMV's own order: fp16 FMA
+    chains per thread, kernel.h:425-470).  The product must be within the north-star 1e-3 of the first, and no farther
+    from the reference-order result than that result is from exact arithmetic (+ 1e-3)."""
     A, W, act = make_layer(M, N, K, seed=N + M, outlier_gain=1.0)
     p = oracle.pack_linear_weights(W, act)
     got = run_enqueue(A, p)
     q_un = oracle.eetq_symmetric_quantize(W.T.copy())[0]
     want = oracle.w8a16_gemv(A, q_un, p["weights_scaling_factor"])   # plugin reuses max/127 scales (SURVEY A.3 #3)
-    assert rel_err(got, want) < 5e-3
+    assert rel_err(got, want) < REL_TOL
+    ref_order = oracle.w8a16_gemv_reforder(A, q_un, p["weights_scaling_factor"])
+    exact = A.astype(np.float64) @ (q_un.astype(np.float64) * p["weights_scaling_factor"].astype(np.float64))
+    ref_vs_exact = rel_err(ref_order, exact.astype(np.float32))
+    assert rel_err(got, ref_order) < ref_vs_exact + REL_TOL
+    assert rel_err(got, exact.astype(np.float32)) <= ref_vs_exact + 2e-4   # at least as close to exact as the reference order
 
 
 def test_tp_shards_compose(oracle):

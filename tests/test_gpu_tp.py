@@ -1,0 +1,123 @@
+"""GPU (-m gpu): the N > 1 layout of the operator with the HIP path doing the compute.  Two ranks share the one GPU of the
+box (transport = gloo through host staging; RCCL needs one GPU per rank), each runs ``plugin.MixQLinear(tp_size=2)`` on
+its row shard of W through the C ABI, and the gathered output must equal
+
+  * the CPU oracle of the UNSHARDED layer bit for bit on a fixture whose fp16 outlier products are exact in fp32 in any
+    summation order (integer-valued outlier activations / weights), bias included, and
+  * the oracle within the north-star 1e-3 on ordinary data (Qwen2-7B qkv shape, which has a bias: BASELINE configs[3]).
+
+Covers plugin.py:137-162 (forward, bias after the collective in the reference) under SURVEY 8e's row sharding."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def exact_fixture(M, N, K, seed, O=128):
+    """Packed tensors + activations for which every fp32 partial sum of the outlier GEMM is an integer < 2^24."""
+    rng = np.random.default_rng(seed)
+    ind = rng.permutation(K)[:O].astype(np.int32)
+    W8 = rng.integers(-127, 128, size=(N, K), dtype=np.int8)
+    W8[:, ind] = 0
+    sW = (rng.random(N) * 4e-4 + 4e-4).astype(np.float16)
+    fpw = rng.integers(-3, 4, size=(N, O)).astype(np.float16)
+    A = rng.standard_normal((M, K)).astype(np.float16)
+    A[:, ind] = rng.integers(-60, 61, size=(M, O)).astype(np.float16)
+    bias = (rng.standard_normal(N) * 0.5).astype(np.float16)
+    packed = dict(weight=W8, weights_scaling_factor=sW, fp_weight=fpw, fp_ind=ind,
+                  qweight=np.zeros((K, N), np.uint8), bias=bias)
+    return A, packed
+
+
+def ordinary_fixture(M, N, K, seed):
+    sys.path.insert(0, ROOT)
+    from mixq_tensorrt_llm_amd import pack
+    rng = np.random.default_rng(seed)
+    act = np.abs(rng.standard_normal(K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) * 0.02).astype(np.float16)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    p = pack.pack_linear_weights(torch.from_numpy(W), torch.from_numpy(act))
+    A[:, p["fp_ind"]] *= 20
+    p["bias"] = (rng.standard_normal(N) * 0.5).astype(np.float16)
+    return A.astype(np.float16), p
+
+
+CASES = [  # (name, M, N, K, exact)
+    ("exact_small", 40, 512, 512, True),
+    ("exact_pp_tiles", 300, 1024, 1024, True),
+    ("qwen2_qkv_bias", 48, 4608, 3584, False),
+]
+
+
+def _worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from mixq_tensorrt_llm_amd import parallel, plugin
+    ok, notes = True, []
+    for name, M, N, K, exact in CASES:
+        A, full = exact_fixture(M, N, K, 5) if exact else ordinary_fixture(M, N, K, 6)
+        mine = parallel.shard_packed(full, world, rank)
+        n0, n1 = parallel.shard_bounds(N, world, rank)
+        assert mine["bias"].shape == (n1 - n0,)
+        Ad = torch.from_numpy(A).cuda()
+        want_nb = oracle.linear_prefill(A, full["weight"], full["weights_scaling_factor"], full["fp_weight"],
+                                        full["fp_ind"])
+        for with_bias in (False, True):
+            want = want_nb
+            if with_bias:  # plugin.py:158-160: one fp16 addition per element after the operator
+                want = (torch.from_numpy(want_nb) + torch.from_numpy(full["bias"])).numpy()
+            for gather in (True, False):
+                layer = plugin.MixQLinear(K, N, bias=with_bias, tp_size=world, tp_group=None, gather_output=gather,
+                                          device="cuda:0").load(mine)
+                assert layer.out_features == N // world and (layer.bias is None or layer.bias.shape == (N // world,))
+                got = layer(Ad).cpu().numpy()
+                ref = want if gather else want[:, n0:n1]
+                if got.shape != ref.shape:
+                    ok = False
+                    notes.append(f"{name} bias={with_bias} gather={gather}: shape {got.shape} vs {ref.shape}")
+                    continue
+                if exact:
+                    good = np.array_equal(got.view(np.uint16), ref.view(np.uint16))
+                else:
+                    err = np.abs(got.astype(np.float64) - ref.astype(np.float64)).max() / np.abs(ref).max()
+                    good = err < 1e-3
+                if not good:
+                    ok = False
+                    notes.append(f"{name} bias={with_bias} gather={gather}: mismatch")
+                # 3-D activations keep their leading dims through the gather
+                if gather and M % 2 == 0 and with_bias:
+                    g3 = layer(Ad.reshape(2, M // 2, K))
+                    ok &= tuple(g3.shape) == (2, M // 2, N) and np.array_equal(
+                        g3.reshape(M, N).cpu().numpy().view(np.uint16), got.view(np.uint16))
+    open(os.path.join(tmp, f"ok{rank}"), "w").write("1" if ok else "0\n" + "\n".join(notes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_mixqlinear_row_sharded_two_ranks_one_gpu(tmp_path, oracle):
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        res = open(tmp_path / f"ok{r}").read()
+        assert res == "1", f"rank {r}: {res}"

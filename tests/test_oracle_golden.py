@@ -212,3 +212,75 @@ def test_pflavour_fixture_from_the_reference_linear_py(oracle):
     sc8 = (np.abs(W).max(axis=1) / np.float16(127)).astype(np.float16)
     assert np.array_equal(sc8.view(np.uint16), g["w8_scale_col"].view(np.uint16))
     assert np.array_equal(np.rint((W / sc8[:, None]).astype(np.float16).astype(np.float64)).astype(np.int8), g["w8_q_weight"])
+
+
+def test_decode_oracle_in_the_cuda_kernels_own_order(oracle):
+    """w8a16_gemv_reforder restates weightOnlyBatchedGemv/kernel.h:300-470 for Int8b per-channel (NPerBlock 2, block 256):
+    fp16 FMA chains per thread, fp32 butterflies.  Checked here: (i) its fp16 FMA primitive against an exact rational
+    evaluation, (ii) on integer-valued data, where every partial sum is exact in fp16, it equals the plain dot product,
+    (iii) on ordinary data it sits within ~1e-3 of exact -- the size of the reference's own fp16-accumulation error."""
+    import ctypes
+    from fractions import Fraction
+    rng = np.random.default_rng(3)
+    # (i) hfma_exact is static: exercise it through a K = 64 GEMV with one non-zero product per thread chain
+    K, N = 64, 4
+    for trial in range(200):
+        A = np.zeros((1, K), np.float16)
+        Wq = np.zeros((K, N), np.int8)
+        k0 = int(rng.integers(0, K - 1))
+        k1 = k0 + 1 if (k0 % 16) != 15 else k0 - 1          # same 16-run: same thread, consecutive FMAs
+        a0, a1 = rng.standard_normal(2).astype(np.float16) * np.float16(2.0 ** int(rng.integers(-8, 8)))
+        A[0, k0], A[0, k1] = a0, a1
+        Wq[k0, 0], Wq[k1, 0] = rng.integers(-128, 128, 2)
+        sc = np.array([rng.random() * 1e-2 + 1e-4] * N, np.float16)
+        got = oracle.w8a16_gemv_reforder(A, Wq, sc)[0, 0]
+        w = [np.float16(np.float32(Wq[k, 0]) * np.float32(sc[0])) for k in (min(k0, k1), max(k0, k1))]
+        a = [A[0, min(k0, k1)], A[0, max(k0, k1)]]
+        first = np.float16(np.float32(w[0]) * np.float32(a[0]))              # fma(w, a, 0): product exact in fp32
+        exact = Fraction(float(w[1])) * Fraction(float(a[1])) + Fraction(float(first))
+        # RNE of the exact rational to fp16
+        cands = [np.float16(float(exact)), np.nextafter(np.float16(float(exact)), np.float16(np.inf)),
+                 np.nextafter(np.float16(float(exact)), np.float16(-np.inf))]
+        best = min(cands, key=lambda c: (abs(Fraction(float(c)) - exact), int(c.view(np.uint16)) & 1))
+        assert got.view(np.uint16) == np.float16(best).view(np.uint16) or (got == 0 and best == 0)
+    # (ii) exact regime
+    K, N, M = 256, 8, 3
+    A = rng.integers(-2, 3, size=(M, K)).astype(np.float16)
+    Wq = rng.integers(-3, 4, size=(K, N)).astype(np.int8)
+    sc = np.ones(N, np.float16)
+    want = (A.astype(np.int64) @ Wq.astype(np.int64)).astype(np.float16)
+    assert np.array_equal(oracle.w8a16_gemv_reforder(A, Wq, sc), want)
+    assert np.array_equal(oracle.w8a16_gemv(A, Wq, sc), want)
+    # (iii) ordinary data, K with a ragged last trip (11008 = 5.375 trips of 2048)
+    K, N, M = 11008, 16, 4
+    A = rng.standard_normal((M, K)).astype(np.float16)
+    Wq = rng.integers(-128, 128, size=(K, N), dtype=np.int8)
+    sc = (rng.random(N) * 1e-3 + 1e-4).astype(np.float16)
+    exact = A.astype(np.float64) @ (Wq.astype(np.float64) * sc.astype(np.float64))
+    err = lambda x: np.abs(x.astype(np.float64) - exact).max() / np.abs(exact).max()  # noqa: E731
+    assert err(oracle.w8a16_gemv(A, Wq, sc)) < 1e-3
+    assert err(oracle.w8a16_gemv_reforder(A, Wq, sc)) < 3e-3
+
+
+def test_dequantization_silu_oracle_against_numpy(oracle):
+    rng = np.random.default_rng(5)
+    M, N = 9, 24
+    x = rng.integers(-50000, 50000, size=(M, N)).astype(np.int32)
+    sa = (rng.random(M) * 0.05).astype(np.float16)
+    sw = (rng.random(N) * 1e-3).astype(np.float16)
+    y = rng.standard_normal((M, N)).astype(np.float16)
+    got = oracle.dequantization_silu(x, sa, sw, y)
+    v = (x.astype(np.float64) * sa.astype(np.float64)[:, None]) * sw.astype(np.float64)[None, :] + y.astype(np.float64)
+    want = v / (1 + np.exp(-v))
+    assert np.abs(got.astype(np.float64) - want).max() <= 1e-3 * np.abs(want).max()
+
+
+def test_top_level_mixlib_module_name():
+    """`import mixlib` (MixQ/src/mixquant/modules/linear.py:5) resolves to the MI355X op surface with every op name the
+    reference's int8_mix callers use (pybind_mix.cpp:256-335)."""
+    import importlib
+    m = importlib.import_module("mixlib")
+    for name in ("FindRowScale", "ExtractOutliersAndSetToZeros", "int8FusedDequantize", "int8FusedDequantizeSilu", "gemm",
+                 "dequantizeInt8", "dequantizeInt8Silu", "Int8quantize", "FindRowScaleFusedExtracOutliers", "int_to_half",
+                 "int8_matrix_to_half", "int_matrix_to_half", "layernorm_forward_cuda_extract_outliers"):
+        assert callable(getattr(m, name)), name

@@ -30,6 +30,7 @@ def _worker(rank, world, port, tmp):
     from mixq_tensorrt_llm_amd import pack, parallel
     A, W, act = make_layer(24, 64, 256, seed=9)
     full = pack.pack_linear_weights(torch.from_numpy(W), torch.from_numpy(act))
+    full["bias"] = np.arange(64, dtype=np.float16)          # per output feature: sharded like sW (Qwen2 qkv has one)
     mine = parallel.shard_packed(full, world, rank)
     out_local = oracle.linear_prefill(A, mine["weight"], mine["weights_scaling_factor"], mine["fp_weight"],
                                       mine["fp_ind"])
@@ -38,6 +39,7 @@ def _worker(rank, world, port, tmp):
     ok = np.array_equal(gathered.numpy().view(np.uint16), want.view(np.uint16))
     # decode weights: the interleaved image shards by contiguous byte ranges of column pairs
     n0, n1 = parallel.shard_bounds(64, world, rank)
+    ok &= np.array_equal(mine["bias"], full["bias"][n0:n1])
     q_un = oracle.eetq_symmetric_quantize(W.T.copy())[0]
     ok &= np.array_equal(mine["qweight"], oracle.eetq_preprocess(np.ascontiguousarray(q_un[:, n0:n1])))
     # 3-D activations keep their leading dims
