@@ -194,10 +194,23 @@ MIXQ_API int mixq_dequantization(void* out_f16, const int32_t* x, const void* sc
  * one rounding.  out may alias y. */
 MIXQ_API int mixq_dequantization_silu(void* out_f16, const int32_t* x, const void* scaleRow, const void* scaleCol,
                                       const void* y_f16, int M, int N, void* stream);
-/* w8_a16_gemm_forward_cuda (weightonlykernel/fpA_intB_gemm_wrapper.cu:29-70): Out = A . dequant(qweight).
- * weight = EETQ-interleaved uint8 [K,N], scale fp16 [N]. */
+/* w8_a16_gemm_forward_cuda (weightonlykernel/fpA_intB_gemm_wrapper.cu:29-70): Out = A . dequant(qweight), fp16 A [m,k],
+ * weight = EETQ-interleaved uint8 [K,N] consumed as stored, scale fp16 [N], Out fp16 [m,n].
+ * m <= 4: the batched GEMV (weightOnlyBatchedGemv, :53-58); m > 4: the fpA_intB tensor-core GEMM (ft::gemm_fp16_int,
+ * :59-69 -> fpA_intB_gemm_template.h:441-552) -- here fp16 MFMA with the int8 weights dequantised in registers
+ * (csrc/w8a16_gemm_kernels.hip).  k % 64 == 0, n % 2 == 0.  The reference passes its GEMM no workspace (nullptr, 0). */
 MIXQ_API int mixq_w8a16_gemm_forward(const void* input_f16, const uint8_t* weight, const void* scale_f16,
                                      void* output_f16, int m, int n, int k, void* stream);
+/* The same with caller-owned scratch (MI355X extension; CUTLASS' split-k workspace, fpA_intB_gemm_wrapper.cu:16-25, is the
+ * counterpart): with few column tiles K is split over several workgroups per tile, which keeps every CU streaming
+ * weights.  mixq_w8a16_gemm_workspace_size(m,n,k) bytes (0: no split for this shape), ZERO-FILLED before its first use,
+ * one per stream; it may be the same buffer as mixq_gemm_mixed_scratch's (every kernel leaves the hand-over words zero).
+ * Results do not depend on whether / how K was split in the last bit only up to fp32 summation order: the parts are
+ * always added in the same order, so a given (shape, scratch-or-not) is deterministic. */
+MIXQ_API size_t mixq_w8a16_gemm_workspace_size(int m, int n, int k);
+MIXQ_API int mixq_w8a16_gemm_forward_ws(const void* input_f16, const uint8_t* weight, const void* scale_f16,
+                                        void* output_f16, int m, int n, int k, void* workspace, size_t workspace_bytes,
+                                        void* stream);
 
 /* MLP fusion beyond the reference (MixQ/src/mixquant/modules/fused/mlp.py:57-64 runs int8FusedDequantizeSilu and then
  * `gate_output *= up_output` as a separate pass over [M,N]): D = fp16( fp16(silu(float(A.B^T)*(sc*sr) + y)) * mul ),

@@ -108,6 +108,8 @@ SIGNATURES = {
     "mixq_dequantization": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "mixq_dequantization_silu": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "mixq_w8a16_gemm_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "mixq_w8a16_gemm_workspace_size": (ctypes.c_size_t, [_i, _i, _i]),
+    "mixq_w8a16_gemm_forward_ws": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, ctypes.c_size_t, _vp]),
     "mixq_preprocess_weights_int8": (_i, [_vp, _vp, _sz, _sz]),
     "mixq_unprocess_weights_int8": (_i, [_vp, _vp, _sz, _sz]),
     "mixq_debug_set_gemm_variant": (None, [_i]),

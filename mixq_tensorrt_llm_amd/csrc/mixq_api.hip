@@ -591,15 +591,40 @@ int mixq_dequantization_silu(void* out, const int32_t* x, const void* scaleRow, 
                                                    static_cast<hipStream_t>(stream)));
 }
 
-int mixq_w8a16_gemm_forward(const void* input, const uint8_t* weight, const void* scale, void* output, int m, int n,
-                            int k, void* stream)
+size_t mixq_w8a16_gemm_workspace_size(int m, int n, int k)
+{
+    if (m <= kSmallMFastPath || n <= 0 || k <= 0) return 0;
+    size_t best = 0;
+    for (int rows = m < 256 ? m : 256, done = 0; !done; done = 1) { // passes of <= 256 tokens; the ragged last pass may plan differently
+        const size_t a = mixq::w8a16_gemm_workspace_size(rows, n, k);
+        const size_t b = m > 256 && m % 256 ? mixq::w8a16_gemm_workspace_size(m % 256, n, k) : 0;
+        best = a > b ? a : b;
+    }
+    return best;
+}
+
+int mixq_w8a16_gemm_forward_ws(const void* input, const uint8_t* weight, const void* scale, void* output, int m, int n,
+                               int k, void* workspace, size_t workspace_bytes, void* stream)
 {
     if (m < 0 || n < 0 || k <= 0) return MIXQ_E_BADARG;
     if (m == 0 || n == 0) return MIXQ_OK;
     if (!input || !weight || !scale || !output) return MIXQ_E_BADARG;
     if (k % 64 || n % 2) return MIXQ_E_SHAPE; // the interleaved layout needs 64-row tiles and column pairs
     if (!aligned16(input) || !aligned16(weight)) return MIXQ_E_ALIGN;
-    return hip_rc(mixq::launch_w8a16(input, weight, scale, output, m, n, k, static_cast<hipStream_t>(stream)));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // fpA_intB_gemm_wrapper.cu:45-70: m <= SMALL_M_FAST_PATH -> the batched GEMV, else the mixed-input tensor-core GEMM
+    if (m <= kSmallMFastPath) return hip_rc(mixq::launch_w8a16(input, weight, scale, output, m, n, k, st));
+    if (k % 8 || (reinterpret_cast<uintptr_t>(output) & 3u)) return MIXQ_E_ALIGN;
+    const void* zeros = mixq::zero_page();
+    if (!zeros) return MIXQ_E_HIP;
+    if (workspace && !aligned16(workspace)) workspace = nullptr, workspace_bytes = 0;
+    return hip_rc(mixq::launch_w8a16_gemm(input, weight, scale, output, m, n, k, workspace, workspace_bytes, zeros, st));
+}
+
+int mixq_w8a16_gemm_forward(const void* input, const uint8_t* weight, const void* scale, void* output, int m, int n,
+                            int k, void* stream)
+{
+    return mixq_w8a16_gemm_forward_ws(input, weight, scale, output, m, n, k, nullptr, 0, stream);
 }
 
 // ------------------------------------------------------------------------------------------- enqueue ----

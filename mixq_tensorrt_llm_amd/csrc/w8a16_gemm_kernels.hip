@@ -1,0 +1,321 @@
+// fpA_intB GEMM for gfx950 (M > 4): Out[m,n] = sum_k A[m,k] * fp16((q[k,n]-128) * scale[n]), fp16 activations x int8
+// weights, weights dequantised IN REGISTERS on their way into the fp16 matrix cores, fp32 accumulation.
+//
+// Replaces (reference, CUDA): weightonlykernel/fpA_intB_gemm_wrapper.cu:45-70 (m > SMALL_M_FAST_PATH ->
+// ft::gemm_fp16_int) -> cutlass_kernels/fpA_intB_gemm/fpA_intB_gemm_template.h:441-552 (CUTLASS mixed-input GEMM:
+// FastInterleavedAndBiasedNumericArrayConverter + per-column scale in the main loop, tensor-core MMA, fp32 accumulate);
+// callers: MixQ/src/mixquant/modules/linear.py:175-181 (weight_only mode), EETQ w8_a16_gemm.
+//
+// The weight operand is consumed in the reference's on-disk layout (EETQ / FasterTransformer interleave, see
+// decode_kernels.hip): column pair p owns 2K contiguous bytes; per 64-row block tb: [64 B of column 2p | 64 B of column
+// 2p+1]; inside a 16-byte group the even bytes are k0..k0+7 and the odd bytes k0+8..k0+15 (that is what the row
+// permutation + byte swap of the layout amount to).  The layout was designed so that one 32-bit word converts into two
+// fp16 PAIRS of adjacent k -- which also makes it MFMA-friendly without any re-layout:
+//
+//   v_mfma_f32_32x32x16_f16, MFMA "A" = 32 weight columns (n), MFMA "B" = 32 tokens (m).  Lane (n = l % 32, kg = l / 32)
+//   loads ONE 16-byte group of its column (group 2j + kg of the 64-row block): v_perm_b32 on the even bytes gives
+//   k0..k0+7 in order (the lane's 8 k-values of MFMA "even"), on the odd bytes k0+8..k0+15 (MFMA "odd").  The token
+//   operand of lane (m, kg) for those two MFMAs is A[m, k0 .. k0+7] and A[m, k0+8 .. k0+15]: two contiguous 16-byte
+//   LDS reads.  Every weight byte is loaded from HBM exactly once per 256 tokens and never touches LDS.
+//   Dequantisation = the GEMV's: v_perm_b32 -> 0x6400|b (1024 + b, exact), v_pk_add_f16 -1152 (exact q - 128),
+//   v_pk_mul_f16 by the column scale (ONE rounding: the fp16((q-128)*scale) the reference feeds its tensor cores).
+//
+// Workgroup = 4 waves x 32 columns = 128 output columns, all M rows of a 32*MT-row super-tile (MT <= 8): the token tile
+// of a K stage (128 k: 32*MT rows x 256 B, XOR-swizzled 16-byte chunks) is staged ONCE per workgroup with LDS-DMA and
+// shared by the four waves; weights are prefetched NST-1 stages ahead in registers.  One barrier per stage.
+// Narrow N / small M leave CUs idle, so K is optionally split over `ks` workgroups per column tile (caller-provided
+// scratch): every workgroup parks its fp32 partial tile with write-through stores and counts itself in; the LAST one to
+// arrive adds all parts IN RANK ORDER (fp32 addition does not commute bitwise: a fixed order keeps the result
+// deterministic whichever workgroup is last) and stores the fp16 tile.  Nobody waits.
+#include "mixq_device.h"
+#include "mixq_launch.h"
+
+namespace mixq {
+
+namespace wo {
+constexpr int KB = 128;        // k per stage
+constexpr int ROWB = KB * 2;   // bytes per token row per stage
+constexpr int BN = 128;        // columns per workgroup (4 waves x 32)
+} // namespace wo
+
+__device__ __forceinline__ v2h wo_dequant_pair(unsigned w, unsigned sel, v2h scale2)
+{
+    const unsigned h = __builtin_amdgcn_perm(0x64646464u, w, sel); // two fp16: 1024 + byte
+    const v2h bias = {(_Float16)-1152.0f, (_Float16)-1152.0f};
+    return (__builtin_bit_cast(v2h, h) + bias) * scale2; // exact subtract, one RNE in the multiply
+}
+
+// WM = 1: 4 waves, each 32 columns x all 32*MT rows.  WM = 2: 8 waves, the second four take the upper half of the rows
+// (two waves per SIMD: one wave's LDS reads and dequant VALU hide under the other's MFMAs -- the large-M form).
+template <int MT, int NST, int WM = 1>
+__global__ __launch_bounds__(256 * WM) void w8a16_gemm_kernel(const uint16_t* __restrict__ A, const uint8_t* __restrict__ Wq,
+                                                          const uint16_t* __restrict__ scale,
+                                                          uint16_t* __restrict__ Out, int M, int N, int K, int ks,
+                                                          void* __restrict__ scratch, const void* __restrict__ zeros)
+{
+    using namespace wo;
+    constexpr int ROWS = MT * 32;
+    constexpr int T = 256 * WM;                   // threads
+    constexpr int MTW = MT / WM;                  // 32-row tiles per wave
+    static_assert(MT % WM == 0, "");
+    constexpr int STAGE = ROWS * ROWB;            // bytes of one token stage
+    constexpr int AL = ROWS * 16 / T;             // 16-byte LDS-DMA copies per thread per stage
+    constexpr int GROUP_OPS = 4 + AL;             // VMEM operations a thread issues per stage
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int ntile = (int)blockIdx.x / ks, krank = (int)blockIdx.x % ks;
+    const int wn = wave & 3, wmh = wave >> 2;     // column group, row half
+    const int n0w = ntile * BN + wn * 32;         // first column of this wave
+    const int trow0 = wmh * MTW * 32;             // first token row of this wave
+
+    // ---- this workgroup's K range, in stages of 128 k -----------------------------------------------------------------
+    const int nst_all = (K + KB - 1) / KB;
+    const int s_begin = (int)((int64_t)nst_all * krank / ks), s_end = (int)((int64_t)nst_all * (krank + 1) / ks);
+    const int nst = s_end - s_begin;
+
+    // ---- weight stream: lane (column n, 16-byte group parity kg) -------------------------------------------------------
+    const int ncol = min(n0w + lr, N - 1);        // clamped columns are computed, never stored
+    const uint8_t* const wbase = Wq + (int64_t)(ncol >> 1) * 2 * K + (ncol & 1) * 64 + lh * 16;
+    v2h scale2;
+    {
+        _Float16 sc;
+        const uint16_t sb = scale[ncol];
+        __builtin_memcpy(&sc, &sb, 2);
+        scale2 = v2h{sc, sc};
+    }
+    const bool khalf = (K % KB) != 0; // K % 64 == 0 is required, so the only ragged case is a last stage of 64 k
+    auto load_w = [&](uint4 (&w)[4], int s) __attribute__((always_inline)) {
+        // groups (tbq, j): 64-row block 2s + tbq, 16-byte group 2j + kg of this lane's column
+        const uint8_t* b = wbase + (int64_t)s * 256;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int off = (q >> 1) * 128 + (q & 1) * 32;
+            // a ragged last stage has no second 64-row block: re-read the first (its products meet zero activations)
+            const bool dup = khalf && s == nst_all - 1 && (q >> 1) == 1;
+            w[q] = *reinterpret_cast<const uint4*>(b + (dup ? off - 128 : off));
+        }
+    };
+
+    // ---- token tile -> LDS: chunk c = i * 256 + tid: row = c / 16, slot = c % 16 holds source chunk slot ^ (row & 15) ----
+    const char* asrc[AL];
+    int akoff[AL];
+#pragma unroll
+    for (int i = 0; i < AL; ++i) {
+        const int row = (i * T + tid) >> 4, slot = tid & 15;
+        const int chunk = slot ^ (row & 15);
+        asrc[i] = reinterpret_cast<const char*>(A) + (int64_t)min(row, M - 1) * K * 2 + chunk * 16;
+        akoff[i] = chunk * 8; // first k of this chunk inside the stage
+    }
+    auto stage_a = [&](int buf, int s) __attribute__((always_inline)) {
+        const int64_t k0 = (int64_t)s * KB;
+#pragma unroll
+        for (int i = 0; i < AL; ++i) {
+            const char* src = asrc[i] + k0 * 2;
+            if (khalf && k0 + akoff[i] >= K) src = static_cast<const char*>(zeros);
+            glds16(src, smem + buf * STAGE + (i * T + wave * 64) * 16);
+        }
+    };
+
+    // ---- fragment read offsets: lane (token row t*32 + lr, kg): chunk = tbq*8 + 2*(2j + kg) + odd -----------------------
+    int aoff[4][2]; // [q = tbq*2 + j][odd]
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const int chunk = (q >> 1) * 8 + 2 * (2 * (q & 1) + lh) + o;
+            aoff[q][o] = lr * ROWB + ((chunk ^ (lr & 15)) << 4);
+        }
+
+    v16f acc[MTW];
+#pragma unroll
+    for (int t = 0; t < MTW; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    auto compute = [&](const uint4 (&w)[4], int buf) __attribute__((always_inline)) {
+        const char* base = smem + buf * STAGE + trow0 * ROWB;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned d[4] = {w[q].x, w[q].y, w[q].z, w[q].w};
+            v2h e2[4], o2[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                e2[x] = wo_dequant_pair(d[x], 0x04020400u, scale2); // bytes 0, 2 -> k0 + 2x, k0 + 2x + 1
+                o2[x] = wo_dequant_pair(d[x], 0x04030401u, scale2); // bytes 1, 3 -> k0 + 8 + 2x, k0 + 9 + 2x
+            }
+            const v8h we = {e2[0][0], e2[0][1], e2[1][0], e2[1][1], e2[2][0], e2[2][1], e2[3][0], e2[3][1]};
+            const v8h wod = {o2[0][0], o2[0][1], o2[1][0], o2[1][1], o2[2][0], o2[2][1], o2[3][0], o2[3][1]};
+#pragma unroll
+            for (int t = 0; t < MTW; ++t) {
+                const v8h ae = *reinterpret_cast<const v8h*>(base + t * 32 * ROWB + aoff[q][0]);
+                const v8h ao = *reinterpret_cast<const v8h*>(base + t * 32 * ROWB + aoff[q][1]);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(we, ae, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wod, ao, acc[t], 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- main loop: stage i's operands were issued NST-1 iterations earlier; one barrier per stage ----------------------
+    // Issue order inside an iteration: weights of stage i + NST - 1 (4 loads), then its token copies (AL): a thread's VMEM
+    // operations complete in order, so "at most (NST - 2) groups outstanding" means group i has landed.
+    uint4 w[NST][4];
+#pragma unroll
+    for (int p = 0; p < NST - 1; ++p) {
+        if (p < nst) {
+            load_w(w[p], s_begin + p);
+            stage_a(p, s_begin + p);
+        }
+    }
+    // (the loop is unrolled NST-fold so that the register sets have static names)
+    for (int i0 = 0; i0 < nst; i0 += NST) {
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int i = i0 + u;
+            if (i >= nst) break;
+            // group i was issued NST-1 iterations ago; the NST-2 younger groups may still be in flight.  Near the end fewer
+            // groups were issued after it, so the bound only gets looser than needed if we do nothing: drain instead.
+            if (NST > 2 && i + NST - 2 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * GROUP_OPS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads(); // stage i visible to every wave; everyone is done reading the buffer stage i+NST-1 will reuse
+            if (i + NST - 1 < nst) {
+                load_w(w[(u + NST - 1) % NST], s_begin + i + NST - 1);
+                stage_a((i + NST - 1) % NST, s_begin + i + NST - 1);
+            }
+            compute(w[u], i % NST);
+        }
+    }
+
+    // ---- K split over workgroups: park, count in, the last one to arrive adds the parts in rank order -----------------
+    if (ks > 1) {
+        __shared__ unsigned arrived_s;
+        constexpr int TILE = MTW * 16 * T; // floats of one parked tile: [tile of the wave][16][thread]
+        unsigned* const counter = static_cast<unsigned*>(scratch) + ntile;
+        float* const slots = reinterpret_cast<float*>(static_cast<char*>(scratch) + kSplitkWordsBytes) +
+                             (size_t)ntile * ks * TILE;
+        float* const mine = slots + (size_t)krank * TILE + tid;
+#pragma unroll
+        for (int t = 0; t < MTW; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                __hip_atomic_store(mine + (t * 16 + e) * T, acc[t][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every write-through acknowledged
+        __syncthreads();
+        if (tid == 0) arrived_s = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (arrived_s != (unsigned)(ks - 1)) return;
+        if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // re-armed
+        v16f own[MTW];
+#pragma unroll
+        for (int t = 0; t < MTW; ++t) own[t] = acc[t];
+#pragma unroll
+        for (int t = 0; t < MTW; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+        for (int r = 0; r < ks; ++r) { // rank order, whichever workgroup is last
+            const float* const theirs = slots + (size_t)r * TILE + tid;
+            const bool self = r == krank;
+#pragma unroll
+            for (int t = 0; t < MTW; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    acc[t][e] += self ? own[t][e]
+                                      : __hip_atomic_load(theirs + (t * 16 + e) * T, __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+
+    // ---- store: lane holds, per 32x32 tile, 4 x (4 consecutive columns) of token row t*32 + lr -------------------------
+#pragma unroll
+    for (int t = 0; t < MTW; ++t) {
+        const int m = trow0 + t * 32 + lr;
+        if (m >= M) continue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = n0w + 8 * g + 4 * lh;
+            uint16_t* dst = Out + (int64_t)m * N + n;
+            const v2h lo = f2h2(acc[t][4 * g], acc[t][4 * g + 1]), hi = f2h2(acc[t][4 * g + 2], acc[t][4 * g + 3]);
+            if (n + 3 < N) {
+                *reinterpret_cast<uint2*>(dst) = uint2{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+            } else if (n < N) { // N % 4 == 2: the last quad is half valid
+                *reinterpret_cast<unsigned*>(dst) = __builtin_bit_cast(unsigned, lo);
+            }
+        }
+    }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------------
+struct WoPlan {
+    int mt;  // 32-row tiles per pass (1, 2, 4, 8)
+    int ks;  // workgroups per column tile
+};
+
+static WoPlan wo_plan(int M, int N, int K, bool have_scratch)
+{
+    const int rows = M < 256 ? M : 256;
+    WoPlan pl{rows <= 32 ? 1 : rows <= 64 ? 2 : rows <= 128 ? 4 : 8, 1};
+    if (!have_scratch) return pl;
+    const int ntiles = (N + wo::BN - 1) / wo::BN, nst = (K + wo::KB - 1) / wo::KB;
+    // as many workgroups as keep the chip streaming (two per CU while the tile is small), at least 4 stages each
+    const int target = (pl.mt <= 2 ? 2 : 1) * num_cus();
+    int ks = target / ntiles;
+    if (ks > nst / 4) ks = nst / 4;
+    if (ks > 32) ks = 32;
+    pl.ks = ks >= 2 ? ks : 1;
+    return pl;
+}
+
+size_t w8a16_gemm_workspace_size(int M, int N, int K)
+{
+    if (M <= 4) return 0;
+    const WoPlan pl = wo_plan(M, N, K, true);
+    if (pl.ks <= 1) return 0;
+    const size_t ntiles = (size_t)(N + wo::BN - 1) / wo::BN;
+    return kSplitkWordsBytes + ntiles * pl.ks * (size_t)pl.mt * 16 * 256 * sizeof(float);
+}
+
+template <int MT, int NST, int WM = 1>
+static hipError_t launch_wo(const uint16_t* A, const uint8_t* Wq, const uint16_t* scale, uint16_t* Out, int M, int N,
+                            int K, int ks, void* scratch, const void* zeros, hipStream_t st)
+{
+    constexpr size_t lds = (size_t)NST * MT * 32 * wo::ROWB;
+    static_assert(lds <= 160 * 1024 - 64, "LDS budget");
+    auto kern = w8a16_gemm_kernel<MT, NST, WM>;
+    static DeviceOnce once;
+    if (hipError_t e = ensure_dynamic_lds(kern, lds, once); e != hipSuccess) return e;
+    const int ntiles = (N + wo::BN - 1) / wo::BN;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles * ks)), dim3(256 * WM), lds, st, A, Wq, scale, Out, M, N, K, ks, scratch,
+                       zeros);
+    return hipGetLastError();
+}
+
+hipError_t launch_w8a16_gemm(const void* A, const uint8_t* Wq, const void* scale, void* Out, int M, int N, int K,
+                             void* scratch, size_t scratch_bytes, const void* zeros, hipStream_t st)
+{
+    if (M <= 0 || N <= 0) return hipSuccess;
+    const uint16_t* a = static_cast<const uint16_t*>(A);
+    const uint16_t* s = static_cast<const uint16_t*>(scale);
+    uint16_t* o = static_cast<uint16_t*>(Out);
+    for (int m0 = 0; m0 < M; m0 += 256) { // 256-token passes (each streams the weights once)
+        const int rows = M - m0 < 256 ? M - m0 : 256;
+        const bool have = scratch != nullptr && scratch_bytes >= w8a16_gemm_workspace_size(rows, N, K) &&
+                          w8a16_gemm_workspace_size(rows, N, K) != 0;
+        const WoPlan pl = wo_plan(rows, N, K, have);
+        const uint16_t* ap = a + (int64_t)m0 * K;
+        uint16_t* op = o + (int64_t)m0 * N;
+        hipError_t e;
+        switch (pl.mt) {
+        case 1: e = launch_wo<1, 4>(ap, Wq, s, op, rows, N, K, pl.ks, scratch, zeros, st); break;
+        case 2: e = launch_wo<2, 4>(ap, Wq, s, op, rows, N, K, pl.ks, scratch, zeros, st); break;
+        case 4: e = launch_wo<4, 3, 2>(ap, Wq, s, op, rows, N, K, pl.ks, scratch, zeros, st); break;
+        default: e = launch_wo<8, 2, 2>(ap, Wq, s, op, rows, N, K, pl.ks, scratch, zeros, st); break;
+        }
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+} // namespace mixq

@@ -87,13 +87,10 @@ _GEMM_SCRATCH = {}
 _GEMM_SCRATCH_RETIRED = []  # superseded buffers stay alive: a HIP graph captured earlier still holds their pointers
 
 
-def gemm_scratch(t, M, N, K):
-    """Device scratch for the K split over workgroups (include/mixq.h, mixq_gemm_mixed_scratch): None when the shape does
-    not use it, else a zero-initialised buffer owned by (device, current stream) -- launches on one stream are ordered,
-    which is what the kernel's hand-over words need.  Never allocates while the stream is being captured."""
-    n = int(_lib.load().mixq_gemm_scratch_size(M, N, K))
-    if n == 0:
-        return None
+def _scratch_bytes(t, n):
+    """The zero-initialised exchange scratch of (device, current stream), at least ``n`` bytes, or None while the stream
+    is being captured and no buffer of that size exists yet.  Launches on one stream are ordered, which is what the
+    kernels' hand-over words need; every kernel leaves those words zero, so all of them share the one buffer."""
     key = (t.device.index, torch.cuda.current_stream(t.device).cuda_stream)
     buf = _GEMM_SCRATCH.get(key)
     if buf is None or buf.numel() < n:
@@ -101,11 +98,20 @@ def gemm_scratch(t, M, N, K):
             return None
         if buf is not None:
             _GEMM_SCRATCH_RETIRED.append(buf)
-        # sized once for every shape where that is affordable (the bound is ~56 MiB), so growth is the exception
+        # sized once for every int8 shape (the bound is ~56 MiB), so growth is the exception
         n = max(n, int(_lib.load().mixq_gemm_scratch_bound()))
         buf = torch.zeros(n, dtype=torch.uint8, device=t.device)
         _GEMM_SCRATCH[key] = buf
     return buf
+
+
+def gemm_scratch(t, M, N, K):
+    """Device scratch for the K split over workgroups (include/mixq.h, mixq_gemm_mixed_scratch): None when the shape does
+    not use it.  Never allocates while the stream is being captured."""
+    n = int(_lib.load().mixq_gemm_scratch_size(M, N, K))
+    if n == 0:
+        return None
+    return _scratch_bytes(t, n)
 
 
 def _fused(name, A, B, scale_row, scale_col, y, M, N, K):
@@ -303,13 +309,18 @@ def int8_matrix_to_half(int_ind):
 
 @_on_tensor_device
 def w8_a16_gemm(input, weight, scale):
-    """EETQ/csrc/eetpy.cpp:7-19 w8_a16_gemm: fp16 [m,k] x interleaved uint8 [k,n] -> fp16 [m,n]."""
+    """EETQ/csrc/eetpy.cpp:7-19 w8_a16_gemm: fp16 [m,k] x interleaved uint8 [k,n] -> fp16 [m,n].
+    m <= 4: batched GEMV; m > 4: the fpA_intB MFMA GEMM (fpA_intB_gemm_wrapper.cu:45-70), with the per-stream scratch
+    for its K split over workgroups."""
     _dev(input, weight, scale)
     m, k = input.shape
     n = scale.numel()
     out = torch.empty((m, n), dtype=torch.float16, device=input.device)
-    _lib.check(_lib.load().mixq_w8a16_gemm_forward(_p(input), _p(weight), _p(scale), _p(out), m, n, k, _st(input)),
-               "w8_a16_gemm")
+    lib = _lib.load()
+    nws = int(lib.mixq_w8a16_gemm_workspace_size(m, n, k))
+    scr = _scratch_bytes(input, nws) if nws else None
+    _lib.check(lib.mixq_w8a16_gemm_forward_ws(_p(input), _p(weight), _p(scale), _p(out), m, n, k, _p(scr),
+                                              scr.numel() if scr is not None else 0, _st(input)), "w8_a16_gemm")
     return out
 
 

@@ -454,18 +454,27 @@ ORACLE_API void mixq_oracle_eetq_preprocess(int64_t K, int64_t N, const int8_t* 
 ORACLE_API void mixq_oracle_w8a16_gemv(int64_t M, int64_t N, int64_t K, const uint16_t* A, const int8_t* Wq_rm,
                                        const uint16_t* scale, uint16_t* Out)
 {
-#pragma omp parallel for schedule(static)
-    for (int64_t n = 0; n < N; ++n) {
-        float sc = h2f(scale[n]);
-        for (int64_t m = 0; m < M; ++m) {
-            float s = 0.f;
-            for (int64_t k = 0; k < K; ++k) {
-                float w16 = h2f(f2h((float)Wq_rm[k * N + n] * sc));
-                s += h2f(A[m * K + k]) * w16;
+    /* any M: this is also the checker of the fpA_intB GEMM (M > 4).  Activations are converted once; per column the
+     * fp16-rounded weights are formed once and every row's dot product runs k = 0..K-1 in fp32. */
+    float* Af = (float*)malloc(sizeof(float) * (size_t)M * (size_t)K);
+    for (int64_t i = 0; i < M * K; ++i) Af[i] = h2f(A[i]);
+#pragma omp parallel
+    {
+        float* w16 = (float*)malloc(sizeof(float) * (size_t)K);
+#pragma omp for schedule(static)
+        for (int64_t n = 0; n < N; ++n) {
+            const float sc = h2f(scale[n]);
+            for (int64_t k = 0; k < K; ++k) w16[k] = h2f(f2h((float)Wq_rm[k * N + n] * sc));
+            for (int64_t m = 0; m < M; ++m) {
+                const float* a = Af + m * K;
+                float s = 0.f;
+                for (int64_t k = 0; k < K; ++k) s += a[k] * w16[k];
+                Out[m * N + n] = f2h(s);
             }
-            Out[m * N + n] = f2h(s);
         }
+        free(w16);
     }
+    free(Af);
 }
 
 /*

@@ -1,0 +1,135 @@
+"""GPU (-m gpu): the fpA_intB GEMM (fp16 activations x int8 weights, M > 4) through the C ABI against the oracle.
+
+Reference: weightonlykernel/fpA_intB_gemm_wrapper.cu:45-70 (m > SMALL_M_FAST_PATH -> ft::gemm_fp16_int) ->
+cutlass_kernels/fpA_intB_gemm/fpA_intB_gemm_template.h:441-552.  The weight operand is the reference's interleaved
+`qweight` exactly as stored (preprocess_weights image); the oracle works on the un-interleaved int8 matrix, so these
+tests also cover the layout.  Tolerance: the north-star 1e-3 (fp32 accumulation order is unspecified on both sides)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+REL_TOL = 1e-3
+
+
+def rel_err(got, want):
+    g, w = got.astype(np.float64), want.astype(np.float64)
+    return np.abs(g - w).max() / max(np.abs(w).max(), 1e-30)
+
+
+def make(M, N, K, seed):
+    rng = np.random.default_rng(seed)
+    q = rng.integers(-128, 128, size=(K, N), dtype=np.int8)
+    sc = (rng.random(N) * 1e-3 + 1e-4).astype(np.float16)
+    A = rng.standard_normal((M, K)).astype(np.float16)
+    return A, q, sc
+
+
+def interleave(q):
+    from mixq_tensorrt_llm_amd import _lib
+    out = np.empty(q.shape, np.uint8)
+    _lib.check(_lib.load().mixq_preprocess_weights_int8(out.ctypes.data, np.ascontiguousarray(q).ctypes.data,
+                                                        q.shape[0], q.shape[1]), "preprocess")
+    return out
+
+
+def run(A, qi, sc, N, scratch):
+    from mixq_tensorrt_llm_amd import _lib
+    lib = _lib.load()
+    M, K = A.shape
+    dev = torch.device("cuda:0")
+    a, w, s = torch.from_numpy(A).to(dev), torch.from_numpy(qi).to(dev), torch.from_numpy(sc).to(dev)
+    out = torch.full((M, N), float("nan"), dtype=torch.float16, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if scratch:
+        n = int(lib.mixq_w8a16_gemm_workspace_size(M, N, K))
+        ws = torch.zeros(max(n, 16384), dtype=torch.uint8, device=dev)
+        rc = lib.mixq_w8a16_gemm_forward_ws(a.data_ptr(), w.data_ptr(), s.data_ptr(), out.data_ptr(), M, N, K,
+                                            ws.data_ptr(), n, st)
+        assert rc == 0
+        first = out.clone()
+        for _ in range(3):  # same scratch again (hand-over words were left zero), same bits (fixed summation order)
+            out.fill_(float("nan"))
+            assert lib.mixq_w8a16_gemm_forward_ws(a.data_ptr(), w.data_ptr(), s.data_ptr(), out.data_ptr(), M, N, K,
+                                                  ws.data_ptr(), n, st) == 0
+            assert torch.equal(out, first)
+        assert int(ws[:16384].view(torch.int32).abs().sum()) == 0, "hand-over words not re-armed"
+        return first.cpu().numpy(), n
+    rc = lib.mixq_w8a16_gemm_forward(a.data_ptr(), w.data_ptr(), s.data_ptr(), out.data_ptr(), M, N, K, st)
+    assert rc == 0
+    return out.cpu().numpy(), 0
+
+
+@pytest.mark.parametrize("M", [5, 32, 128, 512])
+@pytest.mark.parametrize("N,K", [(12288, 4096), (3584, 18944)])
+def test_model_shapes(oracle, M, N, K):
+    """Llama-2-7B qkv and Qwen2-7B down projection, with and without the K split over workgroups."""
+    A, q, sc = make(M, N, K, M + N)
+    qi = interleave(q)
+    want = oracle.w8a16_gemv(A, q, sc)
+    got, nws = run(A, qi, sc, N, scratch=True)
+    assert np.isfinite(got).all() and rel_err(got, want) < REL_TOL
+    if N == 3584:
+        assert nws > 0, "28 column tiles on 256 CUs: the plan must split K"
+    got2, _ = run(A, qi, sc, N, scratch=False)
+    assert rel_err(got2, want) < REL_TOL
+
+
+@pytest.mark.parametrize("M,N,K", [(5, 2, 64), (7, 130, 192), (33, 258, 320), (64, 128, 4160), (65, 384, 128),
+                                   (129, 640, 1088), (255, 96, 704), (257, 256, 256), (300, 1026, 1600), (700, 136, 448)])
+def test_ragged_shapes(oracle, M, N, K):
+    """N not a multiple of the 128-column tile (and N % 4 == 2), K % 128 == 64, one K stage, M across the 32-row tile and
+    256-row pass boundaries."""
+    A, q, sc = make(M, N, K, M * 3 + N + K)
+    qi = interleave(q)
+    want = oracle.w8a16_gemv(A, q, sc)
+    for scratch in (False, True):
+        got, _ = run(A, qi, sc, N, scratch)
+        assert np.isfinite(got).all(), (M, N, K, scratch)
+        assert rel_err(got, want) < REL_TOL, (M, N, K, scratch)
+
+
+def test_exact_on_integer_data_and_row_independence(oracle):
+    """Integer-valued activations and unit scales: every partial sum is exact in fp32, so any summation order gives the
+    same bits -- the GEMM must equal the integer matrix product exactly; and rows are independent (permutation)."""
+    rng = np.random.default_rng(4)
+    M, N, K = 96, 512, 2048
+    q = rng.integers(-128, 128, size=(K, N), dtype=np.int8)
+    A = rng.integers(-4, 5, size=(M, K)).astype(np.float16)
+    sc = np.ones(N, np.float16)
+    qi = interleave(q)
+    want = (A.astype(np.int64) @ q.astype(np.int64)).astype(np.float32).astype(np.float16)
+    for scratch in (False, True):
+        got, _ = run(A, qi, sc, N, scratch)
+        assert np.array_equal(got.view(np.uint16), want.view(np.uint16))
+    perm = rng.permutation(M)
+    got_p, _ = run(np.ascontiguousarray(A[perm]), qi, sc, N, True)
+    assert np.array_equal(got_p.view(np.uint16), want[perm].view(np.uint16))
+
+
+def test_mixlib_twin_and_small_m_boundary(oracle):
+    """mixlib.w8_a16_gemm (EETQ/csrc/eetpy.cpp:7-19): M = 4 takes the GEMV, M = 5 the GEMM; both within tolerance of the
+    same oracle, and the first four rows of an M = 8 call agree with the M = 4 call to 1e-3."""
+    from mixq_tensorrt_llm_amd import mixlib
+    A, q, sc = make(8, 1024, 1024, 9)
+    qi = interleave(q)
+    want = oracle.w8a16_gemv(A, q, sc)
+    dev = torch.device("cuda:0")
+    w, s = torch.from_numpy(qi).to(dev), torch.from_numpy(sc).to(dev)
+    o4 = mixlib.w8_a16_gemm(torch.from_numpy(A[:4]).to(dev), w, s).cpu().numpy()
+    o5 = mixlib.w8_a16_gemm(torch.from_numpy(A[:5]).to(dev), w, s).cpu().numpy()
+    o8 = mixlib.w8_a16_gemm(torch.from_numpy(A).to(dev), w, s).cpu().numpy()
+    assert rel_err(o4, want[:4]) < REL_TOL and rel_err(o5, want[:5]) < REL_TOL and rel_err(o8, want) < REL_TOL
+    assert rel_err(o8[:4], o4) < REL_TOL
+
+
+def test_argument_validation():
+    from mixq_tensorrt_llm_amd import _lib
+    lib = _lib.load()
+    assert lib.mixq_w8a16_gemm_forward_ws(None, None, None, None, 8, 64, 64, None, 0, None) == 1   # bad argument
+    assert lib.mixq_w8a16_gemm_forward_ws(16, 16, 16, 16, 8, 64, 96, None, 0, None) == 2           # K % 64
+    assert lib.mixq_w8a16_gemm_forward_ws(16, 16, 16, 16, 8, 63, 64, None, 0, None) == 2           # odd N
+    assert lib.mixq_w8a16_gemm_workspace_size(4, 4096, 4096) == 0                                   # GEMV: no scratch

@@ -9,15 +9,15 @@ mkdir -p "$(dirname "$OUT")"
   echo "# power cap: $(rocm-smi --showmaxpower 2>/dev/null | grep -m1 -i 'max' | sed 's/  */ /g')"
   echo "# idle sample:"
   rocm-smi --showpower --showclocks 2>/dev/null | grep -E "Power|sclk|mclk|fclk" | sed 's/  */ /g' | tr '\n' ';'; echo
-  echo "# load: python tools/gemm_bench.py --what gemm --iters ${ITERS:-20000} $*"
+  echo "# load: python tools/gemm_bench.py --what gemm --iters ${ITERS:-60000} $*"
 } > "$OUT"
-python tools/gemm_bench.py --what gemm --iters "${ITERS:-20000}" "$@" > "$OUT.gemm.log" 2>&1 &
+python tools/gemm_bench.py --what gemm --iters "${ITERS:-60000}" "$@" > "$OUT.gemm.log" 2>&1 &
 PID=$!
 sleep 6   # import + clock ramp
-T0=$(date +%s.%N)
-for i in $(seq 1 "${SAMPLES:-12}"); do
-  NOW=$(date +%s.%N)
-  printf "t=%.1fs " "$(echo "$NOW - $T0" | bc)" >> "$OUT"
+T0=$(date +%s%N)
+for i in $(seq 1 "${SAMPLES:-16}"); do
+  NOW=$(date +%s%N)
+  printf "t=%d.%ds " $(( (NOW - T0) / 1000000000 )) $(( (NOW - T0) / 100000000 % 10 )) >> "$OUT"
   rocm-smi --showpower --showclocks --showtemp 2>/dev/null | grep -E "Power|sclk|mclk|fclk|junction" | sed 's/  */ /g' | tr '\n' ';' >> "$OUT"
   echo >> "$OUT"
   kill -0 $PID 2>/dev/null || break
