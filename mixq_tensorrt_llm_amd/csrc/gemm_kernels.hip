@@ -564,6 +564,7 @@ static int gemm_variant()
 
 static std::atomic<const char*> g_last_kernel{"none"}; // reporting only (bench.py's roofline.kernel)
 const char* last_gemm_kernel() { return g_last_kernel.load(std::memory_order_relaxed); }
+void note_gemm_kernel(const char* name) { g_last_kernel.store(name, std::memory_order_relaxed); }
 
 hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st)
 {

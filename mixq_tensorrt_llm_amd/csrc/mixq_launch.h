@@ -105,6 +105,7 @@ hipError_t launch_unpack_s4_columns(const uint8_t* weight, const int32_t* ind, i
 hipError_t launch_w8a16(const void* A, const uint8_t* Wq, const void* scale, void* Out, int M, int N, int K,
                         hipStream_t st);
 
+void note_gemm_kernel(const char* name);
 // fpA_intB GEMM (M > 4) on the interleaved qweight (w8a16_gemm_kernels.hip); scratch may be null (no K split)
 size_t w8a16_gemm_workspace_size(int M, int N, int K);
 hipError_t launch_w8a16_gemm(const void* A, const uint8_t* Wq, const void* scale, void* Out, int M, int N, int K,

@@ -289,6 +289,12 @@ hipError_t launch_quant_extract(void* A, int8_t* qA, void* sA, void* fpA, const 
     uint16_t* s = static_cast<uint16_t*>(sA);
     uint16_t* f = static_cast<uint16_t*>(fpA);
     const int nvec = K / 8;
+    // Decode batches (few rows: the launch is a chain of latencies, not a stream): a whole 256-thread block per row, so
+    // that a row is ONE load round trip of 1-4 vectors per lane instead of 8-16 on a single wavefront
+    if (M <= 64 && nvec > 64 * 2) {
+        if (nvec <= 256 * 2) return launch_qe<256, 2>(a, qA, s, f, ind, M, K, O, zero, st, zw);
+        if (nvec <= 256 * 4) return launch_qe<256, 4>(a, qA, s, f, ind, M, K, O, zero, st, zw);
+    }
     if (nvec <= 64 * 2) return launch_qe<64, 2>(a, qA, s, f, ind, M, K, O, zero, st, zw);
     if (nvec <= 64 * 4) return launch_qe<64, 4>(a, qA, s, f, ind, M, K, O, zero, st, zw);
     if (nvec <= 64 * 8) return launch_qe<64, 8>(a, qA, s, f, ind, M, K, O, zero, st, zw);
