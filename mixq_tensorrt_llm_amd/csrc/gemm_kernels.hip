@@ -522,6 +522,10 @@ static std::atomic<int> g_variant{-1};
 
 void set_gemm_variant(int v)
 {
+    if (v == 90 || v == 91) { // 90: split workgroups never wait for their partners (all but the last arriver defer), 91: default
+        set_splitk_patience(v == 90 ? 0u : 3000u);
+        return;
+    }
     if (v >= 70 && v <= 79) { // K split over workgroups (ping-pong kernel): 70 off, 72 / 74 / 78 forced factor, 79 automatic
         set_splitk_force(v == 79 ? -1 : v - 70);
         if (v == 70 || v == 79) set_xsplit_force(v == 79 ? -1 : 0);

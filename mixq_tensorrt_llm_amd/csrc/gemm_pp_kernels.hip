@@ -88,8 +88,8 @@ __device__ __forceinline__ void glds16_sbase(const char* sbase, unsigned voff, u
 //      S = 8 the two 32-column n tiles are permuted the same way by rank bit 2: a change of the staging offsets
 //      only), so that the share it will finish always sits in acc[0 .. NI-1][0 .. PJ-1];
 //   2. parks the other S-1 shares in p.splitk_ws (its own slot), waits for the write-through acknowledgements,
-//      publishes its arrival word, and stages its outlier operands while the others do the same;
-//   3. waits for the other arrival words, adds the S-1 foreign partial sums of its own share (64 / 96 / 112 loads per
+//      draws an arrival ticket, and stages its outlier operands while the others do the same;
+//   3. once all S tickets are drawn, adds the S-1 foreign partial sums of its own share (64 / 96 / 112 loads per
 //      lane, all in flight together, landing in the registers step 2 freed) and runs the usual epilogue on that share
 //      (S = 8: one 32x32 tile per wave, stored with 8-byte stores straight from the accumulator layout).
 // With more tiles than CUs, the first p.splitk_solo tiles (whole waves) are computed by one workgroup each inside the
@@ -101,10 +101,18 @@ __device__ __forceinline__ void glds16_sbase(const char* sbase, unsigned voff, u
 // `global_load sc1` is served coherently, per access, for any pair of XCDs -- no bulk L2 write-back / invalidate (a
 // release / acquire fence pair costs ~70k cycles per tile here), and the compiler tracks the loads (an asm load
 // consumed after a later s_waitcnt gets copied / spilled before its data has arrived).
-// The last workgroup of a group to finish its reads re-arms the group's arrival words for the next launch.
-// Progress: blocks are dispatched in id order, so at most one group is ever partially resident and every other group
-// completes and frees its CUs; the kernel needs S free CUs in total.  The wait is bounded and traps (a loud launch
-// failure, never a hang or a wrong result).
+//
+// NOBODY WAITS WITHOUT BOUND (round 2; round 1 span on the partners' arrival words and trapped after 2^23 polls, which
+// two concurrent split launches on different streams could turn into a circular wait and a dead context).  Words of a
+// tile: [0] tickets drawn, [1 + r] state of rank r's share (0 | DEFERRED | SEEN), [9] workgroups done.
+//   * The workgroup that draws the LAST ticket never waits: every partner has parked and acknowledged already.
+//   * Any other workgroup polls the ticket count for at most kSplitkPatience (wall clock); if the partners are not all
+//     there by then -- they may not even be resident: HIP promises nothing about dispatch order -- it also parks its OWN
+//     share, marks it DEFERRED (compare-and-swap against the last arriver's SEEN mark: exactly one of the two
+//     happens) and exits, freeing its CU.
+//   * The last arriver, after finishing its own share, finishes every DEFERRED share too: all S partial sums of such a
+//     share are in the scratch by then.  Every share is finished exactly once, by its owner or by the last arriver.
+// The last workgroup of a group to be done with the words re-arms them for the next launch.
 template <int EPI, bool HAS_O, bool HAS_Y, int ABL = 0, int SPLITK = 0>
 __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p)
 {
@@ -149,9 +157,11 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
     }
     const int jperm = (rank * PJ) & 3;                             // accumulator m tile jj <-> m tile jj ^ jperm
     const int iperm = S == 8 ? rank >> 2 : 0;                      // accumulator n tile ii <-> n tile ii ^ iperm
-    auto imap = [&](int ii) __attribute__((always_inline)) { return S == 8 ? (ii ^ iperm) : ii; };
+    // the epilogue runs on the share of rank `erank`: this workgroup's own, or -- last arriver only -- a deferred one
+    int ejperm = jperm, eiperm = iperm;
+    auto imap = [&](int ii) __attribute__((always_inline)) { return S == 8 ? (ii ^ eiperm) : ii; };
     const int nt = SPLITK && !solo ? NT : 8;                       // 32x32 accumulator tiles this workgroup finishes
-    auto jmap = [&](int jj) __attribute__((always_inline)) { return SPLITK ? (jj ^ jperm) : jj; };
+    auto jmap = [&](int jj) __attribute__((always_inline)) { return SPLITK ? (jj ^ ejperm) : jj; };
     int tile_m, tile_n;
     {
         constexpr int GROUP_M = 4;
@@ -302,9 +312,13 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
     // SPLITK bookkeeping words of this tile (16 per tile): [0..7] arrival, [8] workgroups done reading.  They live in the FIRST
     // kSplitkWordsBytes of the scratch whatever the shape, so that one scratch can serve launches of different shapes:
     // every launch leaves them zero, and no launch ever parks data there.
-    constexpr int SLOT = (S - 1) * NI * PJ * 16 * T; // dwords per (tile, rank) slot
+    constexpr int SLOT = S * NI * PJ * 16 * T; // dwords per (tile, rank) slot: share 0 = own (deferral only), 1.. = foreign
+    constexpr unsigned DEFERRED = 1u, SEEN = 2u;
     const int t_split = t_lin - n_solo; // index among the split tiles
-    unsigned* const words = SPLITK ? static_cast<unsigned*>(p.splitk_ws) + t_split * 16 : nullptr; // [0..7] arrival, [8] done
+    unsigned* const words = SPLITK ? static_cast<unsigned*>(p.splitk_ws) + t_split * 16 : nullptr; // [0] tickets, [1+r] state, [9] done
+    // workgroup-wide broadcast of lane 0's decisions: two words at the start of the store windows (the 160 KiB of LDS are
+    // all spoken for; the windows are idle until the epilogue, and every broadcast happens before it)
+    volatile unsigned* const sk_bcast = reinterpret_cast<volatile unsigned*>(smem + 2 * BUF);
     int* const ws = reinterpret_cast<int*>(static_cast<char*>(p.splitk_ws) + kSplitkWordsBytes);
     // ---- prologue: slice 0 completely, then stagger the groups ----------------------------------------------
     issue(0, k_begin, true);
@@ -337,6 +351,7 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
     // S = 8: the single tile (sh >> 2, sh & 3).  Share sh of rank r holds the tiles that rank r ^ sh finishes.
     auto share_i0 = [](int sh) { return S == 8 ? sh >> 2 : 0; };
     auto share_j0 = [](int sh) { return S == 8 ? sh & 3 : sh * PJ; };
+    bool am_last = false;
     if (SPLITK && !solo) {
         int* const mine = ws + ((size_t)t_split * S + rank) * SLOT + tid;
 #pragma unroll
@@ -347,12 +362,15 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
                 for (int x = 0; x < PJ; ++x)
 #pragma unroll
                     for (int e = 0; e < 16; ++e)
-                        __hip_atomic_store(mine + ((((sh - 1) * NI + i) * PJ + x) * 16 + e) * T,
+                        __hip_atomic_store(mine + (((sh * NI + i) * PJ + x) * 16 + e) * T,
                                            acc[share_i0(sh) + i][share_j0(sh) + x][e], __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every write-through acknowledged
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(words + rank, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0)
+            sk_bcast[0] = __hip_atomic_fetch_add(words, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // my ticket
+        __syncthreads();
+        am_last = sk_bcast[0] == (unsigned)(S - 1);
         stamp(3);
     }
 
@@ -405,17 +423,79 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    if (SPLITK && !solo) { // ---- add the other workgroups' partial sums of this workgroup's share
+    // ---- who finishes what.  Bit r of `todo`: this workgroup runs the epilogue on the share of rank r.
+    unsigned todo = 1u << rank;
+    if (SPLITK && !solo) {
         stamp(4);
-        if (tid < S && tid != rank) {
-            int spins = 0;
-            while (__hip_atomic_load(words + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1 << 23)) __builtin_trap(); // seconds: only a co-running kernel that never ends gets here
+        int* const mine = ws + ((size_t)t_split * S + rank) * SLOT + tid;
+        if (!am_last) {
+            // bounded wait for the remaining tickets (the partners were dispatched together with this workgroup in every
+            // observed case, so this is ~1-2 us; nothing below depends on that)
+            if (tid == 0) {
+                const unsigned long long t0 = wall_clock64();
+                unsigned seen;
+                for (;;) {
+                    seen = __hip_atomic_load(words, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (seen >= (unsigned)S || wall_clock64() - t0 >= (unsigned long long)p.splitk_patience) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                sk_bcast[1] = seen >= (unsigned)S ? 1u : 0u;
             }
+            __syncthreads();
+            bool all_here = sk_bcast[1] != 0u;
+            if (!all_here) { // defer: park the own share as well, then race the last arriver for its state word
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int x = 0; x < PJ; ++x)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e)
+                            __hip_atomic_store(mine + ((i * PJ + x) * 16 + e) * T, acc[i][x][e], __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) {
+                    unsigned expected = 0u;
+                    const bool mine_now = __hip_atomic_compare_exchange_strong(words + 1 + rank, &expected, DEFERRED,
+                                                                               __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                                               __HIP_MEMORY_SCOPE_AGENT);
+                    sk_bcast[1] = mine_now ? 0u : 1u; // lost to SEEN: the last arriver is here, so everybody is
+                }
+                __syncthreads();
+                all_here = sk_bcast[1] != 0u;
+                if (!all_here) { // deferred for good: the last arriver finishes this share.  Leave (whole workgroup).
+                    if (tid == 0) {
+                        const unsigned before = __hip_atomic_fetch_add(words + 9, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (before == (unsigned)(S - 1))
+#pragma unroll
+                            for (int w = 0; w < 10; ++w)
+                                __hip_atomic_store(words + w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    return;
+                }
+            }
+        } else { // last ticket: every partner has parked.  Mark the shares whose owners are still around as SEEN; the
+                 // ones found DEFERRED are this workgroup's to finish.
+            if (tid == 0) {
+                unsigned mask = 1u << rank;
+                for (int q = 0; q < S; ++q) {
+                    if (q == rank) continue;
+                    unsigned expected = 0u;
+                    if (!__hip_atomic_compare_exchange_strong(words + 1 + q, &expected, SEEN, __ATOMIC_RELAXED,
+                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                        mask |= 1u << q; // (expected == DEFERRED)
+                }
+                sk_bcast[1] = mask;
+            }
+            __syncthreads();
+            todo = sk_bcast[1];
         }
-        __syncthreads();
         stamp(5);
+    }
+
+    // ---- own share (still in registers): add the other workgroups' partial sums of it.  This is the common path and is
+    // kept exactly as it was before the deferral protocol: 64 / 96 / 112 loads per lane, all in flight together.
+    if (SPLITK && !solo) {
         int pk[S > 1 ? S - 1 : 1][NI][PJ][16];
 #pragma unroll
         for (int sh = 1; sh < S; ++sh) { // share sh of workgroup rank ^ sh is this workgroup's own share
@@ -426,7 +506,7 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
                 for (int x = 0; x < PJ; ++x)
 #pragma unroll
                     for (int e = 0; e < 16; ++e)
-                        pk[sh - 1][i][x][e] = __hip_atomic_load(theirs + ((((sh - 1) * NI + i) * PJ + x) * 16 + e) * T,
+                        pk[sh - 1][i][x][e] = __hip_atomic_load(theirs + (((sh * NI + i) * PJ + x) * 16 + e) * T,
                                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
 #pragma unroll
@@ -439,17 +519,19 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
                     for (int e = 0; e < 16; ++e) acc[i][x][e] += pk[sh - 1][i][x][e];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads(); // every wave of this workgroup has its data
-        if (tid == 0) {
-            const unsigned before = __hip_atomic_fetch_add(words + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (before == (unsigned)(S - 1)) { // the whole group is done reading: re-arm for the next launch
+        todo &= ~(1u << rank);
+        if (todo == 0u && tid == 0) { // done with the words and with everybody's parked sums
+            const unsigned before = __hip_atomic_fetch_add(words + 9, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (before == (unsigned)(S - 1)) { // the whole group is done: re-arm for the next launch
 #pragma unroll
-                for (int w = 0; w < 9; ++w) __hip_atomic_store(words + w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int w = 0; w < 10; ++w) __hip_atomic_store(words + w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         stamp(6);
     }
     if (!SPLITK || solo) stamp(3);
 
+    auto epilogue = [&]() __attribute__((always_inline)) {
     // ---- dequant math + stores, one 32 (m) x 64 (n) block of the wave tile at a time.  Results are packed to fp16 and
     // transposed through a wave-private 4-KiB LDS window (32 rows x 128 B; the 32 KiB above the slice buffers), then
     // written as 128-byte row segments (8 rows per store instruction).  No workgroup barrier is involved: LDS
@@ -624,6 +706,52 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    };
+    epilogue();
+    // ---- last arriver only: the shares whose owners deferred.  All S partial sums of such a share are parked (share
+    // w ^ erank of workgroup w; share 0 = the owner's own); the epilogue runs once more with that rank's tile mapping.
+    if (SPLITK && !solo && todo != 0u) {
+        while (todo != 0u) {
+            const int erank = __builtin_ctz(todo);
+            todo &= ~(1u << erank);
+            ejperm = (erank * PJ) & 3, eiperm = S == 8 ? erank >> 2 : 0;
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int x = 0; x < PJ; ++x)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][x][e] = 0;
+            for (int w = 0; w < S; ++w) {
+                const int* const theirs = ws + ((size_t)t_split * S + w) * SLOT + tid;
+                const int sh = w ^ erank;
+                int pk1[NI][PJ][16];
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int x = 0; x < PJ; ++x)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e)
+                            pk1[i][x][e] = __hip_atomic_load(theirs + (((sh * NI + i) * PJ + x) * 16 + e) * T,
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int x = 0; x < PJ; ++x)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[i][x][e] += pk1[i][x][e];
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (todo == 0u && tid == 0) {
+                const unsigned before = __hip_atomic_fetch_add(words + 9, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (before == (unsigned)(S - 1))
+#pragma unroll
+                    for (int w = 0; w < 10; ++w)
+                        __hip_atomic_store(words + w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            epilogue();
+        }
+    }
     if (!SPLITK || solo) {
         stamp(4);
         stamp(5);
@@ -670,6 +798,8 @@ int num_cus()
     return n;
 }
 
+static std::atomic<unsigned> g_splitk_patience{3000u}; // wall-clock ticks (100 MHz) = 30 us; 0: defer at once (tests)
+void set_splitk_patience(unsigned ticks) { g_splitk_patience.store(ticks); }
 static std::atomic<int> g_splitk_force{-1}; // -1 automatic, 0 off, 2 / 4: that factor wherever the shape allows it
 void set_splitk_force(int v) { g_splitk_force.store(v); }
 
@@ -718,9 +848,9 @@ SplitPlan gemm_splitk_plan(int M, int N, int K)
 
 int gemm_splitk_factor(int M, int N, int K) { return gemm_splitk_plan(M, N, K).s; }
 
-static size_t splitk_slot_bytes(int s) // (S - 1) shares of a 256x256 int32 tile's 1/S-th
-{
-    return (size_t)(s - 1) * (pp::BM * pp::BN * 4 / s);
+static size_t splitk_slot_bytes(int) // S shares of a 256x256 int32 tile's 1/S-th: the S - 1 foreign ones + the own share,
+{                                      // which is parked only when a workgroup defers (see the kernel header)
+    return (size_t)pp::BM * pp::BN * 4;
 }
 
 size_t gemm_splitk_workspace_size(int M, int N, int K)
@@ -761,6 +891,7 @@ hipError_t launch_gemm_pp_splitk(const GemmParams& p_in, int epi, hipStream_t st
     if (s == 0 || p_in.splitk_ws == nullptr) return hipErrorInvalidValue;
     GemmParams p = p_in;
     p.splitk_solo = pl.solo;
+    p.splitk_patience = g_splitk_patience.load();
     switch (epi) {
     case EPI_DEQUANT:
         return s == 8   ? launch_pp_splitk_epi<EPI_DEQUANT, 8>(p, st)

@@ -53,6 +53,8 @@ struct GemmParams {
     void* dbg;            // measurement only: 8 x uint64 s_memtime stamps per block (ping-pong kernel), else null
     int xsplit;           // (set by launch_epi) workgroups per tile of the small-tile kernels' K split, else 0
     int splitk_solo;      // (set by launch_gemm_pp_splitk) leading tiles that are not split
+    unsigned splitk_patience; // (set by launch_gemm_pp_splitk) wall-clock ticks a workgroup waits for its partners before
+                              // it defers its share to the last arriver
     void* splitk_ws;      // device scratch of gemm_splitk_workspace_size bytes whose arrival words are zero, or null: lets
                           // launch_gemm split K over 2 / 4 workgroups per 256x256 tile when the tiles alone cover at
                           // most half / a quarter of the CUs (gemm_pp_kernels.hip)
@@ -70,6 +72,7 @@ int gemm_splitk_factor(int M, int N, int K);              // = plan.s
 size_t gemm_splitk_workspace_size(int M, int N, int K);   // 0: the shape does not use the split form (or it is off)
 size_t gemm_splitk_workspace_bound();                     // max of the above over all shapes (for workspace sizing)
 hipError_t launch_gemm_pp_splitk(const GemmParams& p, int epi, hipStream_t st);
+void set_splitk_patience(unsigned ticks); // test knob: 0 = every workgroup but the last arriver defers at once
 void set_splitk_force(int v); // -1 automatic (default), 0 off, 2 / 4: that factor wherever the shape allows it
 // the same idea for the small-tile kernels with in-workgroup split (gemm_kernels.hip, XS): few tiles, long K
 int gemm_xsplit_factor(int M, int N, int K);              // 0 / 2 / 4 / 8 / 16

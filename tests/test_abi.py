@@ -97,9 +97,9 @@ def test_workspace_sizes_are_size_t_clean(lib):
     ws = lib.mixq_workspace_size(h, M, N, K)
     need = M * K + 2 * M + 2 * 128 * M
     # the K-split exchange scratch is sized for THIS N, K and every M <= maxM (it was a flat 56 MiB in round 1):
-    # at most one 224-KiB slot per CU + the hand-over words, and nothing at all for most shapes
+    # at most one 256-KiB slot per CU + the hand-over words, and nothing at all for most shapes
     bound = lib.mixq_gemm_scratch_bound()
-    assert bound == 256 * 7 * 32768 + 16384
+    assert bound == 256 * 262144 + 16384   # one 256-KiB slot per CU (S shares of a tile's 1/S-th) + the hand-over words
     worst = max(lib.mixq_gemm_scratch_size(m, N, K) for m in range(256, M + 1, 256))
     assert need + worst <= ws <= need + worst + 5 * 128 + 128 and worst <= bound
     assert lib.mixq_workspace_size(h, 64, 4096, 4096) <= 64 * 4096 + 2 * 64 + 2 * 64 * 128 + 5 * 128  # no split form: no scratch
@@ -107,8 +107,8 @@ def test_workspace_sizes_are_size_t_clean(lib):
     xsplit = 16384 + 256 * 64 * 64 * 4            # below 256 rows: the small-tile form's scratch (256 workgroups x 16 KiB)
     assert lib.mixq_workspace_size(h, 128, N, K) <= 128 * K + 2 * 128 + 2 * 128 * 128 + xsplit + 5 * 128 + 128
     assert lib.mixq_workspace_size(h, 4, N, K) <= 4 * K + 8 + 8 * 128 + 4 * 128 + 128     # decode: none
-    assert lib.mixq_gemm_scratch_size(1024, 4096, 11008) == 16384 + 64 * 3 * 262144   # 4 workgroups per tile
-    assert lib.mixq_gemm_scratch_size(2048, 4096, 4096) == 16384 + 128 * 1 * 262144  # 2 workgroups per tile
+    assert lib.mixq_gemm_scratch_size(1024, 4096, 11008) == 16384 + 64 * 4 * 262144   # 4 workgroups per tile, a 256-KiB slot each
+    assert lib.mixq_gemm_scratch_size(2048, 4096, 4096) == 16384 + 128 * 2 * 262144  # 2 workgroups per tile
     assert lib.mixq_gemm_scratch_size(8192, 12288, 4096) == 0 and lib.mixq_gemm_scratch_size(64, 4096, 4096) == 0
     # 1M tokens x 11008: the reference's int arithmetic overflows here
     big = lib.mixq_workspace_size(h, 1 << 20, 4096, 11008)

@@ -58,7 +58,7 @@ def test_split_form_gives_the_bits_of_the_one_workgroup_form(lib, factor, M, N, 
     lib.mixq_debug_set_gemm_variant(70 + factor)
     n = lib.mixq_gemm_scratch_size(M, N, K)
     tiles = ((M + 255) // 256) * ((N + 255) // 256)
-    assert n == 16384 + tiles * (factor - 1) * 262144   # hand-over words + (S - 1) x 256 KiB per split tile
+    assert n == 16384 + tiles * factor * 262144   # hand-over words + S slots of 256 KiB per split tile
     scr = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
     for round_ in range(3):   # the same scratch again and again: the last reader of every tile re-arms its words
         out = torch.full((M, N), float("nan"), dtype=torch.float16, device="cuda:0")
@@ -92,7 +92,7 @@ def test_whole_waves_solo_plus_split_tail_in_one_launch(lib, factor, M, N, K):
     lib.mixq_debug_set_gemm_variant(70 + factor)
     n = lib.mixq_gemm_scratch_size(M, N, K)
     tail = tiles % cus
-    assert n == 16384 + tail * (factor - 1) * 262144
+    assert n == 16384 + tail * factor * 262144
     scr = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
     for _ in range(3):
         out = torch.full((M, N), float("nan"), dtype=torch.float16, device="cuda:0")
@@ -157,7 +157,7 @@ def test_automatic_choice_and_graph_replay(lib):
     M, N, K, O = 1024, 4096, 11008, 128
     lib.mixq_debug_set_gemm_variant(79)
     n = lib.mixq_gemm_scratch_size(M, N, K)
-    assert n == 16384 + 64 * 3 * 262144
+    assert n == 16384 + 64 * 4 * 262144
     qA, W, sA, sW, fpA, fpW = operands(M, N, K, O, seed=1)
     ref = torch.empty((M, N), dtype=torch.float16, device="cuda:0")
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -196,10 +196,75 @@ def test_mixlib_wrappers_pick_up_a_per_stream_scratch(lib):
     assert torch.equal(got, ref)
 
 
+@pytest.mark.parametrize("factor", [2, 4, 8])
+@pytest.mark.parametrize("M,N,K", SHAPES[:3] + [(2048, 8448, 2176)])
+def test_nobody_waits_every_workgroup_but_the_last_arriver_defers(lib, factor, M, N, K):
+    """Patience 0 (variant 90): a workgroup that does not find all its partners' tickets at its first look parks its own
+    share too, marks it DEFERRED and leaves; the last arriver of the tile finishes every deferred share.  Same bits, words
+    re-armed -- the path a launch takes when its workgroups are NOT co-resident (HIP promises no dispatch order)."""
+    if factor == 8:
+        K = 2 * K + 16
+    O = 128
+    qA, W, sA, sW, fpA, fpW = operands(M, N, K, O, seed=M + N + K + 1)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ref = torch.empty((M, N), dtype=torch.float16, device="cuda:0")
+    assert lib.mixq_gemm_mixed(p(qA), p(W), p(sA), p(sW), p(fpA), p(fpW), p(ref), M, N, K, O, st) == 0
+    lib.mixq_debug_set_gemm_variant(70 + factor)
+    n = lib.mixq_gemm_scratch_size(M, N, K)
+    if n == 0:
+        pytest.skip("this factor does not apply to the shape")
+    scr = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
+    try:
+        for patience in (90, 91, 90):   # deferring, default, deferring again on the same scratch
+            lib.mixq_debug_set_gemm_variant(patience)
+            for round_ in range(4):
+                out = torch.full((M, N), float("nan"), dtype=torch.float16, device="cuda:0")
+                assert lib.mixq_gemm_mixed_scratch(p(qA), p(W), p(sA), p(sW), p(fpA), p(fpW), p(out), M, N, K, O, p(scr), n,
+                                                   st) == 0
+                torch.cuda.synchronize()
+                assert torch.equal(out, ref), (patience, round_)
+            assert int(scr[:16384].to(torch.int32).sum()) == 0, "hand-over words left non-zero"
+    finally:
+        lib.mixq_debug_set_gemm_variant(91)
+
+
+def test_split_launches_on_two_streams_under_a_cu_hog_1000_iterations(lib):
+    """VERDICT r1 item 7 / ADVICE r1: two split launches on two streams (a scratch each) while a long-running stream of
+    large GEMMs occupies the CUs: 1000 iterations, no trap (there is none any more), bit-identical results."""
+    M, N, K, O = 1024, 4096, 11008, 128
+    lib.mixq_debug_set_gemm_variant(79)
+    n = lib.mixq_gemm_scratch_size(M, N, K)
+    assert n > 0
+    qA, W, sA, sW, fpA, fpW = operands(M, N, K, O, seed=31)
+    ref = torch.empty((M, N), dtype=torch.float16, device="cuda:0")
+    st0 = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.mixq_gemm_mixed(p(qA), p(W), p(sA), p(sW), p(fpA), p(fpW), p(ref), M, N, K, O, st0) == 0
+    torch.cuda.synchronize()
+    hog, s1, s2 = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    x = torch.randn((8192, 8192), device="cuda:0", dtype=torch.float16)
+    scr = [torch.zeros(n, dtype=torch.uint8, device="cuda:0") for _ in range(2)]
+    out = [torch.empty((M, N), dtype=torch.float16, device="cuda:0") for _ in range(2)]
+    bad = 0
+    for it in range(1000):
+        if it % 4 == 0:
+            with torch.cuda.stream(hog):
+                y = (x @ x).clamp_(-1, 1)   # ~1 ms of every CU, on its own queue
+        for which, stream in enumerate((s1, s2)):
+            assert lib.mixq_gemm_mixed_scratch(p(qA), p(W), p(sA), p(sW), p(fpA), p(fpW), p(out[which]), M, N, K, O,
+                                               p(scr[which]), n, ctypes.c_void_p(stream.cuda_stream)) == 0
+        if it % 100 == 99:
+            torch.cuda.synchronize()
+            bad += int(not torch.equal(out[0], ref)) + int(not torch.equal(out[1], ref))
+    torch.cuda.synchronize()
+    del y
+    assert bad == 0 and torch.equal(out[0], ref) and torch.equal(out[1], ref)
+    assert int(scr[0][:16384].to(torch.int32).sum()) == 0 and int(scr[1][:16384].to(torch.int32).sum()) == 0
+
+
 def test_split_form_next_to_other_work_on_the_gpu(lib):
-    """The groups of a split tile wait for each other, so the protocol must make progress when the kernel does not get
-    the whole chip: (a) behind / next to large one-workgroup-per-tile GEMMs on another stream, (b) two split GEMMs on two
-    streams with a scratch each.  Every result must still be the plain kernel's bits."""
+    """The protocol must make progress when the kernel does not get the whole chip: (a) behind / next to large
+    one-workgroup-per-tile GEMMs on another stream, (b) two split GEMMs on two streams with a scratch each.  Every result
+    must still be the plain kernel's bits."""
     M, N, K, O = 1024, 4096, 11008, 128
     lib.mixq_debug_set_gemm_variant(79)
     n = lib.mixq_gemm_scratch_size(M, N, K)
