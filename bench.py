@@ -223,24 +223,43 @@ class Model:
                 t = synth_layer(N, K, dev, gen, n0, n1)
                 if K not in self.acts:  # 8 rotating chunks per K (>1 GB: never resident in the 256 MiB Infinity Cache)
                     self.acts[K] = [synth_activation(chunk, K, t["ind_i32"], dev, gen) for _ in range(8)]
-                if (n1 - n0) not in self.outs:
-                    self.outs[n1 - n0] = torch.empty((chunk, n1 - n0), dtype=torch.float16, device=dev)
-                out = self.outs[n1 - n0]
+                if (n1 - n0) not in self.outs:  # TP: two buffers per shape, so that the gather of call i overlaps GEMM i + 1
+                    self.outs[n1 - n0] = [torch.empty((chunk, n1 - n0), dtype=torch.float16, device=dev)
+                                          for _ in range(2 if tp > 1 else 1)]
+                out = self.outs[n1 - n0][0]
                 ins = [self.acts[K][0], t["weight"], t["weights_scaling_factor"], t["fp_weight"], t["fp_ind"],
                        t["qweight"], t["weights_scaling_factor"]]
                 in_desc = (TensorDesc * 7)(*[TensorDesc.make(x.shape) for x in ins])
                 out_desc = TensorDesc.make(out.shape)
                 in_ptrs = [(ctypes.c_void_p * 7)(*([a.data_ptr()] + [x.data_ptr() for x in ins[1:]]))
                            for a in self.acts[K]]
-                out_ptrs = (ctypes.c_void_p * 1)(out.data_ptr())
+                out_ptrs = [(ctypes.c_void_p * 1)(o.data_ptr()) for o in self.outs[n1 - n0]]
                 h = lib.mixq_create(chunk, n1 - n0, K)
                 max_ws = max(max_ws, lib.mixq_workspace_size(h, chunk, n1 - n0, K))
-                self.calls.append((ctypes.c_void_p(h), in_desc, out_desc, in_ptrs, out_ptrs, n1 - n0, K, out, N))
+                self.calls.append((ctypes.c_void_p(h), in_desc, out_desc, in_ptrs, out_ptrs, n1 - n0, K,
+                                   self.outs[n1 - n0], N))
                 self.keep.append((t, ins))
         self.workspace = torch.empty(max_ws, dtype=torch.uint8, device=dev)
         self.ws_ptr = ctypes.c_void_p(self.workspace.data_ptr())
+        self.gatherers = {}    # N -> parallel.PeerGather (tp > 1, peer-write transport)
+        self.transport = None
+        self.n_call = 0
+        self.gather_done = [None, None]   # event of the last gather that READ output buffer 0 / 1
+
+    def open_peer_transport(self, parallel, rank, group=None):
+        """One-sided peer writes over xGMI for the output all-gather (csrc/tp_kernels.hip); falls back to RCCL."""
+        try:
+            for N in sorted({c[8] for c in self.calls}):
+                self.gatherers[N] = parallel.PeerGather(self.chunk, N, self.tp, rank, self.dev, group)
+            self.transport = "peer writes over xGMI (mixq_tp_push_columns + flags), data lands in place"
+        except Exception as e:  # noqa: BLE001
+            self.gatherers = {}
+            self.transport = f"rccl all_gather_into_tensor + column placement (peer transport unavailable: {e!r})"
 
     def close(self):
+        for g in self.gatherers.values():
+            g.close()
+        self.gatherers = {}
         for c in self.calls:
             self.lib.mixq_destroy(c[0])
         self.calls, self.keep = [], []
@@ -341,23 +360,34 @@ def main():
 
     def one_step(model, group, events=None):
         ei = 0
-        for (h, in_desc, out_desc, in_ptrs_list, out_ptrs, n_loc, K, out, N), c in schedule(model):
+        for (h, in_desc, out_desc, in_ptrs_list, out_ptrs, n_loc, K, outs, N), c in schedule(model):
             in_ptrs = in_ptrs_list[c % len(in_ptrs_list)]   # rotate the activation buffers of this K
             e0 = e1 = None
             if events is not None:
                 e0, e1 = events[ei]
                 ei += 1
-            rc = lib.mixq_enqueue_profiled(h, in_desc, ctypes.byref(out_desc), in_ptrs, out_ptrs, model.ws_ptr, st_ptr,
-                                           e0, e1)
+            par = model.n_call & 1 if model.tp > 1 else 0
+            model.n_call += 1
+            if model.tp > 1 and model.gather_done[par] is not None:
+                stream.wait_event(model.gather_done[par])   # the gather that read this output buffer two calls ago
+            rc = lib.mixq_enqueue_profiled(h, in_desc, ctypes.byref(out_desc), in_ptrs, out_ptrs[par], model.ws_ptr,
+                                           st_ptr, e0, e1)
             if rc != 0:
                 raise _lib.MixQError(rc, "mixq_enqueue")
             if model.tp > 1:
-                # the ONE collective of the path: all-gather the fp16 output columns, overlapped with the next call's
-                # compute on a side stream; the operator's output buffer is consumed before it is reused
+                # the ONE collective of the path: all-gather of the fp16 output columns on a side stream -- it overlaps
+                # the next call's GEMM, which writes the other output buffer
                 comm_stream.wait_stream(stream)
                 with torch.cuda.stream(comm_stream):
-                    model.full[N] = parallel.all_gather_columns(out, group, model.tp)
-                stream.wait_stream(comm_stream)
+                    if N in model.gatherers:
+                        model.full[N] = model.gatherers[N].gather(outs[par])
+                    else:
+                        model.full[N] = parallel.all_gather_columns(outs[par], group, model.tp)
+                    ev = torch.cuda.Event()
+                    ev.record(comm_stream)
+                model.gather_done[par] = ev
+        if model.tp > 1:
+            stream.wait_stream(comm_stream)
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -390,6 +420,8 @@ def main():
 
     # ---- main measurement ------------------------------------------------------------------------------------
     model = Model(lib, TensorDesc, parallel, dev, gen, chunk, tp, tp_rank)
+    if tp > 1:
+        model.open_peer_transport(parallel, tp_rank, tp_group)
     elapsed, median_ms, events, launches_per_step = timed_run(model, tp_group, args.steps, args.warmup, True)
 
     # ---- roofline of the dominant kernel (fused int8 GEMM), from the events recorded inside the timed region ----
@@ -494,13 +526,16 @@ def main():
             torch.cuda.empty_cache()
             assert dist.get_world_size() == world, "RCCL world size"
             tmodel = Model(lib, TensorDesc, parallel, dev, gen, chunk, world, rank, acts=acts)
+            tmodel.open_peer_transport(parallel, rank)
             t_el, t_med, _, _ = timed_run(tmodel, None, args.tp_steps, 1, False)
+            timed_out = any(g.timed_out() for g in tmodel.gatherers.values())
             recv = sum((world - 1) * args.tokens * (c[8] // world) * 2 for c in tmodel.calls)
             tp_obj = {"tp": world, "world_size": world, "backend": backend,
                       "value": args.tokens * args.tp_steps / t_el, "unit": "tokens/s",
                       "ms_per_step": t_el / args.tp_steps * 1e3, "median_ms_per_step": t_med, "steps": args.tp_steps,
-                      "warmup": 1, "scaling": "strong", "collective": "all_gather_into_tensor + column placement "
-                      "(parallel.all_gather_columns), one per linear per chunk, on a side stream",
+                      "warmup": 1, "scaling": "strong",
+                      "collective": "one all-gather of the fp16 output per linear per chunk, on a side stream (overlaps "
+                                    "the next GEMM)", "transport": tmodel.transport, "peer_wait_timed_out": timed_out,
                       "allgather_recv_GB_per_gpu_per_step": recv / 1e9,
                       "tokens_per_step": args.tokens}
         except Exception as e:  # noqa: BLE001 -- the main measurement must survive

@@ -262,6 +262,27 @@ MIXQ_API int mixq_unpack_int4_to_fp16(const uint8_t* weight, const int32_t* ind,
 /* Sign-extending unpack of a packed int4 buffer (packed_bytes % 16 == 0) to int8 -- e.g. once per layer at load time. */
 MIXQ_API int mixq_unpack_int4_to_int8(const uint8_t* src, int8_t* dst, size_t packed_bytes, void* stream);
 
+/* ---- multi-GPU: rows of W sharded over the GPUs of a node --------------------------------------------- */
+/* The path's ONE collective -- all-gather of the fp16 output columns, only where TP > 1 -- as one-sided peer writes over
+ * xGMI (csrc/tp_kernels.hip).  The reference has no working counterpart (plugin.py:155-156 calls allreduce after an
+ * N-split and is guarded off by `assert tp_size == 1`, tensorrt_llm/quantization/quantize.py:342).
+ * One process per GPU.  Every rank allocates its destination buffer(s) with mixq_tp_buffer_alloc (hipMalloc, zeroed;
+ * returns the device pointer and a 64-byte hipIpcMemHandle_t), ships the handle to its peers over any host channel
+ * (torch.distributed in parallel.PeerGather), and opens the peers' handles with mixq_tp_buffer_open: from then on the
+ * peers' buffers are plain device pointers in this process. */
+MIXQ_API int mixq_tp_buffer_alloc(size_t bytes, void** dev_ptr, void* ipc_handle_64);
+MIXQ_API int mixq_tp_buffer_open(const void* ipc_handle_64, void** dev_ptr);
+MIXQ_API int mixq_tp_buffer_close(void* dev_ptr); /* a pointer from mixq_tp_buffer_open */
+MIXQ_API int mixq_tp_buffer_free(void* dev_ptr);  /* a pointer from mixq_tp_buffer_alloc */
+/* src fp16 [M, n_local] (this rank's operator output) -> columns [col0, col0 + n_local) of the fp16 [M, N] buffer of each
+ * of the ndst <= 8 destinations (own rank included), then dst_flags[r][0] = seq (system-scope release) for every r.
+ * done_counter: one zeroed device word of this rank (left zero).  n_local, N, col0 multiples of 8. */
+MIXQ_API int mixq_tp_push_columns(const void* src, void* const* dst_bases, void* const* dst_flags, int ndst, int M,
+                                  int n_local, int N, int col0, uint32_t seq, void* done_counter, void* stream);
+/* Makes `stream` wait until flags[0 .. n) (this rank's flag array, one word per producer) all equal seq; gives up after
+ * ~2 s and sets *timeout_flag = 1 (a device word the host may poll) rather than hanging the stream. */
+MIXQ_API int mixq_tp_wait(const void* flags, int n, uint32_t seq, void* timeout_flag, void* stream);
+
 /* ---- host helpers ----------------------------------------------------------------------------- */
 /* preprocess_weights (weightonlykernel/cutlass_kernels/cutlass_preprocessors.cc:536-545), int8, arch 80-90:
  * row-major int8 [rows=K, cols=N] -> interleaved uint8.  Host memory.  And its inverse. */

@@ -704,6 +704,65 @@ int mixq_enqueue_profiled(const mixq_handle* h, const mixq_tensor_desc* inputDes
     return enqueue_impl(h, inputDesc, inputs, outputs, workspace, stream, ev_gemm_start, ev_gemm_stop);
 }
 
+// ------------------------------------------------------------------------------ multi-GPU ----
+int mixq_tp_buffer_alloc(size_t bytes, void** dev_ptr, void* ipc_handle_64)
+{
+    if (!dev_ptr || !ipc_handle_64 || bytes == 0) return MIXQ_E_BADARG;
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size is part of the ABI");
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) return MIXQ_E_HIP;
+    if (hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        (void)hipFree(p);
+        return MIXQ_E_HIP;
+    }
+    hipIpcMemHandle_t h;
+    if (hipIpcGetMemHandle(&h, p) != hipSuccess) {
+        (void)hipFree(p);
+        return MIXQ_E_HIP;
+    }
+    std::memcpy(ipc_handle_64, &h, sizeof(h));
+    *dev_ptr = p;
+    return MIXQ_OK;
+}
+
+int mixq_tp_buffer_open(const void* ipc_handle_64, void** dev_ptr)
+{
+    if (!ipc_handle_64 || !dev_ptr) return MIXQ_E_BADARG;
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, ipc_handle_64, sizeof(h));
+    void* p = nullptr;
+    if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) return MIXQ_E_HIP;
+    *dev_ptr = p;
+    return MIXQ_OK;
+}
+
+int mixq_tp_buffer_close(void* dev_ptr) { return dev_ptr ? hip_rc(hipIpcCloseMemHandle(dev_ptr)) : MIXQ_E_BADARG; }
+int mixq_tp_buffer_free(void* dev_ptr) { return dev_ptr ? hip_rc(hipFree(dev_ptr)) : MIXQ_E_BADARG; }
+
+int mixq_tp_push_columns(const void* src, void* const* dst_bases, void* const* dst_flags, int ndst, int M, int n_local,
+                         int N, int col0, uint32_t seq, void* done_counter, void* stream)
+{
+    if (!src || !dst_bases || !dst_flags || !done_counter || ndst < 1 || ndst > 8 || M < 0 || n_local <= 0 || N <= 0 ||
+        col0 < 0 || col0 + n_local > N)
+        return MIXQ_E_BADARG;
+    if (n_local % 8 || N % 8 || col0 % 8) return MIXQ_E_SHAPE;
+    if (!aligned16(src)) return MIXQ_E_ALIGN;
+    unsigned* flags[8];
+    for (int r = 0; r < ndst; ++r) {
+        if (!dst_bases[r] || !dst_flags[r] || !aligned16(dst_bases[r])) return MIXQ_E_BADARG;
+        flags[r] = static_cast<unsigned*>(dst_flags[r]);
+    }
+    return hip_rc(mixq::launch_tp_push(src, dst_bases, flags, ndst, M, n_local, N, col0, seq,
+                                       static_cast<unsigned*>(done_counter), static_cast<hipStream_t>(stream)));
+}
+
+int mixq_tp_wait(const void* flags, int n, uint32_t seq, void* timeout_flag, void* stream)
+{
+    if (!flags || !timeout_flag || n < 1 || n > 8) return MIXQ_E_BADARG;
+    return hip_rc(mixq::launch_tp_wait(static_cast<const unsigned*>(flags), n, seq, static_cast<unsigned*>(timeout_flag),
+                                       static_cast<hipStream_t>(stream)));
+}
+
 // ------------------------------------------------------------------------------------- host helpers ----
 static inline size_t swap12(size_t x) { return (x & ~(size_t)3) | ((x & 1) << 1) | ((x & 2) >> 1); }
 

@@ -9,6 +9,7 @@ Every tensor that is per-output-feature is sharded the same way: W int8 [N,K], s
 decode ``qweight`` [K,N] (by column pairs).  ``fp_ind`` and the activations are replicated; the per-token
 quantisation pre-pass is recomputed on every rank (HBM-bound, no communication).
 """
+import ctypes
 from typing import Dict, Tuple
 
 import numpy as np
@@ -74,3 +75,97 @@ def all_gather_columns(x_local: torch.Tensor, group=None, tp_size: int = None) -
     dist.all_gather_into_tensor(gathered, x2, group=group)  # rank-major concatenation along dim 0
     full = gathered.view(tp_size, x2.shape[0], n_loc).permute(1, 0, 2).reshape(x2.shape[0], tp_size * n_loc)
     return full.reshape(*lead, tp_size * n_loc).to(dev)
+
+
+class _RawDeviceBuffer:
+    """A device allocation of the library seen through ``__cuda_array_interface__`` (zero-copy torch view)."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+class PeerGather:
+    """All-gather of the output columns as ONE-SIDED PEER WRITES over xGMI (csrc/tp_kernels.hip, include/mixq.h
+    ``mixq_tp_*``): every rank writes its [M, N/tp] block straight into its column block of every rank's [M, N] buffer,
+    so the gathered tensor lands in its final layout -- no rank-major staging, no permute pass -- and all 7 links of a GPU
+    carry traffic at once.  Completion travels as a sequence number in the consumer's flag array; the consumer's STREAM
+    waits for it (no host sync), so the call is graph-capturable and overlaps with whatever runs on other streams.
+
+    Two destination buffers alternate by call parity.  Contract: whatever reads the tensor returned by call i must be
+    enqueued on the same stream before call i + 1 (then a fast rank can never overwrite data a slow rank still reads:
+    it needs the slow rank's flag of call i + 1 before its own call i + 2 is pushed, and the slow rank publishes that
+    flag only after its readers of call i, which are earlier in its stream).
+
+    One process per GPU; the buffers are exchanged as 64-byte IPC handles through ``torch.distributed`` (any backend)."""
+
+    def __init__(self, max_m: int, n_total: int, tp_size: int, rank: int, device, group=None):
+        from . import _lib
+        assert n_total % tp_size == 0 and (n_total // tp_size) % 8 == 0 and 1 < tp_size <= 8
+        self.lib = _lib.load()
+        self.dev = torch.device(device)
+        self.M, self.N, self.tp, self.rank = int(max_m), int(n_total), int(tp_size), int(rank)
+        self.n_loc = self.N // self.tp
+        self.data_bytes = (self.M * self.N * 2 + 255) // 256 * 256
+        self.nbytes = self.data_bytes + 256                 # + the flag array (one word per producer)
+        self.seq = 0
+        self.own, handles = [], []
+        with torch.cuda.device(self.dev):
+            for _ in range(2):
+                ptr = ctypes.c_void_p()
+                h = ctypes.create_string_buffer(64)
+                _lib.check(self.lib.mixq_tp_buffer_alloc(self.nbytes, ctypes.byref(ptr), h), "mixq_tp_buffer_alloc")
+                self.own.append(ptr.value)
+                handles.append(h.raw)
+        everyone = [None] * self.tp
+        dist.all_gather_object(everyone, handles, group=group)
+        self.peer = [[None, None] for _ in range(self.tp)]  # [rank][parity] -> device pointer in THIS process
+        self._opened = []
+        with torch.cuda.device(self.dev):
+            for r in range(self.tp):
+                for par in range(2):
+                    if r == self.rank:
+                        self.peer[r][par] = self.own[par]
+                        continue
+                    ptr = ctypes.c_void_p()
+                    buf = ctypes.create_string_buffer(everyone[r][par], 64)
+                    _lib.check(self.lib.mixq_tp_buffer_open(buf, ctypes.byref(ptr)), "mixq_tp_buffer_open")
+                    self.peer[r][par] = ptr.value
+                    self._opened.append(ptr.value)
+        self.views = [torch.as_tensor(_RawDeviceBuffer(p, self.nbytes), device=self.dev) for p in self.own]
+        self.small = torch.zeros(2, dtype=torch.int32, device=self.dev)   # [0] done counter, [1] time-out flag
+        dist.barrier(group=group)  # every rank has every buffer mapped before the first push
+
+    def gather(self, x_local: torch.Tensor) -> torch.Tensor:
+        """x_local fp16 [m, N/tp] (m <= max_m, contiguous) -> fp16 [m, N] view of this rank's buffer of the call's parity,
+        valid on the current stream once the returned tensor's producer kernels (push + wait) have run."""
+        assert x_local.is_cuda and x_local.dtype == torch.float16 and x_local.is_contiguous()
+        m = x_local.numel() // self.n_loc
+        assert m <= self.M and x_local.shape[-1] == self.n_loc
+        from . import _lib
+        self.seq += 1
+        par = self.seq & 1
+        st = ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+        bases = (ctypes.c_void_p * self.tp)(*[self.peer[r][par] for r in range(self.tp)])
+        flags = (ctypes.c_void_p * self.tp)(*[self.peer[r][par] + self.data_bytes + 4 * self.rank for r in range(self.tp)])
+        with torch.cuda.device(self.dev):
+            _lib.check(self.lib.mixq_tp_push_columns(x_local.data_ptr(), bases, flags, self.tp, m, self.n_loc, self.N,
+                                                     self.rank * self.n_loc, self.seq, self.small.data_ptr(), st),
+                       "mixq_tp_push_columns")
+            _lib.check(self.lib.mixq_tp_wait(self.own[par] + self.data_bytes, self.tp, self.seq,
+                                             self.small.data_ptr() + 4, st), "mixq_tp_wait")
+        return self.views[par][: m * self.N * 2].view(torch.float16).view(m, self.N)
+
+    def timed_out(self) -> bool:
+        """True if a wait gave up (a peer never published): host-side check, synchronises the device."""
+        return bool(int(self.small[1].item()) != 0)
+
+    def close(self, group=None):
+        torch.cuda.synchronize(self.dev)
+        dist.barrier(group=group)        # nobody frees memory a peer may still write
+        with torch.cuda.device(self.dev):
+            for p in self._opened:
+                self.lib.mixq_tp_buffer_close(ctypes.c_void_p(p))
+            self.views = []
+            for p in self.own:
+                self.lib.mixq_tp_buffer_free(ctypes.c_void_p(p))
+        self._opened, self.own = [], []

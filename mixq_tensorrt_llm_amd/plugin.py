@@ -169,6 +169,7 @@ class MixQLinear:
         self.weights_scaling_factor = torch.zeros(self.out_features, **f16)
         self.bias = torch.zeros(self.out_features, dtype=dtype or torch.float16, device=dev) if bias else None
         self._plugin = None
+        self.peer_gather = None   # optional parallel.PeerGather: one-sided peer writes instead of the RCCL all-gather
 
     def load(self, packed: dict):
         """Install the tensors produced by ``pack.pack_linear_weights`` (true dtypes) as fp16 carriers."""
@@ -203,8 +204,12 @@ class MixQLinear:
         if self.tp_size > 1 and self.gather_output:
             # The reference calls allreduce here (plugin.py:155-156), which is shape-wrong for an N-split and is
             # guarded by assert tp_size==1 upstream; the row-sharded operator needs ONE all-gather of the fp16 output.
-            from .parallel import all_gather_columns
-            x = all_gather_columns(x, self.tp_group, self.tp_size)
+            if self.peer_gather is not None:   # the block lands in its column block of every rank's [M, N] buffer
+                lead = x.shape[:-1]
+                x = self.peer_gather.gather(x.reshape(-1, x.shape[-1])).reshape(*lead, self.out_features * self.tp_size)
+            else:
+                from .parallel import all_gather_columns
+                x = all_gather_columns(x, self.tp_group, self.tp_size)
         return x
 
     __call__ = forward

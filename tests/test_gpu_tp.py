@@ -121,3 +121,62 @@ def test_mixqlinear_row_sharded_two_ranks_one_gpu(tmp_path, oracle):
     for r in range(world):
         res = open(tmp_path / f"ok{r}").read()
         assert res == "1", f"rank {r}: {res}"
+
+
+# ------------------------------------------------------------------- peer-write all-gather (csrc/tp_kernels.hip) ---
+def _peer_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mixq_tensorrt_llm_amd import parallel
+    ok, notes = True, []
+    try:
+        max_m, N = 700, 1024
+        pg = parallel.PeerGather(max_m, N, world, rank, "cuda:0")
+        n_loc = N // world
+        g = torch.Generator(device="cpu").manual_seed(100)          # same stream of numbers on both ranks
+        for call, m in enumerate([700, 33, 256, 1, 699, 700, 512, 8]):  # both parities, m < max_m, repeated sizes
+            full = torch.randn((m, N), generator=g).to(torch.float16)
+            mine = full[:, rank * n_loc:(rank + 1) * n_loc].contiguous().cuda()
+            got = pg.gather(mine)
+            torch.cuda.synchronize()
+            if not torch.equal(got.cpu(), full):
+                ok = False
+                notes.append(f"call {call} m={m}: gathered tensor differs")
+            # the gloo staging path must agree (same contract, different transport)
+            ref = parallel.all_gather_columns(mine, None, world)
+            ok &= torch.equal(ref.cpu(), full)
+        ok &= not pg.timed_out()
+        # through the layer: MixQLinear(tp_size=2, gather_output=True) with the peer transport == the gloo transport
+        from mixq_tensorrt_llm_amd import plugin
+        A, full_p = exact_fixture(64, 512, 512, 5)
+        mine_p = parallel.shard_packed(full_p, world, rank)
+        layer = plugin.MixQLinear(512, 512, bias=True, tp_size=world, gather_output=True, device="cuda:0").load(mine_p)
+        want = layer(torch.from_numpy(A).cuda()).cpu()
+        layer.peer_gather = parallel.PeerGather(64, 512, world, rank, "cuda:0")
+        got = layer(torch.from_numpy(A).cuda())
+        torch.cuda.synchronize()
+        ok &= torch.equal(got.cpu(), want)
+        layer.peer_gather.close()
+        pg.close()
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        ok = False
+        notes.append(traceback.format_exc())
+    open(os.path.join(tmp, f"peer{rank}"), "w").write("1" if ok else "0\n" + "\n".join(notes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_peer_write_allgather_two_ranks_one_gpu(tmp_path, oracle):
+    """One-sided peer writes + flags between two processes (IPC-mapped buffers; both ranks on the one GPU of the box, so
+    the 'peer' memory is local -- the protocol, the IPC plumbing, the column placement and the double buffering are what
+    is covered; xGMI itself needs a multi-GPU node)."""
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_peer_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        res = open(tmp_path / f"peer{r}").read()
+        assert res == "1", f"rank {r}: {res}"
