@@ -522,6 +522,12 @@ static std::atomic<int> g_variant{-1};
 
 void set_gemm_variant(int v)
 {
+    if (v >= 92 && v <= 98) { // skinny-kernel ablations (measurement only, wrong results): 92 + ABL - 1
+        set_skinny_kw(21 + (v - 92));
+        g_force_cfg.store(-1);
+        g_variant.store(0);
+        return;
+    }
     if (v == 90 || v == 91) { // 90: split workgroups never wait for their partners (all but the last arriver defer), 91: default
         set_splitk_patience(v == 90 ? 0u : 3000u);
         return;

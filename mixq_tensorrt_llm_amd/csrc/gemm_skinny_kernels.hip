@@ -18,7 +18,8 @@
 
 namespace mixq {
 
-template <int MT, int EPI, int KW>
+// ABL: measurement-only ablations (wrong results): 1 = no qA loads, 2 = no weight loads, 4 = no epilogue operand loads.
+template <int MT, int EPI, int KW, int ABL = 0>
 __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p)
 {
     __shared__ v4i part[KW][MT][64]; // [K part][m tile][lane]
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
     v8h pxf[PRE], pyf[PRE];
     uint16_t psa = 0;
     uint2 psw = {0u, 0u};
-    const bool fin = EPI != EPI_INT32 && wave < MT; // this wave runs an fp16 epilogue
+    const bool fin = EPI != EPI_INT32 && wave < MT && !(ABL & 4); // this wave runs an fp16 epilogue
     const int fm = wave * 16 + lr, fnb = n0 + 4 * lq;
     if (fin) {
         const int obytes = p.O * 2;
@@ -73,12 +74,15 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
     const v4i zero4 = {0, 0, 0, 0};
     // Weight loads are issued 16 steps (1 KiB per lane-row quarter) ahead: the kernel is latency-bound (each wave only
     // streams K/4 bytes of 16 rows), so as much of W as the registers hold is put in flight before the first MFMA.
+    // (Round 2, ablations on 4096 x 4096, GEMM only, us: M = 32 full 7.8 | no qA loads 4.7 | no weight loads 5.9 | no
+    //  loads at all 4.6; M = 16: 5.8 | 4.8 | 5.3 | 4.7 -- the weight stream alone is free, the qA fragments are what a
+    //  second m tile pays for.  Requesting all 32 qA fragments up front instead of in groups of 4 steps: no change.)
     auto do_steps = [&](int s0, int cnt) __attribute__((always_inline)) {
         v4i wf[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             const int64_t kb = (int64_t)(s0 + u) * 64;
-            wf[u] = (u < cnt && kb + lq * 16 < K) ? *reinterpret_cast<const v4i*>(wrow + kb) : zero4;
+            wf[u] = (!(ABL & 2) && u < cnt && kb + lq * 16 < K) ? *reinterpret_cast<const v4i*>(wrow + kb) : zero4;
         }
 #pragma unroll
         for (int u0 = 0; u0 < 16; u0 += 4) {
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
 #pragma unroll
             for (int u = u0; u < u0 + 4; ++u) {
                 const int64_t kb = (int64_t)(s0 + u) * 64;
-                const bool ok = u < cnt && kb + lq * 16 < K;
+                const bool ok = !(ABL & 1) && u < cnt && kb + lq * 16 < K;
 #pragma unroll
                 for (int t = 0; t < MT; ++t) af[u - u0][t] = ok ? *reinterpret_cast<const v4i*>(arow[t] + kb) : zero4;
             }
@@ -177,16 +181,16 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
 static std::atomic<int> g_skinny_kw{0}; // measurement knob: force the K-split width (0 = auto)
 void set_skinny_kw(int kw) { g_skinny_kw.store(kw); }
 
-template <int EPI, int KW>
+template <int EPI, int KW, int ABL = 0>
 static hipError_t launch_skinny_kw(const GemmParams& p, hipStream_t st)
 {
     const dim3 grid((unsigned)((p.N + 15) / 16)), block(KW * 64);
     const int mt = (p.M + 15) / 16;
     switch (mt) {
-    case 1: hipLaunchKernelGGL((gemm_skinny_kernel<1, EPI, KW>), grid, block, 0, st, p); break;
-    case 2: hipLaunchKernelGGL((gemm_skinny_kernel<2, EPI, KW>), grid, block, 0, st, p); break;
-    case 3: hipLaunchKernelGGL((gemm_skinny_kernel<3, EPI, KW>), grid, block, 0, st, p); break;
-    default: hipLaunchKernelGGL((gemm_skinny_kernel<4, EPI, KW>), grid, block, 0, st, p); break;
+    case 1: hipLaunchKernelGGL((gemm_skinny_kernel<1, EPI, KW, ABL>), grid, block, 0, st, p); break;
+    case 2: hipLaunchKernelGGL((gemm_skinny_kernel<2, EPI, KW, ABL>), grid, block, 0, st, p); break;
+    case 3: hipLaunchKernelGGL((gemm_skinny_kernel<3, EPI, KW, ABL>), grid, block, 0, st, p); break;
+    default: hipLaunchKernelGGL((gemm_skinny_kernel<4, EPI, KW, ABL>), grid, block, 0, st, p); break;
     }
     return hipGetLastError();
 }
@@ -197,7 +201,16 @@ static hipError_t launch_skinny_epi(const GemmParams& p, hipStream_t st)
     // KW = 4 everywhere: measured (tools/skinny_sweep.sh) 8 / 16 K-split waves are never faster, even for N = 4096
     // where KW = 4 leaves one wave per SIMD -- the kernel is bound by the qA re-reads through L1, not by occupancy.
     int kw = g_skinny_kw.load();
-    if (kw == 0) kw = 4;
+    if (EPI == EPI_DEQUANT && kw >= 21 && kw <= 27) { // measurement-only ablations (variant 40 + 20 + ABL): wrong results
+        switch (kw - 20) {
+        case 1: return launch_skinny_kw<EPI, 4, 1>(p, st);
+        case 2: return launch_skinny_kw<EPI, 4, 2>(p, st);
+        case 3: return launch_skinny_kw<EPI, 4, 3>(p, st);
+        case 4: return launch_skinny_kw<EPI, 4, 4>(p, st);
+        default: return launch_skinny_kw<EPI, 4, 7>(p, st);
+        }
+    }
+    if (kw == 0 || kw > 16) kw = 4;
     if (kw >= 16) return launch_skinny_kw<EPI, 16>(p, st);
     if (kw >= 8) return launch_skinny_kw<EPI, 8>(p, st);
     return launch_skinny_kw<EPI, 4>(p, st);
