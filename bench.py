@@ -33,7 +33,8 @@ LLAMA2_7B = dict(name="Llama-2-7B", layers=32, linears=[("attention.qkv", 12288,
                                                        ("mlp.proj", 4096, 11008)])
 NUM_OUTLIERS = 128
 INT8_MFMA_PEAK_TOPS = 5033.0  # dense int8 MFMA: 256 CU x 4 SIMD x 2048 op/clk x 2.4 GHz = 2x the 2.5 PF bf16 dense peak
-                              # (MI355X_MICROARCH.md: "I8 ~2x bf16 rate"; microbenchmark ceiling 4404 TOPS for 32x32x32)
+                              # (MI355X_MICROARCH.md:394 "I8 ... ~2x bf16 rate", 16x16x64 ceiling >= 3944 TOPS; cdna_hip_programming.md:286:
+                              #  micro-benchmark ceiling 4404 TOPS for the 32x32x32 i8 form used here)
 
 
 class Hip:
