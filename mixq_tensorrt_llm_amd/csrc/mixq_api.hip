@@ -105,8 +105,8 @@ int mixq_registry_has_creator(const char* name, const char* version, const char*
 
 const char* mixq_plugin_type(void) { return "MixQ"; }
 const char* mixq_plugin_version(void) { return "1"; }
-static void* g_dbg_stamps = nullptr;
-void mixq_debug_set_stamp_buffer(void* device_u64_8_per_block) { g_dbg_stamps = device_u64_8_per_block; }
+static std::atomic<void*> g_dbg_stamps{nullptr}; // measurement knob only (NULL in production)
+void mixq_debug_set_stamp_buffer(void* device_u64_8_per_block) { g_dbg_stamps.store(device_u64_8_per_block); }
 
 void mixq_debug_set_gemm_variant(int variant) { mixq::set_gemm_variant(variant < 0 ? 0 : variant); }
 
@@ -533,7 +533,7 @@ int mixq_gemm_mixed_scratch(const int8_t* qA, const int8_t* W, const void* sA, c
     p.zeros = mixq::zero_page();
     if (!p.zeros) return MIXQ_E_HIP;
     p.M = M, p.N = N, p.K = K;
-    p.dbg = g_dbg_stamps;
+    p.dbg = g_dbg_stamps.load(std::memory_order_relaxed);
     if (scratch && aligned16(scratch) && scratch_bytes >= gemm_scratch_bytes(M, N, K)) p.splitk_ws = scratch;
     if (O <= kNumOutliers) {
         p.fpA = static_cast<const uint16_t*>(fpA), p.fpW = static_cast<const uint16_t*>(fpW), p.O = O;
