@@ -78,7 +78,7 @@ __device__ __forceinline__ void glds16_sbase(const char* sbase, unsigned voff, u
 }
 } // namespace pp
 
-// ABL: measurement-only ablations (wrong results): 1 = no global_load_lds in the loop, 2 = no vmcnt waits,
+// ABL: measurement-only ablations (wrong results): 32 = MFMA A / B operands swapped, 1 = no global_load_lds in the loop, 2 = no vmcnt waits,
 // 4 = no ds_reads in the loop, 8 = every tile loads tile (0,0)'s operands (all L2 hits), 16 = no epilogue.
 // ABL = 0 is the product kernel.
 // SPLITK = 2 / 4 / 8: K split over S workgroups per output tile, for mid-size problems whose tiles alone cover at most
@@ -263,7 +263,8 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
 #pragma unroll
             for (int jy = 0; jy < 2; ++jy)
                 acc[xi][yhalf * 2 + jy] =
-                    __builtin_amdgcn_mfma_i32_32x32x32_i8(X[ks], Y[jy][ks], acc[xi][yhalf * 2 + jy], 0, 0, 0);
+                    (ABL & 32) ? __builtin_amdgcn_mfma_i32_32x32x32_i8(Y[jy][ks], X[ks], acc[xi][yhalf * 2 + jy], 0, 0, 0)
+                               : __builtin_amdgcn_mfma_i32_32x32x32_i8(X[ks], Y[jy][ks], acc[xi][yhalf * 2 + jy], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     };
 
@@ -921,6 +922,7 @@ hipError_t launch_gemm_pp_ablate(const GemmParams& p, int abl, hipStream_t st)
     case 16: return launch_pp_cfg<EPI_DEQUANT, true, false, 16>(p, st);
     case 24: return launch_pp_cfg<EPI_DEQUANT, true, false, 24>(p, st);
     case 21: return launch_pp_cfg<EPI_DEQUANT, true, false, 21>(p, st);
+    case 32: return launch_pp_cfg<EPI_DEQUANT, true, false, 32>(p, st); // MFMA operands swapped (transposed tiles: timing only)
     default: return launch_pp_cfg<EPI_DEQUANT, true, false, 0>(p, st);
     }
 }
