@@ -248,14 +248,22 @@ class Model:
         self.gather_done = [None, None]   # event of the last gather that READ output buffer 0 / 1
 
     def open_peer_transport(self, parallel, rank, group=None):
-        """One-sided peer writes over xGMI for the output all-gather (csrc/tp_kernels.hip); falls back to RCCL."""
+        """One-sided peer writes over xGMI for the output all-gather (csrc/tp_kernels.hip); falls back to RCCL -- on
+        EVERY rank if any rank could not map its peers' buffers (the ranks must agree on the transport)."""
+        err = None
         try:
             for N in sorted({c[8] for c in self.calls}):
                 self.gatherers[N] = parallel.PeerGather(self.chunk, N, self.tp, rank, self.dev, group)
-            self.transport = "peer writes over xGMI (mixq_tp_push_columns + flags), data lands in place"
         except Exception as e:  # noqa: BLE001
+            err = repr(e)
+        verdicts = [None] * self.tp
+        dist.all_gather_object(verdicts, err, group=group)
+        if all(v is None for v in verdicts):
+            self.transport = "peer writes over xGMI (mixq_tp_push_columns + flags), data lands in place"
+        else:
             self.gatherers = {}
-            self.transport = f"rccl all_gather_into_tensor + column placement (peer transport unavailable: {e!r})"
+            first = next(v for v in verdicts if v is not None)
+            self.transport = f"rccl all_gather_into_tensor + column placement (peer transport unavailable: {first})"
 
     def close(self):
         for g in self.gatherers.values():

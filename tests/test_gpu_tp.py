@@ -61,6 +61,8 @@ CASES = [  # (name, M, N, K, exact)
     ("exact_small", 40, 512, 512, True),
     ("exact_pp_tiles", 300, 1024, 1024, True),
     ("qwen2_qkv_bias", 48, 4608, 3584, False),
+    ("llama2_70b_qkv", 40, 10240, 8192, False),   # BASELINE configs[4] shapes (here sharded 2 ways; 8 ways = 1280 rows)
+    ("llama2_70b_proj_decode_batch", 16, 8192, 28672, False),   # long K: the small-tile K split over workgroups per shard
 ]
 
 
