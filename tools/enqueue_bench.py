@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--K", type=int, default=4096)
     ap.add_argument("--variant", type=int, default=None)
     ap.add_argument("--iters", type=int, default=2000)
+    ap.add_argument("--stamps", action="store_true", help="one-launch operator (variant 81): print the in-kernel timeline "
+                    "(wall-clock ticks of 10 ns) of one call")
     ap.add_argument("--graph", type=int, default=0, help="capture this many calls into one HIP graph and time replays "
                     "(device-paced: no host launch cost per call)")
     a = ap.parse_args()
@@ -54,6 +56,26 @@ def main():
     for _ in range(50):
         assert run() == 0
     torch.cuda.synchronize()
+    if a.stamps:
+        import numpy as np
+        nblk = (N + 15) // 16
+        buf = torch.zeros(nblk * 8, dtype=torch.int64, device=dev)
+        lib.mixq_debug_set_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        lib.mixq_debug_set_stamp_buffer(None)
+        t = buf.cpu().numpy().reshape(nblk, 8).astype(np.float64)
+        t0 = t[:, 0].min()
+        names = ["start->W issued", "quantise+publish", "wait for flags", "GEMM (qA loads + MFMA)", "LDS hand-over",
+                 "epilogue", "re-arm"]
+        print(f"kernel span {(t[:, 7].max() - t0) * 10:.0f} ns; first start -> last start {(t[:, 0].max() - t0) * 10:.0f} ns")
+        d = np.diff(t, axis=1) * 10
+        for i, nme in enumerate(names):
+            print(f"   {nme:26s} mean {d[:, i].mean():8.0f}  min {d[:, i].min():8.0f}  max {d[:, i].max():8.0f} ns")
+        q = t[:M]
+        print(f"   quantiser workgroups: publish done at {((q[:, 2] - t0) * 10).mean():.0f} ns (max {((q[:, 2] - t0) * 10).max():.0f});"
+              f" all workgroups through the wait at {((t[:, 3] - t0) * 10).mean():.0f} ns (max {((t[:, 3] - t0) * 10).max():.0f})")
     if a.graph:
         side = torch.cuda.Stream()
         st = ctypes.c_void_p(side.cuda_stream)

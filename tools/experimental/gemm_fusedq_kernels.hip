@@ -149,6 +149,11 @@ __global__ __launch_bounds__(256) void gemm_skinny_fusedq_kernel(const GemmParam
     const int n0 = blockIdx.x * 16;
     const int lr = lane & 15, lq = lane >> 4;
     const int64_t K = p.K;
+    auto stamp = [&](int idx) __attribute__((always_inline)) {
+        if (p.dbg != nullptr && tid == 0)
+            static_cast<unsigned long long*>(p.dbg)[(size_t)blockIdx.x * 8 + idx] = wall_clock64();
+    };
+    stamp(0);
     int8_t* const qA = const_cast<int8_t*>(p.A);
     uint16_t* const sA = const_cast<uint16_t*>(p.sA);
     uint16_t* const fpA = const_cast<uint16_t*>(p.fpA);
@@ -194,7 +199,9 @@ __global__ __launch_bounds__(256) void gemm_skinny_fusedq_kernel(const GemmParam
         __syncthreads();
         if (tid == 0) __hip_atomic_store(words + FLAG0 + r, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
+    stamp(1);
     for (int r = blockIdx.x; r < p.M; r += gridDim.x) publish_row(r);
+    stamp(2);
 
     // ---- 3. wait for the M flags (bounded; then help) ------------------------------------------------------------------
     {
@@ -225,6 +232,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_fusedq_kernel(const GemmParam
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); // (compiler ordering: no load of qA / sA / fpA above this)
     }
+    stamp(3);
     // through the wait: count in (the answer is only needed at the very end, its latency hides under the GEMM)
     unsigned finished_before = 0u;
     if (tid == 0)
@@ -280,9 +288,11 @@ __global__ __launch_bounds__(256) void gemm_skinny_fusedq_kernel(const GemmParam
         consume(s, cnt);
     }
 
+    stamp(4);
 #pragma unroll
     for (int t = 0; t < MT; ++t) part[wave][t][lane] = acc[t];
     __syncthreads();
+    stamp(5);
 
     if (wave < MT) {
         const int t = wave;
@@ -336,15 +346,17 @@ __global__ __launch_bounds__(256) void gemm_skinny_fusedq_kernel(const GemmParam
             }
         }
     }
+    stamp(6);
     // ---- 5. the last workgroup through the wait re-arms the flags for the next launch ------------------------------------
     if (tid == 0 && finished_before == gridDim.x - 1u) {
         for (int r = 0; r < MAXROWS; ++r)
             __hip_atomic_store(words + FLAG0 + r, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(words + FINISHED, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    stamp(7);
 }
 
-static std::atomic<int> g_fusedq_mode{1};          // 1 on (default), 0 off, 2 on with an immediate time-out (tests)
+static std::atomic<int> g_fusedq_mode{0};          // 1 on (default), 0 off, 2 on with an immediate time-out (tests)
 void set_fusedq_mode(int v) { g_fusedq_mode.store(v); }
 
 // Same domain as launch_gemm's choice of the skinny kernel (gemm_kernels.hip), minus what the in-kernel quantiser does
