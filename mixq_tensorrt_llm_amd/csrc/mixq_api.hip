@@ -594,13 +594,10 @@ int mixq_dequantization_silu(void* out, const int32_t* x, const void* scaleRow, 
 size_t mixq_w8a16_gemm_workspace_size(int m, int n, int k)
 {
     if (m <= kSmallMFastPath || n <= 0 || k <= 0) return 0;
-    size_t best = 0;
-    for (int rows = m < 256 ? m : 256, done = 0; !done; done = 1) { // passes of <= 256 tokens; the ragged last pass may plan differently
-        const size_t a = mixq::w8a16_gemm_workspace_size(rows, n, k);
-        const size_t b = m > 256 && m % 256 ? mixq::w8a16_gemm_workspace_size(m % 256, n, k) : 0;
-        best = a > b ? a : b;
-    }
-    return best;
+    // the GEMM runs in passes of at most 256 tokens; a ragged last pass may plan (and size) differently
+    const size_t full = mixq::w8a16_gemm_workspace_size(m < 256 ? m : 256, n, k);
+    const size_t tail = (m > 256 && m % 256) ? mixq::w8a16_gemm_workspace_size(m % 256, n, k) : 0;
+    return full > tail ? full : tail;
 }
 
 int mixq_w8a16_gemm_forward_ws(const void* input, const uint8_t* weight, const void* scale, void* output, int m, int n,
