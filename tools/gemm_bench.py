@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--what", default="both")
     ap.add_argument("--check", action="store_true", help="compare the output with the plain launch bit for bit (20 rounds)")
     ap.add_argument("--zero", action="store_true", help="zero-filled operands (DVFS ceiling probe)")
+    ap.add_argument("--qa-mode", default="", help="power probe (wrong results): replace qA after the quantiser -- 'offset8' = "
+                    "q + 8 clamped (all small positives), 'abs' = |q|, 'zero_outl' = outlier columns zeroed, 'full' = uniform int8")
     ap.add_argument("--stamps", action="store_true", help="print the per-tile timeline from in-kernel s_memtime stamps")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -61,6 +63,24 @@ def main():
         assert lib.mixq_gemm_mixed_scratch(p(qA), p(W), p(sA), p(sW), p(fpA), p(fpW), p(out), M, N, K, O,
                                            p(scr) if nscr else None, nscr, st) == 0
 
+    if a.qa_mode:
+        quant()
+        torch.cuda.synchronize()
+        q32 = qA.to(torch.int32)
+        if a.qa_mode == "offset8":
+            q32 = (q32 + 8).clamp_(-128, 127)
+        elif a.qa_mode == "abs":
+            q32 = q32.abs().clamp_(max=127)
+        elif a.qa_mode == "zero_outl":
+            q32[:, ind.long()] = 0
+        elif a.qa_mode == "offset8_zero_outl":
+            q32 = (q32 + 8).clamp_(-128, 127)
+            q32[:, ind.long()] = 8
+        elif a.qa_mode == "full":
+            q32 = torch.randint(-127, 128, q32.shape, device=dev, generator=g, dtype=torch.int32)
+        qA.copy_(q32.to(torch.int8))
+        print("qA mode", a.qa_mode, "mean |q|", float(qA.float().abs().mean()), "frac negative", float((qA < 0).float().mean()))
+        a.what = "gemm"
     if a.what == "decode":
         Wq = torch.randint(0, 256, (K, N), dtype=torch.uint8, device=dev, generator=g)
         for m in (1, 2, 4):
