@@ -284,3 +284,22 @@ def test_top_level_mixlib_module_name():
                  "dequantizeInt8", "dequantizeInt8Silu", "Int8quantize", "FindRowScaleFusedExtracOutliers", "int_to_half",
                  "int8_matrix_to_half", "int_matrix_to_half", "layernorm_forward_cuda_extract_outliers"):
         assert callable(getattr(m, name)), name
+
+
+def test_top_level_eetq_module_name(oracle):
+    """`from EETQ import quant_weights, preprocess_weights, w8_a16_gemm` (linear.py:9, model_config_utils.py:434): same
+    return convention as the extension (eetpy.cpp:14-17) and the oracle's restatement of symmetric_quantize +
+    preprocess_weights (cutlass_preprocessors.cc:497-660) byte for byte."""
+    import torch
+    from EETQ import preprocess_weights, quant_weights, w8_a16_gemm
+    assert callable(w8_a16_gemm)
+    rng = np.random.default_rng(8)
+    Wt = (rng.standard_normal((128, 64)) * 0.02).astype(np.float16)          # [K, N] = W^T as the callers pass it
+    processed, scales = quant_weights(torch.from_numpy(Wt), torch.int8, False)
+    assert processed.dtype == torch.int8 and tuple(processed.shape) == (128, 64) and scales.dtype == torch.float16
+    q_un, sc = oracle.eetq_symmetric_quantize(Wt)
+    assert np.array_equal(scales.numpy().view(np.uint16), sc.view(np.uint16))
+    assert np.array_equal(processed.numpy().view(np.uint8), oracle.eetq_preprocess(q_un))
+    un, processed2, _ = quant_weights(torch.from_numpy(Wt), torch.int8, True)
+    assert np.array_equal(un.numpy(), q_un) and torch.equal(processed2, processed)
+    assert np.array_equal(preprocess_weights(torch.from_numpy(q_un)).numpy().view(np.uint8), oracle.eetq_preprocess(q_un))
