@@ -254,6 +254,15 @@ class Model:
         try:
             for N in sorted({c[8] for c in self.calls}):
                 self.gatherers[N] = parallel.PeerGather(self.chunk, N, self.tp, rank, self.dev, group)
+            # self-test before anything is timed (this transport has never seen a multi-GPU node): every rank pushes a
+            # block that names it, and must find every peer's block in its place, without a wait timing out
+            for N, g in self.gatherers.items():
+                mine = torch.full((64, N // self.tp), float(rank + 1), dtype=torch.float16, device=self.dev)
+                got = g.gather(mine)
+                torch.cuda.synchronize(self.dev)
+                want = torch.arange(1, self.tp + 1, dtype=torch.float16, device=self.dev).repeat_interleave(N // self.tp)
+                if g.timed_out() or not torch.equal(got, want.expand(64, N)):
+                    raise RuntimeError(f"peer-write self-test failed for N={N} (timed out: {g.timed_out()})")
         except Exception as e:  # noqa: BLE001
             err = repr(e)
         verdicts = [None] * self.tp
