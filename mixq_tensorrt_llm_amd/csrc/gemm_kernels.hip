@@ -572,6 +572,21 @@ static int gemm_variant()
     return v;
 }
 
+// 128 x 256 ping-pong tiles (gemm_pp128_kernels.hip) win where they fill most of ONE wave of the chip and K is short enough
+// that the 256 x 256 form's K split over workgroups would not amortise its exchange: measured on 90 mid-size shapes
+// (tools/pp128_sweep.sh, profiles/r02_pp128_sweep.txt): 88..256 tiles at K < 8192 (-3..-21 %), 160..256 tiles at
+// 8192 <= K < 10240 (-4..-5 %); more than one wave of tiles, fewer than ~88 tiles or longer K: the other forms.
+static bool pp128_wins(int M, int N, int K)
+{
+    if (M <= 128) return false;
+    const int64_t t = (int64_t)((M + 127) / 128) * ((N + 255) / 256);
+    const int nk = (K + 127) / 128, cus = num_cus();
+    if (t > cus) return false;
+    if (nk < 64) return 256 * t >= (int64_t)88 * cus;
+    if (nk < 80) return 256 * t >= (int64_t)160 * cus;
+    return false;
+}
+
 static std::atomic<const char*> g_last_kernel{"none"}; // reporting only (bench.py's roofline.kernel)
 const char* last_gemm_kernel() { return g_last_kernel.load(std::memory_order_relaxed); }
 void note_gemm_kernel(const char* name) { g_last_kernel.store(name, std::memory_order_relaxed); }
@@ -593,9 +608,17 @@ hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st)
     const int64_t tiles256 = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256);
     if (variant >= 100) return launch_gemm_pp_ablate(p, variant - 100, st); // measurement-only ablations
     const int64_t wg64 = (int64_t)((p.M + 63) / 64) * ((p.N + 63) / 64);
+    if (variant == 0 && pp128_wins(p.M, p.N, p.K)) {
+        chose("gemm_w8a8o16_pp128_kernel (128x256 ping-pong)");
+        return launch_gemm_pp128(p, epi, st);
+    }
     if (variant == 0 && epi != EPI_INT32 && p.splitk_ws != nullptr && gemm_splitk_factor(p.M, p.N, p.K) != 0) {
         chose("gemm_w8a8o16_pp_kernel<SPLITK> (256x256 ping-pong, K split over workgroups)");
         return launch_gemm_pp_splitk(p, epi, st); // 2 / 4 / 8 workgroups per tile
+    }
+    if (variant == 5) { // (measurement / tests) the 128 x 256 ping-pong kernel for every M > 4
+        chose("gemm_w8a8o16_pp128_kernel (128x256 ping-pong)");
+        return launch_gemm_pp128(p, epi, st);
     }
     if (variant == 2 || (variant == 0 && p.M > 128 && tiles256 >= 96 && wg64 > 768)) {
         chose("gemm_w8a8o16_pp_kernel (256x256 ping-pong)");

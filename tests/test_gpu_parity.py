@@ -169,14 +169,15 @@ def test_int32_accumulators_bit_exact(oracle, M, N, K):
 
 @pytest.fixture
 def variant():
-    """Force a main-loop schedule (1 = 2-barrier kernel, 2 = 256x256 ping-pong kernel); auto again afterwards."""
+    """Force a main-loop schedule (1 = 2-barrier kernel, 2 = 256x256 ping-pong kernel, 5 = 128x256 ping-pong kernel); auto
+    again afterwards."""
     from mixq_tensorrt_llm_amd import _lib
     lib = _lib.load()
     yield lib.mixq_debug_set_gemm_variant
     lib.mixq_debug_set_gemm_variant(0)
 
 
-@pytest.mark.parametrize("which", [1, 2])
+@pytest.mark.parametrize("which", [1, 2, 5])
 @pytest.mark.parametrize("M,N,K", [(5, 16, 16), (33, 144, 272), (129, 256, 384), (256, 512, 128), (300, 768, 640),
                                    (513, 1280, 896), (700, 528, 2064), (1024, 1024, 4096)])
 def test_every_schedule_gives_identical_int32(oracle, variant, which, M, N, K):
@@ -211,7 +212,7 @@ def test_every_tile_configuration_of_the_two_barrier_kernel(oracle, variant, cfg
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 768, 1280), (700, 528, 2112), (520, 1024, 512), (257, 272, 704)])
-@pytest.mark.parametrize("which", [1, 2])
+@pytest.mark.parametrize("which", [1, 2, 5])
 def test_every_schedule_full_operator(oracle, variant, which, M, N, K):
     """Both schedules on ragged M/N, a partial last K slice, odd slice counts."""
     variant(which)
@@ -220,6 +221,27 @@ def test_every_schedule_full_operator(oracle, variant, which, M, N, K):
     got = run_enqueue(A, p)
     want = oracle.linear_prefill(A, p["weight"], p["weights_scaling_factor"], p["fp_weight"], p["fp_ind"])
     assert rel_err(got, want) < REL_TOL
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 11008, 1024), (513, 5008, 448), (384, 12288, 512), (1500, 4096, 640)])
+def test_mid_size_shapes_take_the_128x256_tiles_and_match_the_oracle(oracle, M, N, K):
+    """88..256 tiles of 128 x 256 at short K: launch_gemm picks gemm_w8a8o16_pp128_kernel by itself (ragged M / N, a partial
+    last K slice, one and several K slices); same bits as the two-barrier kernel, 1e-3 from the oracle."""
+    from mixq_tensorrt_llm_amd import _lib
+    lib = _lib.load()
+    lib.mixq_debug_set_gemm_variant(0)
+    A, W, act = make_layer(M, N, K, seed=M + K)
+    p = oracle.pack_linear_weights(W, act)
+    got = run_enqueue(A, p)
+    assert b"pp128" in lib.mixq_debug_last_gemm_kernel(), lib.mixq_debug_last_gemm_kernel()
+    want = oracle.linear_prefill(A, p["weight"], p["weights_scaling_factor"], p["fp_weight"], p["fp_ind"])
+    assert rel_err(got, want) < REL_TOL
+    lib.mixq_debug_set_gemm_variant(1)
+    try:
+        two_barrier = run_enqueue(A, p)
+    finally:
+        lib.mixq_debug_set_gemm_variant(0)
+    assert np.array_equal(bits(got), bits(two_barrier))
 
 
 def test_schedules_agree_bitwise_on_the_full_operator(variant):
@@ -232,10 +254,10 @@ def test_schedules_agree_bitwise_on_the_full_operator(variant):
     fpw = (torch.randn((N, 128), generator=g) * 0.02).to(torch.float16).to(dev())
     ind = torch.randperm(K, generator=g)[:128].to(torch.int32).to(dev())
     outs = []
-    for which in (1, 2):
+    for which in (1, 2, 5):
         variant(which)
         outs.append(mixlib.mixq_linear(A, W, sW, fpw, ind))
-    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     # more tiles than CUs, odd slice count
     M2, N2, K2 = 4200, 5136, 1152 + 128
     A2 = torch.randn((M2, K2), generator=g).to(torch.float16).to(dev())
@@ -244,7 +266,7 @@ def test_schedules_agree_bitwise_on_the_full_operator(variant):
     fpw2 = (torch.randn((N2, 128), generator=g) * 0.02).to(torch.float16).to(dev())
     ind2 = torch.randperm(K2, generator=g)[:128].to(torch.int32).to(dev())
     outs = []
-    for which in (1, 2):
+    for which in (1, 2, 5):
         variant(which)
         outs.append(mixlib.mixq_linear(A2, W2, sW2, fpw2, ind2))
     assert torch.equal(outs[0], outs[1])
