@@ -25,6 +25,13 @@
 //           to slot s has landed by the end of LOAD(s+2), and a barrier lies before LOAD(s+3).
 //   WAR     X0(j+2) overwrites X0(j), last read at slot 2j-1;  X1(j+1) overwrites X1(j-1), last read at slot 2j-1;
 //           Y(j+2) overwrites Y(j), read at slot 2j: always an earlier slot, with barriers between.
+//
+// Measured (round 2, one box, tools/ab.sh): 2048 x 4096 x 4096 40.4 us = one wave of 256 tiles (the 256 x 256 form with K split
+// 2 ways: 45.9-47.7), i.e. ~57 % MFMA occupancy inside the loop against 92 % for 256 x 256 tiles: a slice costs every wave 16
+// fragment reads + 6 copy instructions for 16 MFMAs (256 x 256: 24 + 8 for 32), so the LOAD segments, not the matrix
+// pipe, pace it.  Tried: three slice buffers with one copy per phase issued BEHIND the MFMAs of the COMPUTE segment, where
+// the wave otherwise waits for its partner's LOAD segment: bit-identical, 2-6 % slower on four shapes (a copy next to
+// MFMAs opens a bubble in the matrix pipe, as in the 256 x 256 kernel); not kept.
 #include "mixq_device.h"
 #include "mixq_launch.h"
 #include <type_traits>
