@@ -576,7 +576,7 @@ static int gemm_variant()
 // that the 256 x 256 form's K split over workgroups would not amortise its exchange: measured on 90 mid-size shapes
 // (tools/pp128_sweep.sh, profiles/r02_pp128_sweep.txt): 88..256 tiles at K < 8192 (-3..-21 %), 160..256 tiles at
 // 8192 <= K < 10240 (-4..-5 %); more than one wave of tiles, fewer than ~88 tiles or longer K: the other forms.
-static bool pp128_wins(int M, int N, int K)
+bool gemm_pp128_wins(int M, int N, int K)
 {
     if (M <= 128) return false;
     const int64_t t = (int64_t)((M + 127) / 128) * ((N + 255) / 256);
@@ -608,7 +608,7 @@ hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st)
     const int64_t tiles256 = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256);
     if (variant >= 100) return launch_gemm_pp_ablate(p, variant - 100, st); // measurement-only ablations
     const int64_t wg64 = (int64_t)((p.M + 63) / 64) * ((p.N + 63) / 64);
-    if (variant == 0 && pp128_wins(p.M, p.N, p.K)) {
+    if (variant == 0 && gemm_pp128_wins(p.M, p.N, p.K)) {
         chose("gemm_w8a8o16_pp128_kernel (128x256 ping-pong)");
         return launch_gemm_pp128(p, epi, st);
     }

@@ -817,6 +817,7 @@ SplitPlan gemm_splitk_plan(int M, int N, int K)
     SplitPlan none{0, 0};
     const int force = g_splitk_force.load();
     if (force == 0 || M <= 128) return none;
+    if (force < 0 && gemm_pp128_wins(M, N, K)) return none; // one wave of 128 x 256 tiles instead (gemm_pp128_kernels.hip)
     const int tiles = ((M + pp::BM - 1) / pp::BM) * ((N + pp::BN - 1) / pp::BN);
     const int nk = (K + pp::KS - 1) / pp::KS;
     const int cus = num_cus() & ~7;

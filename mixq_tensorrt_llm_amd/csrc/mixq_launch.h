@@ -63,6 +63,7 @@ struct GemmParams {
 hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st);
 hipError_t launch_gemm_pp(const GemmParams& p, int epi, hipStream_t st);  // 256x256 ping-pong schedule
 hipError_t launch_gemm_pp128(const GemmParams& p, int epi, hipStream_t st); // 128x256 ping-pong schedule (mid-size problems)
+bool gemm_pp128_wins(int M, int N, int K); // launch_gemm's rule for taking the 128x256 tiles (then no K split, no scratch)
 constexpr size_t kSplitkWordsBytes = 16384; // hand-over words (64 B per tile) of up to 256 split tiles, at the start of the scratch
 struct SplitPlan {
     int s;    // workgroups per split tile: 0 (no split form for this shape) / 2 / 4 / 8

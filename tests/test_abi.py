@@ -108,7 +108,8 @@ def test_workspace_sizes_are_size_t_clean(lib):
     assert lib.mixq_workspace_size(h, 128, N, K) <= 128 * K + 2 * 128 + 2 * 128 * 128 + xsplit + 5 * 128 + 128
     assert lib.mixq_workspace_size(h, 4, N, K) <= 4 * K + 8 + 8 * 128 + 4 * 128 + 128     # decode: none
     assert lib.mixq_gemm_scratch_size(1024, 4096, 11008) == 16384 + 64 * 4 * 262144   # 4 workgroups per tile, a 256-KiB slot each
-    assert lib.mixq_gemm_scratch_size(2048, 4096, 4096) == 16384 + 128 * 2 * 262144  # 2 workgroups per tile
+    assert lib.mixq_gemm_scratch_size(2048, 4096, 4096) == 0          # 256 tiles of 128 x 256: no K split, no scratch
+    assert lib.mixq_gemm_scratch_size(2048, 4096, 12288) == 16384 + 128 * 2 * 262144  # longer K: 2 workgroups per tile
     assert lib.mixq_gemm_scratch_size(8192, 12288, 4096) == 0 and lib.mixq_gemm_scratch_size(64, 4096, 4096) == 0
     # 1M tokens x 11008: the reference's int arithmetic overflows here
     big = lib.mixq_workspace_size(h, 1 << 20, 4096, 11008)

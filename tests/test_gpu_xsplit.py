@@ -105,7 +105,7 @@ def test_shared_scratch_across_shapes_and_both_split_forms(lib):
     """One scratch per stream serves every layer: small-tile splits, 256x256 splits and unsplit launches in any order."""
     lib.mixq_debug_set_gemm_variant(79)
     lib.mixq_debug_set_gemm_variant(69)
-    shapes = [(32, 4096, 11008), (1024, 4096, 11008), (64, 1024, 28672), (512, 12288, 4096), (128, 4096, 16384),
+    shapes = [(32, 4096, 11008), (1024, 4096, 11008), (64, 1024, 28672), (512, 12288, 11008), (128, 4096, 16384),
               (24, 2048, 8192), (256, 4096, 16384), (32, 4096, 11008)]
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     sizes = [lib.mixq_gemm_scratch_size(*s) for s in shapes]
