@@ -119,11 +119,11 @@ def small_m_points(lib, TensorDesc, dev, gen, st_ptr, iters=300):
 
 
 def mid_m_points(lib, TensorDesc, dev, gen, st_ptr, iters=100):
-    """Informational (never part of `value`): decode batches (32 / 128 rows) and a short prefill (1024 / 2048 tokens) of
+    """Informational (never part of `value`): decode batches (32 / 128 / 512 rows) and a short prefill (1024 / 2048 tokens) of
     the same three linears, where the tiles no longer fill the chip and the library splits K over several workgroups per
     tile.  Whole operator (quantiser + GEMM) through mixq_enqueue."""
     out = {}
-    for M in (32, 128, 1024, 2048):
+    for M in (32, 128, 512, 1024, 2048):   # 512 = the top of the batch range the reference publishes numbers for
         per = {}
         total = 0.0
         for name, N, K in LLAMA2_7B["linears"]:
@@ -151,7 +151,8 @@ def mid_m_points(lib, TensorDesc, dev, gen, st_ptr, iters=100):
             lib.mixq_destroy(h)
             total += dt
             per[name] = {"us_per_call": dt * 1e6, "TOPS": 2.0 * M * N * (K + NUM_OUTLIERS) / dt / 1e12,
-                         "k_split": lib.mixq_gemm_scratch_size(M, N, K) > 0}
+                         "k_split": lib.mixq_gemm_scratch_size(M, N, K) > 0,
+                         "kernel": lib.mixq_debug_last_gemm_kernel().decode()}
             del t, A, o, ws
         out[f"chunk_of_{M}_tokens"] = {"linears": per, "tokens_per_s": M / (total * LLAMA2_7B["layers"])}
     return out
