@@ -244,6 +244,33 @@ def test_mid_size_shapes_take_the_128x256_tiles_and_match_the_oracle(oracle, M, 
     assert np.array_equal(bits(got), bits(two_barrier))
 
 
+@pytest.mark.parametrize("epi", ["dequant", "dequant+y", "silu+y", "silu_mul"])
+@pytest.mark.parametrize("M,N,K", [(300, 528, 2064), (129, 272, 384)])
+def test_every_epilogue_on_the_128x256_tiles(variant, epi, M, N, K):
+    """The P-flavour epilogues (addend y, SiLU, SiLU * up) through gemm_w8a8o16_pp128_kernel (variant 5) on ragged shapes
+    with a partial last K slice: the same bits as the two-barrier kernel (variant 1)."""
+    from mixq_tensorrt_llm_amd import mixlib
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    a = torch.randint(-127, 128, (M, K), dtype=torch.int8, generator=g).to(dev())
+    b = torch.randint(-127, 128, (N, K), dtype=torch.int8, generator=g).to(dev())
+    sa = (torch.rand(M, generator=g) * 0.05 + 0.01).to(torch.float16).to(dev())
+    sb = (torch.rand(N, generator=g) * 4e-4 + 1e-4).to(torch.float16).to(dev())
+    y = torch.randn((M, N), generator=g).to(torch.float16).to(dev()) if "+y" in epi or epi == "silu_mul" else None
+    up = torch.randn((M, N), generator=g).to(torch.float16).to(dev())
+
+    def run():
+        if epi.startswith("dequant"):
+            return mixlib.int8FusedDequantize(a, b, sa, sb, y, M, N, K)
+        if epi == "silu+y":
+            return mixlib.int8FusedDequantizeSilu(a, b, sa, sb, y, M, N, K)
+        return mixlib.int8FusedDequantizeSiluMul(a, b, sa, sb, y, up, M, N, K)
+    variant(1)
+    ref = run()
+    variant(5)
+    got = run()
+    assert torch.equal(got, ref)
+
+
 def test_schedules_agree_bitwise_on_the_full_operator(variant):
     from mixq_tensorrt_llm_amd import mixlib
     g = torch.Generator(device="cpu").manual_seed(5)
