@@ -528,6 +528,12 @@ void set_gemm_variant(int v)
         g_variant.store(0);
         return;
     }
+    if (v >= 80 && v <= 89) { // fpA_intB GEMM (w8a16_gemm_kernels.hip): 80 automatic, 81 narrow passes, 82 / 84 wide form with
+                              // 128- / 256-row tiles; 85 K split automatic, 86..89: 1 / 2 / 4 / 8 workgroups per tile
+        if (v <= 84) set_wo_force(v == 80 ? -1 : v == 81 ? 0 : v == 82 ? 2 : v == 84 ? 4 : -1, -2);
+        else set_wo_force(-2, v == 85 ? -1 : 1 << (v - 86));
+        return;
+    }
     if (v == 90 || v == 91) { // 90: split workgroups never wait for their partners (all but the last arriver defer), 91: default
         set_splitk_patience(v == 90 ? 0u : 3000u);
         return;

@@ -594,10 +594,7 @@ int mixq_dequantization_silu(void* out, const int32_t* x, const void* scaleRow, 
 size_t mixq_w8a16_gemm_workspace_size(int m, int n, int k)
 {
     if (m <= kSmallMFastPath || n <= 0 || k <= 0) return 0;
-    // the GEMM runs in passes of at most 256 tokens; a ragged last pass may plan (and size) differently
-    const size_t full = mixq::w8a16_gemm_workspace_size(m < 256 ? m : 256, n, k);
-    const size_t tail = (m > 256 && m % 256) ? mixq::w8a16_gemm_workspace_size(m % 256, n, k) : 0;
-    return full > tail ? full : tail;
+    return mixq::w8a16_gemm_workspace_size(m, n, k);
 }
 
 int mixq_w8a16_gemm_forward_ws(const void* input, const uint8_t* weight, const void* scale, void* output, int m, int n,

@@ -247,6 +247,240 @@ __global__ __launch_bounds__(256 * WM) void w8a16_gemm_kernel(const uint16_t* __
     }
 }
 
+// ---- the large-M form: 64-column wave tiles, M tiled in the grid -----------------------------------------------------------
+// Above one pass of 256 tokens the kernel above is bound by LDS bandwidth, not by the matrix cores: its waves are 32
+// columns wide, so every v_mfma_f32_32x32x16_f16 needs its own 1-KiB token fragment from LDS (8 LDS cycles per 32 MFMA
+// cycles on each of 4 SIMDs = the whole LDS port), and every 256-token pass streams and dequantises all weights again.
+// Here a wave owns 64 columns x 32*MTW rows: each token fragment feeds TWO MFMAs (LDS traffic per MFMA halved), a
+// workgroup (8 waves = 2 row halves x 4 column groups) owns a 64*MTW-row x 256-column tile of the output and the grid
+// walks the M x N tiles (grouped along M, one contiguous range per XCD, so that the workgroups resident on an XCD share
+// weight columns and token rows in its L2).  K stage = 64 k (one 64-row block of the interleaved layout): 8 weight
+// registers per column block per stage, so three stages fit the register file beside 128 accumulators.
+// Same arithmetic as above per output element (same MFMA, same k order inside a K range, same ordered reduction when K
+// is split), so both forms and the oracle agree to the same tolerance; the two forms are not bit-identical to each other
+// only where their K splits differ.
+namespace wo {
+constexpr int KBW = 64;        // k per stage of the wide form
+constexpr int ROWBW = KBW * 2; // bytes per token row per stage
+constexpr int BNW = 256;       // columns per workgroup (4 waves x 64)
+} // namespace wo
+
+template <int MTW, int NST>
+__global__ __launch_bounds__(512) void w8a16_gemm_wide_kernel(const uint16_t* __restrict__ A, const uint8_t* __restrict__ Wq,
+                                                               const uint16_t* __restrict__ scale,
+                                                               uint16_t* __restrict__ Out, int M, int N, int K, int ks,
+                                                               void* __restrict__ scratch)
+{
+    using namespace wo;
+    constexpr int T = 512;
+    constexpr int ROWS = 2 * MTW * 32;            // token rows of the workgroup tile
+    constexpr int STAGE = ROWS * ROWBW;           // bytes of one token stage
+    constexpr int AL = ROWS * 8 / T;              // 16-byte LDS-DMA copies per thread per stage
+    constexpr int GROUP_OPS = 4 + AL;             // VMEM operations a thread issues per stage
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int wn = wave & 3, wmh = wave >> 2;     // column group (64 columns), row half
+
+    // ---- block -> (tile, K rank): the ks workgroups of a tile are consecutive blocks; tiles: XCD-contiguous, grouped ----
+    const int tiles_m = (M + ROWS - 1) / ROWS, tiles_n = (N + BNW - 1) / BNW;
+    const int nwg = tiles_m * tiles_n;
+    const int bid = (int)blockIdx.x / ks, krank = (int)blockIdx.x % ks;
+    int tile_m, tile_n;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        const int t_lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        constexpr int GROUP_M = 4;
+        const int per_group = GROUP_M * tiles_n;
+        const int g = t_lin / per_group, first_m = g * GROUP_M;
+        const int gsz = min(tiles_m - first_m, GROUP_M);
+        const int within = t_lin - g * per_group;
+        tile_m = first_m + within % gsz;
+        tile_n = within / gsz;
+    }
+    const int m0 = tile_m * ROWS;
+    const int n0w = tile_n * BNW + wn * 64;       // first column of this wave
+    const int trow0 = wmh * MTW * 32;             // first token row of this wave inside the tile
+
+    const int nst_all = K / KBW;
+    const int s_begin = (int)((int64_t)nst_all * krank / ks), s_end = (int)((int64_t)nst_all * (krank + 1) / ks);
+    const int nst = s_end - s_begin;
+
+    // ---- weight stream: two column blocks per wave; lane (column n, 16-byte group parity kg) -----------------------------
+    const uint8_t* wbase[2];
+    v2h scale2[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int ncol = min(n0w + cb * 32 + lr, N - 1); // clamped columns are computed, never stored
+        wbase[cb] = Wq + (int64_t)(ncol >> 1) * 2 * K + (ncol & 1) * 64 + lh * 16;
+        _Float16 sc;
+        const uint16_t sb = scale[ncol];
+        __builtin_memcpy(&sc, &sb, 2);
+        scale2[cb] = v2h{sc, sc};
+    }
+    auto load_w = [&](uint4 (&w)[4], int s) __attribute__((always_inline)) {
+        // [cb * 2 + j]: 16-byte group 2j + kg of 64-row block s of the lane's column in block cb
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                w[cb * 2 + j] = *reinterpret_cast<const uint4*>(wbase[cb] + (int64_t)s * 128 + j * 32);
+    };
+
+    // ---- token tile -> LDS: chunk c = i * T + tid: row = c / 8, slot = c % 8 holds source chunk slot ^ (row & 7) ---------
+    const char* asrc[AL];
+#pragma unroll
+    for (int i = 0; i < AL; ++i) {
+        const int row = (i * T + tid) >> 3, slot = tid & 7;
+        const int chunk = slot ^ (row & 7);
+        asrc[i] = reinterpret_cast<const char*>(A) + (int64_t)min(m0 + row, M - 1) * K * 2 + chunk * 16;
+    }
+    auto stage_a = [&](int buf, int s) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < AL; ++i)
+            glds16(asrc[i] + (int64_t)s * KBW * 2, smem + buf * STAGE + (i * T + wave * 64) * 16);
+    };
+
+    // ---- fragment read offsets: lane (token row t*32 + lr, kg): chunk = 2*(2j + kg) + odd --------------------------------
+    int aoff[2][2]; // [j][odd]
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const int chunk = 2 * (2 * j + lh) + o;
+            aoff[j][o] = lr * ROWBW + ((chunk ^ (lr & 7)) << 4);
+        }
+
+    v16f acc[2][MTW];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int t = 0; t < MTW; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[cb][t][e] = 0.f;
+
+    auto compute = [&](const uint4 (&w)[4], int buf) __attribute__((always_inline)) {
+        const char* base = smem + buf * STAGE + trow0 * ROWBW;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            v8h we[2], wod[2];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const unsigned d[4] = {w[cb * 2 + j].x, w[cb * 2 + j].y, w[cb * 2 + j].z, w[cb * 2 + j].w};
+                v2h e2[4], o2[4];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    e2[x] = wo_dequant_pair(d[x], 0x04020400u, scale2[cb]);
+                    o2[x] = wo_dequant_pair(d[x], 0x04030401u, scale2[cb]);
+                }
+                we[cb] = v8h{e2[0][0], e2[0][1], e2[1][0], e2[1][1], e2[2][0], e2[2][1], e2[3][0], e2[3][1]};
+                wod[cb] = v8h{o2[0][0], o2[0][1], o2[1][0], o2[1][1], o2[2][0], o2[2][1], o2[3][0], o2[3][1]};
+            }
+#pragma unroll
+            for (int t = 0; t < MTW; ++t) {
+                const v8h ae = *reinterpret_cast<const v8h*>(base + t * 32 * ROWBW + aoff[j][0]);
+                const v8h ao = *reinterpret_cast<const v8h*>(base + t * 32 * ROWBW + aoff[j][1]);
+                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(we[0], ae, acc[0][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(we[1], ae, acc[1][t], 0, 0, 0);
+                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wod[0], ao, acc[0][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wod[1], ao, acc[1][t], 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- main loop: as above -- stage i's operands were issued NST-1 iterations earlier; one barrier per stage -----------
+    uint4 w[NST][4];
+#pragma unroll
+    for (int p = 0; p < NST - 1; ++p) {
+        if (p < nst) {
+            load_w(w[p], s_begin + p);
+            stage_a(p, s_begin + p);
+        }
+    }
+    for (int i0 = 0; i0 < nst; i0 += NST) {
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int i = i0 + u;
+            if (i >= nst) break;
+            if (NST > 2 && i + NST - 2 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * GROUP_OPS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (i + NST - 1 < nst) {
+                load_w(w[(u + NST - 1) % NST], s_begin + i + NST - 1);
+                stage_a((i + NST - 1) % NST, s_begin + i + NST - 1);
+            }
+            compute(w[u], i % NST);
+        }
+    }
+
+    // ---- K split over workgroups: park, count in, the last one to arrive adds the parts in rank order -----------------
+    if (ks > 1) {
+        __shared__ unsigned arrived_s;
+        constexpr int TILE = 2 * MTW * 16 * T; // floats of one parked tile: [column block][row tile][16][thread]
+        unsigned* const counter = static_cast<unsigned*>(scratch) + (tile_m * tiles_n + tile_n);
+        float* const slots = reinterpret_cast<float*>(static_cast<char*>(scratch) + kSplitkWordsBytes) +
+                             (size_t)(tile_m * tiles_n + tile_n) * ks * TILE;
+        float* const mine = slots + (size_t)krank * TILE + tid;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int t = 0; t < MTW; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    __hip_atomic_store(mine + ((cb * MTW + t) * 16 + e) * T, acc[cb][t][e], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every write-through acknowledged
+        __syncthreads();
+        if (tid == 0) arrived_s = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (arrived_s != (unsigned)(ks - 1)) return;
+        if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // re-armed
+        // rank order, whichever workgroup is last; the own part is read back like the others (it was parked above with
+        // write-through stores): no second register copy of the tile, and all loads of a rank are in flight together
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int t = 0; t < MTW; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[cb][t][e] = 0.f;
+        for (int r = 0; r < ks; ++r) {
+            const float* const theirs = slots + (size_t)r * TILE + tid;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int t = 0; t < MTW; ++t)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        acc[cb][t][e] += __hip_atomic_load(theirs + ((cb * MTW + t) * 16 + e) * T, __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+
+    // ---- store: lane holds, per 32x32 tile, 4 x (4 consecutive columns) of token row t*32 + lr -------------------------
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int t = 0; t < MTW; ++t) {
+            const int m = m0 + trow0 + t * 32 + lr;
+            if (m >= M) continue;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0w + cb * 32 + 8 * g + 4 * lh;
+                uint16_t* dst = Out + (int64_t)m * N + n;
+                const v2h lo = f2h2(acc[cb][t][4 * g], acc[cb][t][4 * g + 1]);
+                const v2h hi = f2h2(acc[cb][t][4 * g + 2], acc[cb][t][4 * g + 3]);
+                if (n + 3 < N) {
+                    *reinterpret_cast<uint2*>(dst) = uint2{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+                } else if (n < N) { // N % 4 == 2: the last quad is half valid
+                    *reinterpret_cast<unsigned*>(dst) = __builtin_bit_cast(unsigned, lo);
+                }
+            }
+        }
+}
+
 // ---- host side ----------------------------------------------------------------------------------------------------------
 struct WoPlan {
     int mt;  // 32-row tiles per pass (1, 2, 4, 8)
@@ -268,13 +502,80 @@ static WoPlan wo_plan(int M, int N, int K, bool have_scratch)
     return pl;
 }
 
-size_t w8a16_gemm_workspace_size(int M, int N, int K)
+static size_t wo_narrow_workspace(int rows, int N, int K)
 {
-    if (M <= 4) return 0;
-    const WoPlan pl = wo_plan(M, N, K, true);
+    const WoPlan pl = wo_plan(rows, N, K, true);
     if (pl.ks <= 1) return 0;
     const size_t ntiles = (size_t)(N + wo::BN - 1) / wo::BN;
     return kSplitkWordsBytes + ntiles * pl.ks * (size_t)pl.mt * 16 * 256 * sizeof(float);
+}
+
+// The wide form (M tiled in the grid, 64-column wave tiles) for more than one 256-token pass.
+struct WoWidePlan {
+    int mtw; // 32-row tiles per wave: 2 (128-row workgroup tiles) or 4 (256-row); 0: the narrow form in passes
+    int ks;  // workgroups per tile along K
+};
+
+static std::atomic<int> g_wo_form{-1}; // measurement knob: -1 automatic, 0 narrow passes, 2 / 4 wide with that mtw
+static std::atomic<int> g_wo_ks{-1};   // -1 automatic, else the K split of the wide form (where K allows)
+void set_wo_force(int form, int ks)
+{
+    if (form >= -1) g_wo_form.store(form);
+    if (ks >= -1) g_wo_ks.store(ks);
+}
+
+// Plan = the (tile height, K split) with the smallest estimated time.  Constants from tools/w8a16_forms.sh on MI355X
+// (profiles/r02_w8a16_forms.txt): a 64-k stage of a 256-row tile takes ~2.2 us with the whole chip busy (MFMA-bound at the
+// power-capped clock), of a 128-row tile ~1.45 us (the dequantisation VALU work is amortised over half as many rows);
+// both ~15 % less while at most 3/4 of the CUs are busy (higher clocks under the power cap); the hand-over of a K split costs
+// ~6 + 2.5 ks us (128-row tiles) / ~12 + 4.3 ks us (256-row tiles: twice the bytes per workgroup).  K is split only while
+// all workgroups fit one wave (which also bounds the scratch: at most one 256-KiB slot per CU).
+static WoWidePlan wo_wide_plan(int M, int N, int K, bool have_scratch)
+{
+    const int form = g_wo_form.load(), fks = g_wo_ks.load();
+    if (M <= 256 || form == 0) return {0, 1};
+    const int cus = num_cus(), tn = (N + wo::BNW - 1) / wo::BNW, nst = K / wo::KBW;
+    const int ks_hi = !have_scratch ? 1 : nst / 8 < 8 ? (nst / 8 < 1 ? 1 : nst / 8) : 8; // at least 8 stages (512 k) each
+    WoWidePlan best{2, 1};
+    float best_t = 1e30f;
+    for (int mtw = 2; mtw <= 4; mtw += 2) {
+        if ((form == 2 || form == 4) && mtw != form) continue;
+        const int rows = 64 * mtw, tiles = ((M + rows - 1) / rows) * tn;
+        for (int ks = 1; ks <= ks_hi; ++ks) {
+            if (fks > 0) { // (measurements, tests) that split wherever K allows it, whatever the tile count
+                if (ks != (fks <= ks_hi ? fks : 1)) continue;
+            } else if (ks > 1 && tiles * ks > cus) {
+                break;
+            }
+            const int wgs = tiles * ks, waves = (wgs + cus - 1) / cus;
+            const float load = 4 * wgs <= 3 * cus ? 0.85f : 1.f;
+            const float stage = (mtw == 4 ? 2.2f : 1.45f) * load;
+            const float hand = ks == 1 ? 0.f : (mtw == 4 ? 12.f + 4.3f * ks : 6.f + 2.5f * ks);
+            const float t = (float)waves * (float)((nst + ks - 1) / ks) * stage + hand;
+            if (t < best_t) best_t = t, best = WoWidePlan{mtw, ks};
+        }
+    }
+    return best;
+}
+
+static size_t wo_wide_workspace(int M, int N, int K)
+{
+    const WoWidePlan pl = wo_wide_plan(M, N, K, true);
+    if (pl.mtw == 0 || pl.ks <= 1) return 0;
+    const int rows = 64 * pl.mtw;
+    const size_t tiles = (size_t)((M + rows - 1) / rows) * ((N + wo::BNW - 1) / wo::BNW);
+    if (tiles * sizeof(unsigned) > kSplitkWordsBytes) return 0; // (more tiles than hand-over words: no split needed there)
+    return kSplitkWordsBytes + tiles * pl.ks * (size_t)(2 * pl.mtw * 16 * 512) * sizeof(float);
+}
+
+size_t w8a16_gemm_workspace_size(int M, int N, int K)
+{
+    if (M <= 4 || N <= 0 || K <= 0) return 0;
+    if (wo_wide_plan(M, N, K, true).mtw != 0) return wo_wide_workspace(M, N, K);
+    // narrow form: passes of at most 256 tokens; a ragged last pass may plan (and size) differently
+    const size_t full = wo_narrow_workspace(M < 256 ? M : 256, N, K);
+    const size_t tail = (M > 256 && M % 256) ? wo_narrow_workspace(M % 256, N, K) : 0;
+    return full > tail ? full : tail;
 }
 
 template <int MT, int NST, int WM = 1>
@@ -292,6 +593,21 @@ static hipError_t launch_wo(const uint16_t* A, const uint8_t* Wq, const uint16_t
     return hipGetLastError();
 }
 
+template <int MTW, int NST>
+static hipError_t launch_wo_wide(const uint16_t* A, const uint8_t* Wq, const uint16_t* scale, uint16_t* Out, int M, int N,
+                                 int K, int ks, void* scratch, hipStream_t st)
+{
+    constexpr int rows = 64 * MTW;
+    constexpr size_t lds = (size_t)NST * rows * wo::ROWBW;
+    static_assert(lds <= 160 * 1024 - 64, "LDS budget");
+    auto kern = w8a16_gemm_wide_kernel<MTW, NST>;
+    static DeviceOnce once;
+    if (hipError_t e = ensure_dynamic_lds(kern, lds, once); e != hipSuccess) return e;
+    const int tiles = ((M + rows - 1) / rows) * ((N + wo::BNW - 1) / wo::BNW);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * ks)), dim3(512), lds, st, A, Wq, scale, Out, M, N, K, ks, scratch);
+    return hipGetLastError();
+}
+
 hipError_t launch_w8a16_gemm(const void* A, const uint8_t* Wq, const void* scale, void* Out, int M, int N, int K,
                              void* scratch, size_t scratch_bytes, const void* zeros, hipStream_t st)
 {
@@ -299,10 +615,17 @@ hipError_t launch_w8a16_gemm(const void* A, const uint8_t* Wq, const void* scale
     const uint16_t* a = static_cast<const uint16_t*>(A);
     const uint16_t* s = static_cast<const uint16_t*>(scale);
     uint16_t* o = static_cast<uint16_t*>(Out);
+    if (wo_wide_plan(M, N, K, false).mtw != 0) {
+        const size_t need = wo_wide_workspace(M, N, K);
+        const bool have = scratch != nullptr && need != 0 && scratch_bytes >= need;
+        const WoWidePlan pl = wo_wide_plan(M, N, K, have);
+        return pl.mtw == 4 ? launch_wo_wide<4, 3>(a, Wq, s, o, M, N, K, pl.ks, scratch, st)
+                           : launch_wo_wide<2, 4>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
+    }
     for (int m0 = 0; m0 < M; m0 += 256) { // 256-token passes (each streams the weights once)
         const int rows = M - m0 < 256 ? M - m0 : 256;
-        const bool have = scratch != nullptr && scratch_bytes >= w8a16_gemm_workspace_size(rows, N, K) &&
-                          w8a16_gemm_workspace_size(rows, N, K) != 0;
+        const size_t need = wo_narrow_workspace(rows, N, K);
+        const bool have = scratch != nullptr && need != 0 && scratch_bytes >= need;
         const WoPlan pl = wo_plan(rows, N, K, have);
         const uint16_t* ap = a + (int64_t)m0 * K;
         uint16_t* op = o + (int64_t)m0 * N;

@@ -92,6 +92,52 @@ def test_ragged_shapes(oracle, M, N, K):
         assert rel_err(got, want) < REL_TOL, (M, N, K, scratch)
 
 
+@pytest.fixture
+def form():
+    """Force the form of the fpA_intB GEMM (81 narrow passes | 82 / 84 wide, 128- / 256-row tiles; 86..89: 1 / 2 / 4 / 8
+    workgroups per tile along K); automatic again afterwards."""
+    from mixq_tensorrt_llm_amd import _lib
+    lib = _lib.load()
+    yield lib.mixq_debug_set_gemm_variant
+    lib.mixq_debug_set_gemm_variant(80)
+    lib.mixq_debug_set_gemm_variant(85)
+
+
+@pytest.mark.parametrize("which,ks", [(81, 85), (82, 86), (82, 87), (82, 88), (84, 86), (84, 87), (84, 89)])
+@pytest.mark.parametrize("M,N,K", [(257, 256, 2048), (300, 1026, 1600), (513, 770, 3136), (700, 136, 448),
+                                   (1024, 512, 1024), (1100, 2304, 1088)])
+def test_large_m_forms(oracle, form, which, ks, M, N, K):
+    """More than one 256-token pass: the wide form (64-column wave tiles, M tiled in the grid, optional K split) in both
+    tile heights against the oracle, ragged in M (last tile partly empty), N (N % 256, N % 4 == 2) and K (stage counts
+    that do not divide by the pipeline depth or the split)."""
+    A, q, sc = make(M, N, K, M + 7 * N + K)
+    qi = interleave(q)
+    want = oracle.w8a16_gemv(A, q, sc)
+    form(which)
+    form(ks)
+    got, _ = run(A, qi, sc, N, scratch=True)
+    assert np.isfinite(got).all() and rel_err(got, want) < REL_TOL
+    got2, _ = run(A, qi, sc, N, scratch=False)
+    assert np.isfinite(got2).all() and rel_err(got2, want) < REL_TOL
+
+
+def test_large_m_forms_agree_exactly_on_integer_data(form):
+    """Integer activations, unit scales: every fp32 partial sum is exact, so every form, tile height and K split must give
+    the integer product bit for bit."""
+    rng = np.random.default_rng(11)
+    M, N, K = 600, 1280, 4096
+    q = rng.integers(-128, 128, size=(K, N), dtype=np.int8)
+    A = rng.integers(-4, 5, size=(M, K)).astype(np.float16)
+    sc = np.ones(N, np.float16)
+    qi = interleave(q)
+    want = (A.astype(np.int64) @ q.astype(np.int64)).astype(np.float32).astype(np.float16)
+    for which, ks in [(81, 85), (82, 85), (82, 88), (84, 85), (84, 87), (80, 85)]:
+        form(which)
+        form(ks)
+        got, _ = run(A, qi, sc, N, True)
+        assert np.array_equal(got.view(np.uint16), want.view(np.uint16)), (which, ks)
+
+
 def test_exact_on_integer_data_and_row_independence(oracle):
     """Integer-valued activations and unit scales: every partial sum is exact in fp32, so any summation order gives the
     same bits -- the GEMM must equal the integer matrix product exactly; and rows are independent (permutation)."""
