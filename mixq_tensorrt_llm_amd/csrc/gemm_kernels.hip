@@ -528,9 +528,17 @@ void set_gemm_variant(int v)
         g_variant.store(0);
         return;
     }
+    if (v >= 831 && v <= 834) { // fpA_intB wide-form configuration 1..4 (w8a16_gemm_kernels.hip kWoCfg)
+        set_wo_force(v - 830, -2);
+        return;
+    }
+    if (v >= 800 && v < 816) { // fpA_intB wide-form ablations (measurement only, wrong results): 800 + ABL
+        set_wo_force(100 + (v - 800), -2);
+        return;
+    }
     if (v >= 80 && v <= 89) { // fpA_intB GEMM (w8a16_gemm_kernels.hip): 80 automatic, 81 narrow passes, 82 / 84 wide form with
                               // 128- / 256-row tiles; 85 K split automatic, 86..89: 1 / 2 / 4 / 8 workgroups per tile
-        if (v <= 84) set_wo_force(v == 80 ? -1 : v == 81 ? 0 : v == 82 ? 2 : v == 84 ? 4 : -1, -2);
+        if (v <= 84) set_wo_force(v == 80 ? -1 : v == 81 ? 0 : v == 82 ? 3 : 4, -2);
         else set_wo_force(-2, v == 85 ? -1 : 1 << (v - 86));
         return;
     }

@@ -56,18 +56,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
         __builtin_amdgcn_sched_barrier(0);              \
     } while (0)
 
-__device__ __forceinline__ void glds16_sbase(const char* sbase, unsigned voff, unsigned lds_addr)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\t"
-                 "s_mov_b32 m0, %3\n\t"
-                 "s_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %2\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(sbase), "s"(lds_addr)
-                 : "memory");
-}
+// (glds16_sbase: the asm-form 16-byte LDS-DMA with an SGPR base, mixq_device.h)
 } // namespace pp128
 
 template <int EPI, bool HAS_O, bool HAS_Y>

@@ -61,21 +61,7 @@ __device__ __forceinline__ void wait_vmcnt()
     else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
 }
 
-// 16-byte LDS-DMA, SGPR-base form.  LDS destination = M0 (wave-uniform) + lane*16; M0 is saved/restored inside the
-// statement (it is compiler-reserved).  The compiler does not count this load: every consumer sits behind one of the
-// explicit vmcnt waits + a barrier.
-__device__ __forceinline__ void glds16_sbase(const char* sbase, unsigned voff, unsigned lds_addr)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\t"
-                 "s_mov_b32 m0, %3\n\t"
-                 "s_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %2\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(sbase), "s"(lds_addr)
-                 : "memory");
-}
+// (glds16_sbase: the asm-form 16-byte LDS-DMA with an SGPR base, mixq_device.h)
 } // namespace pp
 
 // ABL: measurement-only ablations (wrong results): 32 = MFMA A / B operands swapped, 1 = no global_load_lds in the loop, 2 = no vmcnt waits,

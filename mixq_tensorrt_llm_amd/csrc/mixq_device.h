@@ -66,6 +66,26 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base)
     __builtin_amdgcn_global_load_lds(MIXQ_GLOBAL_PTR(gsrc), MIXQ_LDS_PTR(lds_wave_base), 16, 0, 0);
 }
 
+// The same copy in asm form: wave-uniform 64-bit base in SGPRs + per-lane 32-bit byte offset; LDS destination = M0
+// (wave-uniform LDS byte address) + lane * 16.  M0 is saved / restored inside the statement (it is compiler-reserved).
+// WHY asm: the compiler's s_waitcnt insertion treats the builtin as a FLAT access that may touch LDS and memory, and
+// while one is pending every dependency wait becomes vmcnt(0) / lgkmcnt(0) -- a loop that keeps DMA copies in flight
+// loses its whole register prefetch (every use of a loaded register drains all copies) and every LDS read waits for the
+// youngest one.  The asm form is not counted: every consumer of the copied bytes must sit behind an explicit
+// `s_waitcnt vmcnt(n)` (n counted over ALL VMEM operations of the thread, these included) and a barrier.
+__device__ __forceinline__ void glds16_sbase(const char* sbase, unsigned voff, unsigned lds_addr)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %3\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_addr)
+                 : "memory");
+}
+
 // One fp16 quotient with the reference's semantics (kernel/i8gemm.cu:103-104):
 //   (int8) __half2int_rn( __hdiv(x, s) )
 // __hdiv = correctly rounded fp16 division = RNE_fp16(fp32 IEEE quotient) (innocuous double rounding);

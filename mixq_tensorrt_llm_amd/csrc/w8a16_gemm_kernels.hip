@@ -27,6 +27,8 @@
 // scratch): every workgroup parks its fp32 partial tile with write-through stores and counts itself in; the LAST one to
 // arrive adds all parts IN RANK ORDER (fp32 addition does not commute bitwise: a fixed order keeps the result
 // deterministic whichever workgroup is last) and stores the fp16 tile.  Nobody waits.
+#include <type_traits>
+
 #include "mixq_device.h"
 #include "mixq_launch.h"
 
@@ -254,8 +256,18 @@ __global__ __launch_bounds__(256 * WM) void w8a16_gemm_kernel(const uint16_t* __
 // Here a wave owns 64 columns x 32*MTW rows: each token fragment feeds TWO MFMAs (LDS traffic per MFMA halved), a
 // workgroup (8 waves = 2 row halves x 4 column groups) owns a 64*MTW-row x 256-column tile of the output and the grid
 // walks the M x N tiles (grouped along M, one contiguous range per XCD, so that the workgroups resident on an XCD share
-// weight columns and token rows in its L2).  K stage = 64 k (one 64-row block of the interleaved layout): 8 weight
-// registers per column block per stage, so three stages fit the register file beside 128 accumulators.
+// weight columns and token rows in its L2).  K stage = 64 k (one 64-row block of the interleaved layout).
+//
+// BOTH operands of a stage travel global -> LDS as asm-form LDS-DMA (glds16_sbase: not counted by the compiler, explicit
+// vmcnt accounting, NST-1 stages in flight): the token tile (rows x 128 B) and the RAW weight bytes of the 256 columns
+// (128 column pairs x 128 B = 16 KiB, fetched once per workgroup instead of once per row half).  A lane then reads its
+// 16-byte weight groups from LDS like the GEMV reads them from memory, so the dequantisation is unchanged.  With the
+// builtin LDS-DMA + weights prefetched in registers (first build of this kernel) the compiler drained EVERY outstanding
+// load before each use of a weight register (see glds16_sbase): 2.2 us per stage = one memory latency.
+//
+// The main loop is software-pipelined by hand: while the 4 MFMAs of (k step j, row tile t) run, the token fragments of
+// the next (j, t) are read and a share of step j + 1's weights is dequantised (v_perm / v_pk_add / v_pk_mul ride in the
+// shadow of the MFMAs; sched_group_barrier pins the interleave).
 // Same arithmetic as above per output element (same MFMA, same k order inside a K range, same ordered reduction when K
 // is split), so both forms and the oracle agree to the same tolerance; the two forms are not bit-identical to each other
 // only where their K splits differ.
@@ -263,27 +275,31 @@ namespace wo {
 constexpr int KBW = 64;        // k per stage of the wide form
 constexpr int ROWBW = KBW * 2; // bytes per token row per stage
 constexpr int BNW = 256;       // columns per workgroup (4 waves x 64)
+constexpr int WSTAGE = BNW * KBW; // weight bytes per stage
 } // namespace wo
 
-template <int MTW, int NST>
-__global__ __launch_bounds__(512) void w8a16_gemm_wide_kernel(const uint16_t* __restrict__ A, const uint8_t* __restrict__ Wq,
+// ABL (measurement only, wrong results): 1 no copies in the loop, 2 no dequantisation, 4 token fragments read once, 8 no MFMAs
+template <int MTW, int WMH, int NST, int ABL = 0>
+__global__ __launch_bounds__(256 * WMH) void w8a16_gemm_wide_kernel(const uint16_t* __restrict__ A, const uint8_t* __restrict__ Wq,
                                                                const uint16_t* __restrict__ scale,
                                                                uint16_t* __restrict__ Out, int M, int N, int K, int ks,
                                                                void* __restrict__ scratch)
 {
     using namespace wo;
-    constexpr int T = 512;
-    constexpr int ROWS = 2 * MTW * 32;            // token rows of the workgroup tile
-    constexpr int STAGE = ROWS * ROWBW;           // bytes of one token stage
-    constexpr int AL = ROWS * 8 / T;              // 16-byte LDS-DMA copies per thread per stage
-    constexpr int GROUP_OPS = 4 + AL;             // VMEM operations a thread issues per stage
+    constexpr int T = 256 * WMH;                  // WMH = 1: 4 waves (one per SIMD, each all rows), 2: 8 waves (two row halves)
+    constexpr int ROWS = WMH * MTW * 32;          // token rows of the workgroup tile
+    constexpr int ASTAGE = ROWS * ROWBW;          // token bytes of one stage
+    constexpr int STAGE = ASTAGE + WSTAGE;        // [tokens | raw weights]
+    constexpr int AL = ROWS * 8 / T;              // token copies (16 B) per thread per stage
+    constexpr int WL = WSTAGE / 16 / T;           // weight copies per thread per stage (2 or 4)
+    constexpr int GROUP_OPS = AL + WL;            // VMEM operations a thread issues per stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 31, lh = lane >> 5;
-    const int wn = wave & 3, wmh = wave >> 2;     // column group (64 columns), row half
+    const int wn = wave & 3, wmh = wave >> 2;     // column group (64 columns), row half (0 when WMH = 1)
 
     // ---- block -> (tile, K rank): the ks workgroups of a tile are consecutive blocks; tiles: XCD-contiguous, grouped ----
     const int tiles_m = (M + ROWS - 1) / ROWS, tiles_n = (N + BNW - 1) / BNW;
@@ -309,50 +325,61 @@ __global__ __launch_bounds__(512) void w8a16_gemm_wide_kernel(const uint16_t* __
     const int s_begin = (int)((int64_t)nst_all * krank / ks), s_end = (int)((int64_t)nst_all * (krank + 1) / ks);
     const int nst = s_end - s_begin;
 
-    // ---- weight stream: two column blocks per wave; lane (column n, 16-byte group parity kg) -----------------------------
-    const uint8_t* wbase[2];
-    v2h scale2[2];
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        const int ncol = min(n0w + cb * 32 + lr, N - 1); // clamped columns are computed, never stored
-        wbase[cb] = Wq + (int64_t)(ncol >> 1) * 2 * K + (ncol & 1) * 64 + lh * 16;
-        _Float16 sc;
-        const uint16_t sb = scale[ncol];
-        __builtin_memcpy(&sc, &sb, 2);
-        scale2[cb] = v2h{sc, sc};
-    }
-    auto load_w = [&](uint4 (&w)[4], int s) __attribute__((always_inline)) {
-        // [cb * 2 + j]: 16-byte group 2j + kg of 64-row block s of the lane's column in block cb
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                w[cb * 2 + j] = *reinterpret_cast<const uint4*>(wbase[cb] + (int64_t)s * 128 + j * 32);
-    };
-
-    // ---- token tile -> LDS: chunk c = i * T + tid: row = c / 8, slot = c % 8 holds source chunk slot ^ (row & 7) ---------
-    const char* asrc[AL];
+    // ---- stage copies: wave-uniform base + per-thread offset, destination = this wave's 1-KiB window of each 8-KiB row --
+    // tokens: chunk c = i * T + tid: row = c / 8, slot = c % 8 holds source chunk slot ^ ((row / 2) % 8): rows are 128 B = half a
+    //         256-B bank row, so a 16-lane group of ds_read_b128 (rows 0-3, 12-15, 20-27 ...) needs (row % 2, slot) distinct
+    // weights: chunk q = i * T + tid: local pair pl = q / 8; slot q % 8 holds the pair's 16-byte group (q % 8) ^ ((pl / 2) % 4)
+    //          (group g < 4: column 2p, 16-byte group g of the 64-row block; g >= 4: column 2p + 1, group g - 4)
+    const char* const abase = reinterpret_cast<const char*>(A) + ((int64_t)m0 * K + (int64_t)s_begin * KBW) * 2;
+    const int pair0 = tile_n * (BNW / 2), npairs = N >> 1;
+    const char* const wbase = reinterpret_cast<const char*>(Wq) + (int64_t)pair0 * 2 * K + (int64_t)s_begin * 128;
+    unsigned aoffv[AL], woffv[WL];
 #pragma unroll
     for (int i = 0; i < AL; ++i) {
         const int row = (i * T + tid) >> 3, slot = tid & 7;
-        const int chunk = slot ^ (row & 7);
-        asrc[i] = reinterpret_cast<const char*>(A) + (int64_t)min(m0 + row, M - 1) * K * 2 + chunk * 16;
+        aoffv[i] = (unsigned)(min(m0 + row, M - 1) - m0) * (unsigned)K * 2u + (unsigned)((slot ^ ((row >> 1) & 7)) << 4);
     }
-    auto stage_a = [&](int buf, int s) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < AL; ++i)
-            glds16(asrc[i] + (int64_t)s * KBW * 2, smem + buf * STAGE + (i * T + wave * 64) * 16);
+    for (int i = 0; i < WL; ++i) {
+        const int pl = (i * T + tid) >> 3, gq = (tid & 7) ^ ((pl >> 1) & 3);
+        woffv[i] = (unsigned)(min(pair0 + pl, npairs - 1) - pair0) * (unsigned)K * 2u + (unsigned)(gq << 4);
+    }
+    const unsigned lds0 = (unsigned)(size_t)(MIXQ_LDS_PTR(smem)) + wave * 1024;
+    auto issue = [&](int rel, int buf) __attribute__((always_inline)) { // stage s_begin + rel -> buffer buf
+        if ((ABL & 1) && rel >= NST - 1) return;
+        const char* const ab = abase + (int64_t)rel * (KBW * 2);
+        const char* const wb = wbase + (int64_t)rel * 128;
+#pragma unroll
+        for (int i = 0; i < AL; ++i) glds16_sbase(ab, aoffv[i], lds0 + buf * STAGE + i * T * 16);
+#pragma unroll
+        for (int i = 0; i < WL; ++i) glds16_sbase(wb, woffv[i], lds0 + buf * STAGE + ASTAGE + i * T * 16);
     };
 
-    // ---- fragment read offsets: lane (token row t*32 + lr, kg): chunk = 2*(2j + kg) + odd --------------------------------
+    // ---- fragment read offsets ----------------------------------------------------------------------------------------
+    // tokens: lane (row t*32 + lr, kg): chunk = 2*(2j + kg) + odd;  weights: lane (column, kg): group 2j + kg of its column
     int aoff[2][2]; // [j][odd]
+    int woff[2][2]; // [cb][j]
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 2; ++j) {
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
             const int chunk = 2 * (2 * j + lh) + o;
-            aoff[j][o] = lr * ROWBW + ((chunk ^ (lr & 7)) << 4);
+            aoff[j][o] = lr * ROWBW + ((chunk ^ ((lr >> 1) & 7)) << 4);
         }
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const int pl = wn * 32 + cb * 16 + (lr >> 1), g = (lr & 1) * 4 + 2 * j + lh;
+            woff[cb][j] = ASTAGE + ((pl * 8 + (g ^ ((pl >> 1) & 3))) << 4);
+        }
+    }
+    v2h scale2[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        _Float16 sc;
+        const uint16_t sb = scale[min(n0w + cb * 32 + lr, N - 1)]; // clamped columns are computed, never stored
+        __builtin_memcpy(&sc, &sb, 2);
+        scale2[cb] = v2h{sc, sc};
+    }
 
     v16f acc[2][MTW];
 #pragma unroll
@@ -362,57 +389,118 @@ __global__ __launch_bounds__(512) void w8a16_gemm_wide_kernel(const uint16_t* __
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[cb][t][e] = 0.f;
 
-    auto compute = [&](const uint4 (&w)[4], int buf) __attribute__((always_inline)) {
-        const char* base = smem + buf * STAGE + trow0 * ROWBW;
+    // ---- main loop: NST - 1 stages in flight, one barrier per stage ------------------------------------------------------
+    // A stage = two k steps (j) of MTW row tiles x 4 MFMAs.  Step 0's MFMAs hide the dequantisation of step 1's weights;
+    // step 0's own weights are dequantised in the open at the top of the stage.  (A second barrier in the middle of the
+    // stage, certifying stage i+1 so that step 1 hides the NEXT stage's step 0 as well, measured the same: the stage is
+    // bound by issue slots and power, not by that bubble -- ablations in DESIGN.md 2.5.)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            v8h we[2], wod[2];
+    for (int p = 0; p < NST - 1; ++p)
+        if (p < nst) issue(p, p);
+    v2h E[2][2][4], O[2][2][4]; // [k step j][column block][x]: dequantised operands (even / odd k halves of a 16-byte group)
+    auto dequant_half = [&](const uint4& wv, int h, v2h sc, v2h (&e2)[4], v2h (&o2)[4]) __attribute__((always_inline)) {
+        const unsigned d0 = h ? wv.z : wv.x, d1 = h ? wv.w : wv.y;
+        if (ABL & 2) {
+            e2[2 * h] = o2[2 * h] = __builtin_bit_cast(v2h, d0);
+            e2[2 * h + 1] = o2[2 * h + 1] = __builtin_bit_cast(v2h, d1);
+            return;
+        }
+        e2[2 * h] = wo_dequant_pair(d0, 0x04020400u, sc);     // bytes 0, 2 -> k0 + 4h .. + 1
+        o2[2 * h] = wo_dequant_pair(d0, 0x04030401u, sc);     // bytes 1, 3 -> k0 + 8 + 4h ..
+        e2[2 * h + 1] = wo_dequant_pair(d1, 0x04020400u, sc);
+        o2[2 * h + 1] = wo_dequant_pair(d1, 0x04030401u, sc);
+    };
+    // certify group g: the NST-2 groups issued after it may still be in flight (fewer near the end: drain instead)
+    auto certify = [&](int g) __attribute__((always_inline)) {
+        if (NST > 2 && g + NST - 2 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * GROUP_OPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    // one k step: MFMAs of (j, all row tiles) with the operands E[j] / O[j]; meanwhile `wnext` ([cb] raw groups) is
+    // dequantised into E[j ^ 1] / O[j ^ 1] (DEQ) and the token fragments of the next (j, t) are read
+    auto step = [&](const char* base, auto j_tag, const uint4 (&wnext)[2], auto deq_tag) __attribute__((always_inline)) {
+        constexpr int j = decltype(j_tag)::value;
+        constexpr bool DEQ = decltype(deq_tag)::value;
+        v8h fa[2], fo[2];
+        fa[0] = *reinterpret_cast<const v8h*>(base + aoff[j][0]);
+        fo[0] = *reinterpret_cast<const v8h*>(base + aoff[j][1]);
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                const unsigned d[4] = {w[cb * 2 + j].x, w[cb * 2 + j].y, w[cb * 2 + j].z, w[cb * 2 + j].w};
-                v2h e2[4], o2[4];
-#pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    e2[x] = wo_dequant_pair(d[x], 0x04020400u, scale2[cb]);
-                    o2[x] = wo_dequant_pair(d[x], 0x04030401u, scale2[cb]);
-                }
-                we[cb] = v8h{e2[0][0], e2[0][1], e2[1][0], e2[1][1], e2[2][0], e2[2][1], e2[3][0], e2[3][1]};
-                wod[cb] = v8h{o2[0][0], o2[0][1], o2[1][0], o2[1][1], o2[2][0], o2[2][1], o2[3][0], o2[3][1]};
+        for (int t = 0; t < MTW; ++t) {
+            const int cur = t & 1;
+            if (t + 1 < MTW && !(ABL & 4)) {
+                fa[cur ^ 1] = *reinterpret_cast<const v8h*>(base + (t + 1) * 32 * ROWBW + aoff[j][0]);
+                fo[cur ^ 1] = *reinterpret_cast<const v8h*>(base + (t + 1) * 32 * ROWBW + aoff[j][1]);
             }
+            const v8h we0 = {E[j][0][0][0], E[j][0][0][1], E[j][0][1][0], E[j][0][1][1],
+                             E[j][0][2][0], E[j][0][2][1], E[j][0][3][0], E[j][0][3][1]};
+            const v8h we1 = {E[j][1][0][0], E[j][1][0][1], E[j][1][1][0], E[j][1][1][1],
+                             E[j][1][2][0], E[j][1][2][1], E[j][1][3][0], E[j][1][3][1]};
+            const v8h wo0 = {O[j][0][0][0], O[j][0][0][1], O[j][0][1][0], O[j][0][1][1],
+                             O[j][0][2][0], O[j][0][2][1], O[j][0][3][0], O[j][0][3][1]};
+            const v8h wo1 = {O[j][1][0][0], O[j][1][0][1], O[j][1][1][0], O[j][1][1][1],
+                             O[j][1][2][0], O[j][1][2][1], O[j][1][3][0], O[j][1][3][1]};
+            const int fc = (ABL & 4) ? 0 : cur;
+            if (ABL & 8) {
+                acc[0][t][0] += we0[0] * fa[fc][0] + wo0[1] * fo[fc][1];
+                acc[1][t][0] += we1[0] * fa[fc][0] + wo1[1] * fo[fc][1];
+            } else {
+                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(we0, fa[fc], acc[0][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(we1, fa[fc], acc[1][t], 0, 0, 0);
+                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wo0, fo[fc], acc[0][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wo1, fo[fc], acc[1][t], 0, 0, 0);
+            }
+            // this row tile's share of the next step's dequantisation: 4 (cb, h) units spread over the MTW tiles
+            constexpr int UNITS_LO = MTW >= 4 ? 1 : 4 / MTW; // units per tile that takes any (MTW = 8: every other tile)
+            constexpr int EVERY = MTW > 4 ? MTW / 4 : 1;
+            const bool takes = (t % EVERY) == 0;
+            if constexpr (DEQ) {
+                if (takes) {
 #pragma unroll
-            for (int t = 0; t < MTW; ++t) {
-                const v8h ae = *reinterpret_cast<const v8h*>(base + t * 32 * ROWBW + aoff[j][0]);
-                const v8h ao = *reinterpret_cast<const v8h*>(base + t * 32 * ROWBW + aoff[j][1]);
-                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(we[0], ae, acc[0][t], 0, 0, 0);
-                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(we[1], ae, acc[1][t], 0, 0, 0);
-                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wod[0], ao, acc[0][t], 0, 0, 0);
-                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wod[1], ao, acc[1][t], 0, 0, 0);
+                    for (int q = 0; q < UNITS_LO; ++q) {
+                        const int unit = (MTW <= 4 ? t * UNITS_LO : t / EVERY) + q, cb = unit >> 1, h = unit & 1;
+                        dequant_half(wnext[cb], h, scale2[cb], E[j ^ 1][cb], O[j ^ 1][cb]);
+                    }
+                }
+            }
+            // pin the order: fragment reads first, then one MFMA : its share of the VALU work, four times
+            if constexpr (ABL == 0) {
+                if (t + 1 < MTW) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (DEQ && takes) __builtin_amdgcn_sched_group_barrier(0x002, 3 * UNITS_LO, 0);
+                }
             }
         }
     };
-
-    // ---- main loop: as above -- stage i's operands were issued NST-1 iterations earlier; one barrier per stage -----------
-    uint4 w[NST][4];
-#pragma unroll
-    for (int p = 0; p < NST - 1; ++p) {
-        if (p < nst) {
-            load_w(w[p], s_begin + p);
-            stage_a(p, s_begin + p);
-        }
-    }
     for (int i0 = 0; i0 < nst; i0 += NST) {
 #pragma unroll
         for (int u = 0; u < NST; ++u) {
             const int i = i0 + u;
             if (i >= nst) break;
-            if (NST > 2 && i + NST - 2 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * GROUP_OPS) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (i + NST - 1 < nst) {
-                load_w(w[(u + NST - 1) % NST], s_begin + i + NST - 1);
-                stage_a((i + NST - 1) % NST, s_begin + i + NST - 1);
+            const char* const sb = smem + u * STAGE;
+            const char* const base = sb + trow0 * ROWBW;
+            uint4 wr[2];
+            {
+                // stage i certified at its top; step 0's weights are dequantised in the open, step 1's under step 0's MFMAs
+                certify(i);
+                if (i + NST - 1 < nst) issue(i + NST - 1, (u + NST - 1) % NST);
+                uint4 w0[2];
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    w0[cb] = *reinterpret_cast<const uint4*>(sb + woff[cb][0]);
+                    wr[cb] = *reinterpret_cast<const uint4*>(sb + woff[cb][1]);
+                }
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) dequant_half(w0[cb], h, scale2[cb], E[0][cb], O[0][cb]);
+                __builtin_amdgcn_sched_barrier(0);
+                step(base, std::integral_constant<int, 0>{}, wr, std::true_type{});
+                __builtin_amdgcn_sched_barrier(0);
+                step(base, std::integral_constant<int, 1>{}, wr, std::false_type{});
             }
-            compute(w[u], i % NST);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
@@ -510,37 +598,63 @@ static size_t wo_narrow_workspace(int rows, int N, int K)
     return kSplitkWordsBytes + ntiles * pl.ks * (size_t)pl.mt * 16 * 256 * sizeof(float);
 }
 
-// The wide form (M tiled in the grid, 64-column wave tiles) for more than one 256-token pass.
+// The wide form (64-column wave tiles, both operands through LDS-DMA, M tiled in the grid): its configurations.
+struct WoCfg {
+    int rows, mtw, wmh;
+};
+static constexpr WoCfg kWoCfg[5] = {
+    {0, 0, 0},    // 0: the narrow form above, in passes of 256 tokens
+    {32, 1, 1},   // 1: 4 waves x (32 rows x 64 columns)
+    {64, 2, 1},   // 2: 4 waves x (64 x 64)
+    {128, 2, 2},  // 3: 8 waves x (64 x 64)
+    {256, 4, 2},  // 4: 8 waves x (128 x 64)
+};
+// (Measured and dropped: 4 "fat" waves x (128 x 64) and 4 x (256 x 64), one wave per SIMD, every weight dequantised once
+// per workgroup instead of once per row half -- equal to / 5-8 % slower than the 8-wave forms of the same height.)
 struct WoWidePlan {
-    int mtw; // 32-row tiles per wave: 2 (128-row workgroup tiles) or 4 (256-row); 0: the narrow form in passes
+    int cfg; // index into kWoCfg; 0: the narrow form
     int ks;  // workgroups per tile along K
 };
 
-static std::atomic<int> g_wo_form{-1}; // measurement knob: -1 automatic, 0 narrow passes, 2 / 4 wide with that mtw
+static std::atomic<int> g_wo_abl{0};
+static std::atomic<int> g_wo_form{-1}; // measurement knob: -1 automatic, else the configuration index
 static std::atomic<int> g_wo_ks{-1};   // -1 automatic, else the K split of the wide form (where K allows)
 void set_wo_force(int form, int ks)
 {
-    if (form >= -1) g_wo_form.store(form);
+    if (form >= 100) {
+        g_wo_abl.store(form - 100);
+        return;
+    }
+    if (form == -1) g_wo_abl.store(0);
+    if (form >= -1 && form <= 4) g_wo_form.store(form);
     if (ks >= -1) g_wo_ks.store(ks);
 }
 
-// Plan = the (tile height, K split) with the smallest estimated time.  Constants from tools/w8a16_forms.sh on MI355X
-// (profiles/r02_w8a16_forms.txt): a 64-k stage of a 256-row tile takes ~2.2 us with the whole chip busy (MFMA-bound at the
-// power-capped clock), of a 128-row tile ~1.45 us (the dequantisation VALU work is amortised over half as many rows);
-// both ~15 % less while at most 3/4 of the CUs are busy (higher clocks under the power cap); the hand-over of a K split costs
-// ~6 + 2.5 ks us (128-row tiles) / ~12 + 4.3 ks us (256-row tiles: twice the bytes per workgroup).  K is split only while
-// all workgroups fit one wave (which also bounds the scratch: at most one 256-KiB slot per CU).
+// Plan = the (configuration, K split) with the smallest estimated time.  Constants from tools/w8a16_forms.sh on MI355X
+// (profiles/r02_w8a16_forms.txt), microseconds per 64-k stage with the whole chip busy: 0.61 / 0.75 / 1.25 / 2.1 for 32- /
+// 64- / 128- / 256-row tiles (the dequantisation VALU work is amortised over the rows of a wave: taller is cheaper per
+// row), ~15 % less while at most 3/4 of the CUs are busy (higher clocks under the power cap); the hand-over of a K split
+// costs c0 + c1 ks us, growing with the tile (the last arriver reads ks tiles).  K is split only while all workgroups
+// fit one wave (which also bounds the scratch: at most one 256-KiB slot per CU).  Up to 32 tokens the narrow form's
+// register-streamed weights are as fast or faster (it also serves when the caller gives no scratch: short-M wide tiles
+// rely on the K split to fill the chip).
 static WoWidePlan wo_wide_plan(int M, int N, int K, bool have_scratch)
 {
     const int form = g_wo_form.load(), fks = g_wo_ks.load();
-    if (M <= 256 || form == 0) return {0, 1};
+    if (form == 0 || (form < 0 && (M <= 32 || (M <= 256 && !have_scratch)))) return {0, 1};
     const int cus = num_cus(), tn = (N + wo::BNW - 1) / wo::BNW, nst = K / wo::KBW;
-    const int ks_hi = !have_scratch ? 1 : nst / 8 < 8 ? (nst / 8 < 1 ? 1 : nst / 8) : 8; // at least 8 stages (512 k) each
-    WoWidePlan best{2, 1};
+    static constexpr float kStage[5] = {0.f, 0.61f, 0.75f, 1.25f, 2.1f};
+    static constexpr float kHand0[5] = {0.f, 2.f, 3.f, 6.f, 12.f}, kHand1[5] = {0.f, 0.8f, 1.3f, 2.5f, 4.3f};
+    WoWidePlan best{3, 1};
     float best_t = 1e30f;
-    for (int mtw = 2; mtw <= 4; mtw += 2) {
-        if ((form == 2 || form == 4) && mtw != form) continue;
-        const int rows = 64 * mtw, tiles = ((M + rows - 1) / rows) * tn;
+    for (int cfg = 1; cfg <= 4; ++cfg) {
+        if (form > 0 && cfg != form) continue;
+        const int rows = kWoCfg[cfg].rows, tiles = ((M + rows - 1) / rows) * tn;
+        if (form < 0 && rows >= 2 * M && cfg > 1) break; // (a tile twice as tall as the problem)
+        const int per = rows <= 64 ? 4 : 8; // at least this many stages per workgroup
+        int ks_hi = !have_scratch ? 1 : nst / per;
+        if (ks_hi > (rows <= 64 ? 16 : 8)) ks_hi = rows <= 64 ? 16 : 8;
+        if (ks_hi < 1 || (size_t)tiles * sizeof(unsigned) > kSplitkWordsBytes) ks_hi = 1; // (one hand-over word per tile)
         for (int ks = 1; ks <= ks_hi; ++ks) {
             if (fks > 0) { // (measurements, tests) that split wherever K allows it, whatever the tile count
                 if (ks != (fks <= ks_hi ? fks : 1)) continue;
@@ -549,10 +663,9 @@ static WoWidePlan wo_wide_plan(int M, int N, int K, bool have_scratch)
             }
             const int wgs = tiles * ks, waves = (wgs + cus - 1) / cus;
             const float load = 4 * wgs <= 3 * cus ? 0.85f : 1.f;
-            const float stage = (mtw == 4 ? 2.2f : 1.45f) * load;
-            const float hand = ks == 1 ? 0.f : (mtw == 4 ? 12.f + 4.3f * ks : 6.f + 2.5f * ks);
-            const float t = (float)waves * (float)((nst + ks - 1) / ks) * stage + hand;
-            if (t < best_t) best_t = t, best = WoWidePlan{mtw, ks};
+            const float hand = ks == 1 ? 0.f : kHand0[cfg] + kHand1[cfg] * ks;
+            const float t = (float)waves * (float)((nst + ks - 1) / ks) * kStage[cfg] * load + hand;
+            if (t < best_t) best_t = t, best = WoWidePlan{cfg, ks};
         }
     }
     return best;
@@ -561,17 +674,16 @@ static WoWidePlan wo_wide_plan(int M, int N, int K, bool have_scratch)
 static size_t wo_wide_workspace(int M, int N, int K)
 {
     const WoWidePlan pl = wo_wide_plan(M, N, K, true);
-    if (pl.mtw == 0 || pl.ks <= 1) return 0;
-    const int rows = 64 * pl.mtw;
+    if (pl.cfg == 0 || pl.ks <= 1) return 0;
+    const int rows = kWoCfg[pl.cfg].rows;
     const size_t tiles = (size_t)((M + rows - 1) / rows) * ((N + wo::BNW - 1) / wo::BNW);
-    if (tiles * sizeof(unsigned) > kSplitkWordsBytes) return 0; // (more tiles than hand-over words: no split needed there)
-    return kSplitkWordsBytes + tiles * pl.ks * (size_t)(2 * pl.mtw * 16 * 512) * sizeof(float);
+    return kSplitkWordsBytes + tiles * pl.ks * (size_t)rows * wo::BNW * sizeof(float);
 }
 
 size_t w8a16_gemm_workspace_size(int M, int N, int K)
 {
     if (M <= 4 || N <= 0 || K <= 0) return 0;
-    if (wo_wide_plan(M, N, K, true).mtw != 0) return wo_wide_workspace(M, N, K);
+    if (wo_wide_plan(M, N, K, true).cfg != 0) return wo_wide_workspace(M, N, K);
     // narrow form: passes of at most 256 tokens; a ragged last pass may plan (and size) differently
     const size_t full = wo_narrow_workspace(M < 256 ? M : 256, N, K);
     const size_t tail = (M > 256 && M % 256) ? wo_narrow_workspace(M % 256, N, K) : 0;
@@ -593,18 +705,18 @@ static hipError_t launch_wo(const uint16_t* A, const uint8_t* Wq, const uint16_t
     return hipGetLastError();
 }
 
-template <int MTW, int NST>
+template <int MTW, int WMH, int NST, int ABL = 0>
 static hipError_t launch_wo_wide(const uint16_t* A, const uint8_t* Wq, const uint16_t* scale, uint16_t* Out, int M, int N,
                                  int K, int ks, void* scratch, hipStream_t st)
 {
-    constexpr int rows = 64 * MTW;
-    constexpr size_t lds = (size_t)NST * rows * wo::ROWBW;
+    constexpr int rows = 32 * MTW * WMH;
+    constexpr size_t lds = (size_t)NST * (rows * wo::ROWBW + wo::WSTAGE);
     static_assert(lds <= 160 * 1024 - 64, "LDS budget");
-    auto kern = w8a16_gemm_wide_kernel<MTW, NST>;
+    auto kern = w8a16_gemm_wide_kernel<MTW, WMH, NST, ABL>;
     static DeviceOnce once;
     if (hipError_t e = ensure_dynamic_lds(kern, lds, once); e != hipSuccess) return e;
     const int tiles = ((M + rows - 1) / rows) * ((N + wo::BNW - 1) / wo::BNW);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * ks)), dim3(512), lds, st, A, Wq, scale, Out, M, N, K, ks, scratch);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * ks)), dim3(256 * WMH), lds, st, A, Wq, scale, Out, M, N, K, ks, scratch);
     return hipGetLastError();
 }
 
@@ -615,12 +727,26 @@ hipError_t launch_w8a16_gemm(const void* A, const uint8_t* Wq, const void* scale
     const uint16_t* a = static_cast<const uint16_t*>(A);
     const uint16_t* s = static_cast<const uint16_t*>(scale);
     uint16_t* o = static_cast<uint16_t*>(Out);
-    if (wo_wide_plan(M, N, K, false).mtw != 0) {
-        const size_t need = wo_wide_workspace(M, N, K);
-        const bool have = scratch != nullptr && need != 0 && scratch_bytes >= need;
-        const WoWidePlan pl = wo_wide_plan(M, N, K, have);
-        return pl.mtw == 4 ? launch_wo_wide<4, 3>(a, Wq, s, o, M, N, K, pl.ks, scratch, st)
-                           : launch_wo_wide<2, 4>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
+    const size_t need_wide = wo_wide_workspace(M, N, K); // 0: the plan with scratch is the narrow form or does not split K
+    const WoWidePlan pl = wo_wide_plan(M, N, K, need_wide == 0 || (scratch != nullptr && scratch_bytes >= need_wide));
+    if (pl.cfg != 0) {
+        if (pl.cfg == 4) {
+            switch (g_wo_abl.load()) { // measurement-only ablations of the 256-row form
+            case 1: return launch_wo_wide<4, 2, 3, 1>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
+            case 2: return launch_wo_wide<4, 2, 3, 2>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
+            case 4: return launch_wo_wide<4, 2, 3, 4>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
+            case 8: return launch_wo_wide<4, 2, 3, 8>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
+            case 7: return launch_wo_wide<4, 2, 3, 7>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
+            case 14: return launch_wo_wide<4, 2, 3, 14>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
+            default: break;
+            }
+        }
+        switch (pl.cfg) {
+        case 1: return launch_wo_wide<1, 1, 6>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
+        case 2: return launch_wo_wide<2, 1, 6>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
+        case 3: return launch_wo_wide<2, 2, 4>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
+        default: return launch_wo_wide<4, 2, 3>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
+        }
     }
     for (int m0 = 0; m0 < M; m0 += 256) { // 256-token passes (each streams the weights once)
         const int rows = M - m0 < 256 ? M - m0 : 256;

@@ -94,8 +94,8 @@ def test_ragged_shapes(oracle, M, N, K):
 
 @pytest.fixture
 def form():
-    """Force the form of the fpA_intB GEMM (81 narrow passes | 82 / 84 wide, 128- / 256-row tiles; 86..89: 1 / 2 / 4 / 8
-    workgroups per tile along K); automatic again afterwards."""
+    """Force the form of the fpA_intB GEMM (81 narrow passes | 831..834 wide with 32- / 64- / 128- / 256-row tiles, 82 / 84 =
+    833 / 834; 86..89: 1 / 2 / 4 / 8 workgroups per tile along K); automatic again afterwards."""
     from mixq_tensorrt_llm_amd import _lib
     lib = _lib.load()
     yield lib.mixq_debug_set_gemm_variant
@@ -121,6 +121,22 @@ def test_large_m_forms(oracle, form, which, ks, M, N, K):
     assert np.isfinite(got2).all() and rel_err(got2, want) < REL_TOL
 
 
+@pytest.mark.parametrize("cfg", [831, 832, 833, 834])
+@pytest.mark.parametrize("ks", [85, 86, 88])
+@pytest.mark.parametrize("M,N,K", [(5, 130, 192), (33, 258, 320), (64, 128, 4160), (129, 640, 1088), (257, 256, 2048),
+                                   (300, 1026, 1600)])
+def test_every_configuration_of_the_wide_form(oracle, form, cfg, ks, M, N, K):
+    """The four workgroup shapes of the wide form (32 / 64 rows: 4 waves, 128 / 256 rows: 8 waves), each on shapes smaller and
+    larger than its tile, with K unsplit / split automatically / split 4 ways."""
+    A, q, sc = make(M, N, K, M + 3 * N + K + cfg)
+    qi = interleave(q)
+    want = oracle.w8a16_gemv(A, q, sc)
+    form(cfg)
+    form(ks)
+    got, _ = run(A, qi, sc, N, scratch=True)
+    assert np.isfinite(got).all() and rel_err(got, want) < REL_TOL
+
+
 def test_large_m_forms_agree_exactly_on_integer_data(form):
     """Integer activations, unit scales: every fp32 partial sum is exact, so every form, tile height and K split must give
     the integer product bit for bit."""
@@ -131,7 +147,7 @@ def test_large_m_forms_agree_exactly_on_integer_data(form):
     sc = np.ones(N, np.float16)
     qi = interleave(q)
     want = (A.astype(np.int64) @ q.astype(np.int64)).astype(np.float32).astype(np.float16)
-    for which, ks in [(81, 85), (82, 85), (82, 88), (84, 85), (84, 87), (80, 85)]:
+    for which, ks in [(81, 85), (82, 85), (82, 88), (84, 85), (84, 87), (80, 85), (831, 85), (832, 88), (833, 87)]:
         form(which)
         form(ks)
         got, _ = run(A, qi, sc, N, True)
