@@ -528,6 +528,10 @@ void set_gemm_variant(int v)
         g_variant.store(0);
         return;
     }
+    if (v >= 840 && v <= 842) { // fpA_intB two-pass form: 840 automatic (from 1280 tokens), 841 never, 842 whenever the shape allows
+        set_wo_force(200 + (v - 840), -2);
+        return;
+    }
     if (v >= 831 && v <= 834) { // fpA_intB wide-form configuration 1..4 (w8a16_gemm_kernels.hip kWoCfg)
         set_wo_force(v - 830, -2);
         return;

@@ -248,6 +248,13 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int jy = 0; jy < 2; ++jy)
+                if constexpr (EPI == EPI_F16GEMM) // same 16 bytes per lane per step, read as 8 fp16 of a 16-k step; the
+                                                  // accumulator registers hold fp32 bit patterns
+                    acc[xi][yhalf * 2 + jy] = __builtin_bit_cast(
+                        v16i, __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                                  __builtin_bit_cast(v8h, X[ks]), __builtin_bit_cast(v8h, Y[jy][ks]),
+                                  __builtin_bit_cast(v16f, acc[xi][yhalf * 2 + jy]), 0, 0, 0));
+                else
                 acc[xi][yhalf * 2 + jy] =
                     (ABL & 32) ? __builtin_amdgcn_mfma_i32_32x32x32_i8(Y[jy][ks], X[ks], acc[xi][yhalf * 2 + jy], 0, 0, 0)
                                : __builtin_amdgcn_mfma_i32_32x32x32_i8(X[ks], Y[jy][ks], acc[xi][yhalf * 2 + jy], 0, 0, 0);
@@ -532,7 +539,7 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
     float sa[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) // (clamped rows are never stored)
-        sa[j] = 2 * j < nt ? h2f(p.sA[min(m0 + wm * 128 + jmap(j) * 32 + lr, p.M - 1)]) : 0.f;
+        sa[j] = EPI == EPI_F16GEMM ? 1.f : 2 * j < nt ? h2f(p.sA[min(m0 + wm * 128 + jmap(j) * 32 + lr, p.M - 1)]) : 0.f;
 
     // side GEMM of tile (i, j): 8 k-steps of 16 outlier columns
     auto side = [&](int i, int j) __attribute__((always_inline)) {
@@ -563,7 +570,8 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-            swq[i][g] = *reinterpret_cast<const uint2*>(p.sW + min(n0 + wn * 64 + imap(i) * 32 + 4 * lh + 8 * g, p.N - 4));
+            swq[i][g] = EPI == EPI_F16GEMM ? make_uint2(0u, 0u)
+                                           : *reinterpret_cast<const uint2*>(p.sW + min(n0 + wn * 64 + imap(i) * 32 + 4 * lh + 8 * g, p.N - 4));
     // [M,N] fp16 operands of the epilogue (the caller's addend y, the gate*up multiplicand) take the store path in
     // reverse: coalesced 16-byte loads of 128-byte row segments (8 rows per instruction), one block ahead, then through
     // the wave's window into the accumulator layout (8 bytes = 4 consecutive n of row lane & 31).  Reading them in the
@@ -627,8 +635,16 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
                 } else {
                     c2 = v2f{h2f(yh[e2]), h2f(yh[e2 + 1])};
                 }
-                float v0 = __builtin_fmaf((float)acc[i][j][4 * g + e2], s2[0], c2[0]);
-                float v1 = __builtin_fmaf((float)acc[i][j][4 * g + e2 + 1], s2[1], c2[1]);
+                float v0, v1;
+                if constexpr (EPI == EPI_F16GEMM) { // fp32 sums of the fp16 GEMM: one rounding to fp16 below
+                    // (through named ints: __builtin_bit_cast applied to a vector ELEMENT expression reads element 0)
+                    const int b0 = acc[i][j][4 * g + e2], b1 = acc[i][j][4 * g + e2 + 1];
+                    v0 = __builtin_bit_cast(float, b0);
+                    v1 = __builtin_bit_cast(float, b1);
+                } else {
+                    v0 = __builtin_fmaf((float)acc[i][j][4 * g + e2], s2[0], c2[0]);
+                    v1 = __builtin_fmaf((float)acc[i][j][4 * g + e2 + 1], s2[1], c2[1]);
+                }
                 if (epi_has_silu(EPI)) {
                     v0 = silu_f32(v0);
                     v1 = silu_f32(v1);
@@ -762,6 +778,8 @@ static hipError_t launch_pp_cfg(const GemmParams& p, hipStream_t st)
     return hipGetLastError();
 }
 
+hipError_t launch_gemm_f16_pp(const void* A, const void* B, void* D, int M, int N, int K, const void* zeros, hipStream_t st);
+
 template <int EPI>
 static hipError_t launch_pp_epi(const GemmParams& p, hipStream_t st)
 {
@@ -769,6 +787,16 @@ static hipError_t launch_pp_epi(const GemmParams& p, hipStream_t st)
     if (has_o) return launch_pp_cfg<EPI, true, false>(p, st); // the API never passes both an addend and outliers
     if (has_y) return launch_pp_cfg<EPI, false, true>(p, st);
     return launch_pp_cfg<EPI, false, false>(p, st);
+}
+
+hipError_t launch_gemm_f16_pp(const void* A, const void* B, void* D, int M, int N, int K, const void* zeros, hipStream_t st)
+{
+    if (K % 8 || N % 8) return hipErrorInvalidValue;
+    if (M <= 0 || N <= 0) return hipSuccess;
+    GemmParams p{};
+    p.A = static_cast<const int8_t*>(A), p.B = static_cast<const int8_t*>(B), p.D = D, p.zeros = zeros;
+    p.M = M, p.N = N, p.K = 2 * K; // the kernel counts K in bytes
+    return launch_pp_cfg<EPI_F16GEMM, false, false>(p, st);
 }
 
 // ---- K split over 2 / 4 workgroups per tile (see the kernel header) ---------------------------------------------------

@@ -35,7 +35,9 @@ inline hipError_t ensure_dynamic_lds(Kern kern, size_t bytes, DeviceOnce& once)
 }
 int num_cus(); // of the current device (cached per device)
 
-enum { EPI_DEQUANT = 0, EPI_DEQUANT_SILU = 1, EPI_INT32 = 2, EPI_DEQUANT_SILU_MUL = 3 };
+enum { EPI_DEQUANT = 0, EPI_DEQUANT_SILU = 1, EPI_INT32 = 2, EPI_DEQUANT_SILU_MUL = 3,
+       EPI_F16GEMM = 4 }; // 4: the operands are fp16 (K counts BYTES), fp32 accumulation, D = fp16(A B^T): the ping-pong kernel
+                          // with v_mfma_f32_32x32x16_f16 (second pass of the two-pass fpA_intB GEMM, w8a16_gemm_kernels.hip)
 constexpr bool epi_has_silu(int epi) { return epi == EPI_DEQUANT_SILU || epi == EPI_DEQUANT_SILU_MUL; }
 
 struct GemmParams {
@@ -62,7 +64,9 @@ struct GemmParams {
 
 hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st);
 hipError_t launch_gemm_pp(const GemmParams& p, int epi, hipStream_t st);  // 256x256 ping-pong schedule
-hipError_t launch_gemm_pp128(const GemmParams& p, int epi, hipStream_t st); // 128x256 ping-pong schedule (mid-size problems)
+hipError_t launch_gemm_pp128(const GemmParams& p, int epi, hipStream_t st);
+// D[M,N] fp16 = A[M,K] B[N,K]^T, fp16 operands (K % 8 == 0, N % 8 == 0, 16-byte aligned rows), fp32 accumulation
+hipError_t launch_gemm_f16_pp(const void* A, const void* B, void* D, int M, int N, int K, const void* zeros, hipStream_t st); // 128x256 ping-pong schedule (mid-size problems)
 bool gemm_pp128_wins(int M, int N, int K); // launch_gemm's rule for taking the 128x256 tiles (then no K split, no scratch)
 constexpr size_t kSplitkWordsBytes = 16384; // hand-over words (64 B per tile) of up to 256 split tiles, at the start of the scratch
 struct SplitPlan {

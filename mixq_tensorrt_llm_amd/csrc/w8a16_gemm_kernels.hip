@@ -569,6 +569,39 @@ __global__ __launch_bounds__(256 * WMH) void w8a16_gemm_wide_kernel(const uint16
         }
 }
 
+// ---- the two-pass form (large M): dequantise W once, then the 256x256 ping-pong kernel with the fp16 MFMA -------------------
+// In the fused forms every weight is dequantised once per 64 / 128 token rows (3 packed-f16 VALU per 2 weights beside the
+// MFMAs: -25 % of the time of a full-chip launch when ablated).  From ~1300 tokens on it is cheaper to pay
+// ~3 bytes of HBM traffic per weight once: this kernel writes Wf[n][k] = fp16((q[k][n] - 128) * scale[n]) -- the very
+// values the fused forms feed the matrix cores -- row-major with K contiguous, which is the B operand layout of
+// gemm_w8a8o16_pp_kernel<EPI_F16GEMM> (gemm_pp_kernels.hip).  One thread per 16-byte group of the interleaved image:
+// group G of the image = column pair G / (K/8), 64-row block (G % (K/8)) / 8, column 2p + (G % 8) / 4, group (G % 4) of
+// the block: even bytes k0..k0+7, odd bytes k0+8..k0+15 (see the header).  Fully coalesced 16-byte loads, 32-byte stores.
+__global__ __launch_bounds__(256) void w8a16_dequant_kernel(const uint8_t* __restrict__ Wq, const uint16_t* __restrict__ scale,
+                                                             uint16_t* __restrict__ Wf, int N, int K)
+{
+    const int64_t G = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int gpp = K >> 3; // 16-byte groups per column pair
+    if (G >= (int64_t)(N >> 1) * gpp) return;
+    const int pair = (int)(G / gpp), r = (int)(G - (int64_t)pair * gpp);
+    const int col = 2 * pair + ((r >> 2) & 1), k0 = (r >> 3) * 64 + (r & 3) * 16;
+    const uint4 wv = *reinterpret_cast<const uint4*>(Wq + G * 16);
+    _Float16 sc;
+    const uint16_t sb = scale[col];
+    __builtin_memcpy(&sc, &sb, 2);
+    const v2h sc2 = {sc, sc};
+    const unsigned d[4] = {wv.x, wv.y, wv.z, wv.w};
+    unsigned e[4], o[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        e[x] = __builtin_bit_cast(unsigned, wo_dequant_pair(d[x], 0x04020400u, sc2)); // k0 + 2x, + 1
+        o[x] = __builtin_bit_cast(unsigned, wo_dequant_pair(d[x], 0x04030401u, sc2)); // k0 + 8 + 2x, + 1
+    }
+    uint4* const dst = reinterpret_cast<uint4*>(Wf + (int64_t)col * K + k0);
+    dst[0] = uint4{e[0], e[1], e[2], e[3]};
+    dst[1] = uint4{o[0], o[1], o[2], o[3]};
+}
+
 // ---- host side ----------------------------------------------------------------------------------------------------------
 struct WoPlan {
     int mt;  // 32-row tiles per pass (1, 2, 4, 8)
@@ -617,15 +650,20 @@ struct WoWidePlan {
 };
 
 static std::atomic<int> g_wo_abl{0};
+static std::atomic<int> g_wo_twopass{-1}; // -1 automatic, 0 never, 1 whenever the shape allows it (measurements, tests)
 static std::atomic<int> g_wo_form{-1}; // measurement knob: -1 automatic, else the configuration index
 static std::atomic<int> g_wo_ks{-1};   // -1 automatic, else the K split of the wide form (where K allows)
 void set_wo_force(int form, int ks)
 {
+    if (form >= 200) { // 200 automatic, 201 never, 202 always
+        g_wo_twopass.store(form == 200 ? -1 : form - 201);
+        return;
+    }
     if (form >= 100) {
         g_wo_abl.store(form - 100);
         return;
     }
-    if (form == -1) g_wo_abl.store(0);
+    if (form == -1) g_wo_abl.store(0), g_wo_twopass.store(-1);
     if (form >= -1 && form <= 4) g_wo_form.store(form);
     if (ks >= -1) g_wo_ks.store(ks);
 }
@@ -680,9 +718,27 @@ static size_t wo_wide_workspace(int M, int N, int K)
     return kSplitkWordsBytes + tiles * pl.ks * (size_t)rows * wo::BNW * sizeof(float);
 }
 
+// Two-pass form: for large problems, if the
+// caller's scratch holds the fp16 image of W (N * K * 2 bytes) and the rows of the output are 16-byte aligned (N % 8 == 0).
+// Measured crossover (profiles/r02_w8a16_gemm.txt): the second pass runs 256 x 256 tiles only, so it needs about a full
+// wave of them (>= 200) besides enough rows to amortise the dequantisation pass.
+constexpr int kTwoPassMinM = 1280;
+static bool wo_two_pass_wanted(int M, int N, int K)
+{
+    const int f = g_wo_twopass.load();
+    if (f == 0 || M <= 4 || N % 8 || K % 64) return false;
+    return f == 1 || (M >= kTwoPassMinM && (int64_t)((M + 255) / 256) * ((N + 255) / 256) >= 200);
+}
+// (the image sits BEHIND the hand-over words of the K splits, which every call must leave zero)
+static size_t wo_two_pass_bytes(int N, int K) { return kSplitkWordsBytes + (size_t)N * K * 2; }
+
 size_t w8a16_gemm_workspace_size(int M, int N, int K)
 {
     if (M <= 4 || N <= 0 || K <= 0) return 0;
+    if (wo_two_pass_wanted(M, N, K)) { // (a smaller scratch still serves the wide form's K split, or none)
+        const size_t wide = wo_wide_plan(M, N, K, true).cfg != 0 ? wo_wide_workspace(M, N, K) : 0;
+        return wo_two_pass_bytes(N, K) > wide ? wo_two_pass_bytes(N, K) : wide;
+    }
     if (wo_wide_plan(M, N, K, true).cfg != 0) return wo_wide_workspace(M, N, K);
     // narrow form: passes of at most 256 tokens; a ragged last pass may plan (and size) differently
     const size_t full = wo_narrow_workspace(M < 256 ? M : 256, N, K);
@@ -727,6 +783,13 @@ hipError_t launch_w8a16_gemm(const void* A, const uint8_t* Wq, const void* scale
     const uint16_t* a = static_cast<const uint16_t*>(A);
     const uint16_t* s = static_cast<const uint16_t*>(scale);
     uint16_t* o = static_cast<uint16_t*>(Out);
+    if (wo_two_pass_wanted(M, N, K) && scratch != nullptr && scratch_bytes >= wo_two_pass_bytes(N, K)) {
+        const int64_t groups = (int64_t)(N >> 1) * (K >> 3);
+        uint16_t* const wf = reinterpret_cast<uint16_t*>(static_cast<char*>(scratch) + kSplitkWordsBytes);
+        hipLaunchKernelGGL(w8a16_dequant_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, Wq, s, wf, N, K);
+        if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+        return launch_gemm_f16_pp(A, wf, Out, M, N, K, zeros, st);
+    }
     const size_t need_wide = wo_wide_workspace(M, N, K); // 0: the plan with scratch is the narrow form or does not split K
     const WoWidePlan pl = wo_wide_plan(M, N, K, need_wide == 0 || (scratch != nullptr && scratch_bytes >= need_wide));
     if (pl.cfg != 0) {

@@ -99,7 +99,7 @@ def form():
     from mixq_tensorrt_llm_amd import _lib
     lib = _lib.load()
     yield lib.mixq_debug_set_gemm_variant
-    lib.mixq_debug_set_gemm_variant(80)
+    lib.mixq_debug_set_gemm_variant(80)   # (also: two-pass form automatic again)
     lib.mixq_debug_set_gemm_variant(85)
 
 
@@ -137,6 +137,24 @@ def test_every_configuration_of_the_wide_form(oracle, form, cfg, ks, M, N, K):
     assert np.isfinite(got).all() and rel_err(got, want) < REL_TOL
 
 
+@pytest.mark.parametrize("M,N,K", [(5, 8, 64), (33, 264, 320), (300, 1032, 1600), (700, 136, 448), (1300, 2304, 1088),
+                                   (2048, 512, 4096)])
+def test_two_pass_form(oracle, form, M, N, K):
+    """Dequantise-once + fp16 ping-pong GEMM (automatic from 1280 tokens; forced here on every size): the weights it
+    multiplies are the fused forms' fp16((q - 128) * scale), so the same tolerance holds; ragged M / N tiles, N % 256,
+    K of 1 .. 64 slices; a second call on the same scratch gives the same bits and leaves the hand-over words zero."""
+    A, q, sc = make(M, N, K, 2 * M + N + K)
+    qi = interleave(q)
+    want = oracle.w8a16_gemv(A, q, sc)
+    form(842)
+    got, nws = run(A, qi, sc, N, scratch=True)
+    assert nws >= 16384 + 2 * N * K
+    assert np.isfinite(got).all() and rel_err(got, want) < REL_TOL
+    form(841)
+    ref, _ = run(A, qi, sc, N, scratch=True)
+    assert rel_err(got, ref) < REL_TOL
+
+
 def test_large_m_forms_agree_exactly_on_integer_data(form):
     """Integer activations, unit scales: every fp32 partial sum is exact, so every form, tile height and K split must give
     the integer product bit for bit."""
@@ -147,7 +165,7 @@ def test_large_m_forms_agree_exactly_on_integer_data(form):
     sc = np.ones(N, np.float16)
     qi = interleave(q)
     want = (A.astype(np.int64) @ q.astype(np.int64)).astype(np.float32).astype(np.float16)
-    for which, ks in [(81, 85), (82, 85), (82, 88), (84, 85), (84, 87), (80, 85), (831, 85), (832, 88), (833, 87)]:
+    for which, ks in [(81, 85), (82, 85), (82, 88), (84, 85), (84, 87), (80, 85), (831, 85), (832, 88), (833, 87), (842, 85)]:
         form(which)
         form(ks)
         got, _ = run(A, qi, sc, N, True)
