@@ -43,7 +43,7 @@ def main():
             out = torch.empty((M, N), dtype=torch.float16, device=dev)
             cells = []
             for knobs in sets:
-                lib.mixq_debug_set_gemm_variant(80)
+                lib.mixq_debug_set_gemm_variant(80)   # (also: ablations off, two-pass form automatic)
                 lib.mixq_debug_set_gemm_variant(85)
                 for v in knobs:
                     lib.mixq_debug_set_gemm_variant(v)
