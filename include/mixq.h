@@ -203,7 +203,9 @@ MIXQ_API int mixq_w8a16_gemm_forward(const void* input_f16, const uint8_t* weigh
                                      void* output_f16, int m, int n, int k, void* stream);
 /* The same with caller-owned scratch (MI355X extension; CUTLASS' split-k workspace, fpA_intB_gemm_wrapper.cu:16-25, is the
  * counterpart): with few column tiles K is split over several workgroups per tile, which keeps every CU streaming
- * weights.  mixq_w8a16_gemm_workspace_size(m,n,k) bytes (0: no split for this shape), ZERO-FILLED before its first use,
+ * weights; large problems (from ~1300 tokens) run in two passes -- W dequantised once to fp16 in the scratch (n k 2 bytes
+ * behind the hand-over words), then the fp16 ping-pong GEMM -- when the scratch is large enough, the fused form otherwise.
+ * mixq_w8a16_gemm_workspace_size(m,n,k) bytes (0: nothing to gain for this shape), ZERO-FILLED before its first use,
  * one per stream; it may be the same buffer as mixq_gemm_mixed_scratch's (every kernel leaves the hand-over words zero).
  * Results do not depend on whether / how K was split in the last bit only up to fp32 summation order: the parts are
  * always added in the same order, so a given (shape, scratch-or-not) is deterministic. */
