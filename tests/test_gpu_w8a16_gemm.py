@@ -155,6 +155,29 @@ def test_two_pass_form(oracle, form, M, N, K):
     assert rel_err(got, ref) < REL_TOL
 
 
+def test_randomised_soak_over_forms_and_shapes(oracle, form):
+    """120 random (M, N, K) x a random form (narrow / one of the four wide tile heights / two-pass / automatic) x a random
+    K split, against the oracle: ragged everything, N % 4 == 2 included, K from one 64-k stage up."""
+    rng = np.random.default_rng(2024)
+    knobs_form = [80, 81, 831, 832, 833, 834, 842]
+    knobs_ks = [85, 86, 87, 88, 89]
+    for it in range(120):
+        M = int(rng.integers(5, 420)) if it % 4 else int(rng.integers(5, 40))
+        N = 2 * int(rng.integers(1, 520))
+        K = 64 * int(rng.integers(1, 28))
+        f, k = int(rng.choice(knobs_form)), int(rng.choice(knobs_ks))
+        A, q, sc = make(M, N, K, 7000 + it)
+        qi = interleave(q)
+        want = oracle.w8a16_gemv(A, q, sc)
+        form(80)
+        form(85)
+        form(f)
+        form(k)
+        got, _ = run(A, qi, sc, N, scratch=bool(it % 3))
+        assert np.isfinite(got).all(), (it, M, N, K, f, k)
+        assert rel_err(got, want) < REL_TOL, (it, M, N, K, f, k, rel_err(got, want))
+
+
 def test_large_m_forms_agree_exactly_on_integer_data(form):
     """Integer activations, unit scales: every fp32 partial sum is exact, so every form, tile height and K split must give
     the integer product bit for bit."""
