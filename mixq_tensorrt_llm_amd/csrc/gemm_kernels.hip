@@ -528,6 +528,10 @@ void set_gemm_variant(int v)
         g_variant.store(0);
         return;
     }
+    if (v >= 850 && v <= 855) { // fpA_intB skinny form (5..32 tokens): 850 automatic, 851 off, 852..855 a fixed shape
+        set_wo_force(300 + (v - 850), -2);
+        return;
+    }
     if (v >= 840 && v <= 842) { // fpA_intB two-pass form: 840 automatic (from 1280 tokens), 841 never, 842 whenever the shape allows
         set_wo_force(200 + (v - 840), -2);
         return;

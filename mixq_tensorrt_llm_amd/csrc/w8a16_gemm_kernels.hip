@@ -569,6 +569,118 @@ __global__ __launch_bounds__(256 * WMH) void w8a16_gemm_wide_kernel(const uint16
         }
 }
 
+// ---- the skinny form (5 .. 32 tokens): an MFMA GEMV ------------------------------------------------------------------------
+// Up to 32 tokens the operator is a weight stream (N K bytes) with almost no arithmetic; the narrow form spends its time on
+// launch + first-byte latency + the cross-workgroup K split it needs to fill the chip with 128-column tiles.  Built like
+// the decode GEMV and the int8 skinny kernel instead: a workgroup = 32 output columns x KW waves that split K (partials meet
+// in LDS: no cross-workgroup hand-over, no scratch), weights straight from memory into MFMA A fragments
+// (v_mfma_f32_16x16x32_f16: lane (n = l % 16, kq = l / 16) loads 16-byte group kq of its column's 64-row block; even bytes
+// = the lane's 8 k-values of one MFMA, odd bytes those of the next), the token fragments (B operand: lane (m, kq) = 32
+// contiguous bytes of token row m per block) through L2, shared by the wave's two 16-column groups.  No LDS staging, no
+// barrier in the loop, every load counted by the compiler.
+typedef float v4f_ __attribute__((ext_vector_type(4)));
+
+// CG: 16-column groups per wave (2 or 4: the token fragments are shared by CG MFMA A operands)
+template <int MT, int KW, int CG>
+__global__ __launch_bounds__(KW * 64) void w8a16_skinny_kernel(const uint16_t* __restrict__ A, const uint8_t* __restrict__ Wq,
+                                                                const uint16_t* __restrict__ scale,
+                                                                uint16_t* __restrict__ Out, int M, int N, int K)
+{
+    __shared__ v4f_ part[KW][CG][MT][64]; // [K part][column group][token tile][lane]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ln = lane & 15, kq = lane >> 4;
+    const int n0 = blockIdx.x * (16 * CG);
+
+    const int nblk = K >> 6; // 64-row blocks
+    const int per = (nblk + KW - 1) / KW;
+    const int b_begin = min(wave * per, nblk), b_end = min(b_begin + per, nblk);
+
+    const uint8_t* wsrc[CG];
+    v2h scale2[CG];
+#pragma unroll
+    for (int cg = 0; cg < CG; ++cg) {
+        const int col = min(n0 + cg * 16 + ln, N - 1); // clamped columns are computed, never stored
+        wsrc[cg] = Wq + (int64_t)(col >> 1) * 2 * K + (col & 1) * 64 + kq * 16;
+        _Float16 sc;
+        const uint16_t sb = scale[col];
+        __builtin_memcpy(&sc, &sb, 2);
+        scale2[cg] = v2h{sc, sc};
+    }
+    const uint16_t* asrc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) asrc[t] = A + (int64_t)min(t * 16 + ln, M - 1) * K + kq * 16;
+
+    v4f_ acc[CG][MT];
+#pragma unroll
+    for (int cg = 0; cg < CG; ++cg)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[cg][t] = v4f_{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int UB = CG == 2 ? 4 : 2; // blocks per batch: 8 weight loads + 2 UB MT token loads in flight per lane
+    for (int b0 = b_begin; b0 < b_end; b0 += UB) {
+        uint4 wv[UB][CG];
+        uint4 av[UB][MT][2];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int b = min(b0 + u, b_end - 1); // (the tail re-reads the last block; its products are skipped below)
+#pragma unroll
+            for (int cg = 0; cg < CG; ++cg) wv[u][cg] = *reinterpret_cast<const uint4*>(wsrc[cg] + (int64_t)b * 128);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                av[u][t][0] = *reinterpret_cast<const uint4*>(asrc[t] + b * 64);
+                av[u][t][1] = *reinterpret_cast<const uint4*>(asrc[t] + b * 64 + 8);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            if (b0 + u >= b_end) break;
+#pragma unroll
+            for (int cg = 0; cg < CG; ++cg) {
+                const unsigned d[4] = {wv[u][cg].x, wv[u][cg].y, wv[u][cg].z, wv[u][cg].w};
+                v2h e2[4], o2[4];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    e2[x] = wo_dequant_pair(d[x], 0x04020400u, scale2[cg]);
+                    o2[x] = wo_dequant_pair(d[x], 0x04030401u, scale2[cg]);
+                }
+                const v8h we = {e2[0][0], e2[0][1], e2[1][0], e2[1][1], e2[2][0], e2[2][1], e2[3][0], e2[3][1]};
+                const v8h wod = {o2[0][0], o2[0][1], o2[1][0], o2[1][1], o2[2][0], o2[2][1], o2[3][0], o2[3][1]};
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    acc[cg][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(we, __builtin_bit_cast(v8h, av[u][t][0]), acc[cg][t], 0, 0, 0);
+                    acc[cg][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wod, __builtin_bit_cast(v8h, av[u][t][1]), acc[cg][t], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int cg = 0; cg < CG; ++cg)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) part[wave][cg][t][lane] = acc[cg][t];
+    __syncthreads();
+
+    // wave w finishes (column group, token tile) w: the KW parts are added in K order (a fixed order: same bits every run)
+    for (int job = wave; job < CG * MT; job += KW) {
+        const int cg = job / MT, t = job % MT;
+        v4f_ sum = part[0][cg][t][lane];
+#pragma unroll
+        for (int w2 = 1; w2 < KW; ++w2) sum += part[w2][cg][t][lane];
+        // C/D layout of the 16x16 MFMA: column (token) = lane % 16, rows (output columns) 4 * (lane / 16) + r
+        const int m = t * 16 + ln, n = n0 + cg * 16 + 4 * kq;
+        if (m >= M) continue;
+        uint16_t* dst = Out + (int64_t)m * N + n;
+        const v2h lo = f2h2(sum[0], sum[1]), hi = f2h2(sum[2], sum[3]);
+        if (n + 3 < N && (N & 3) == 0) {
+            *reinterpret_cast<uint2*>(dst) = uint2{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+        } else {
+            if (n + 1 < N) *reinterpret_cast<unsigned*>(dst) = __builtin_bit_cast(unsigned, lo);
+            if (n + 3 < N) *reinterpret_cast<unsigned*>(dst + 2) = __builtin_bit_cast(unsigned, hi);
+        }
+    }
+}
+
 // ---- the two-pass form (large M): dequantise W once, then the 256x256 ping-pong kernel with the fp16 MFMA -------------------
 // In the fused forms every weight is dequantised once per 64 / 128 token rows (3 packed-f16 VALU per 2 weights beside the
 // MFMAs: -25 % of the time of a full-chip launch when ablated).  From ~1300 tokens on it is cheaper to pay
@@ -650,11 +762,16 @@ struct WoWidePlan {
 };
 
 static std::atomic<int> g_wo_abl{0};
+static std::atomic<int> g_wo_skinny{1}; // the skinny form up to 32 tokens: 1 automatic, 0 off, 2..5 a fixed shape (measurements)
 static std::atomic<int> g_wo_twopass{-1}; // -1 automatic, 0 never, 1 whenever the shape allows it (measurements, tests)
 static std::atomic<int> g_wo_form{-1}; // measurement knob: -1 automatic, else the configuration index
 static std::atomic<int> g_wo_ks{-1};   // -1 automatic, else the K split of the wide form (where K allows)
 void set_wo_force(int form, int ks)
 {
+    if (form >= 300 && form <= 305) { // skinny form: 300 automatic, 301 off, 302..305 a fixed shape
+        g_wo_skinny.store(form == 300 ? 1 : form == 301 ? 0 : form - 300);
+        return;
+    }
     if (form >= 200) { // 200 automatic, 201 never, 202 always
         g_wo_twopass.store(form == 200 ? -1 : form - 201);
         return;
@@ -663,7 +780,7 @@ void set_wo_force(int form, int ks)
         g_wo_abl.store(form - 100);
         return;
     }
-    if (form == -1) g_wo_abl.store(0), g_wo_twopass.store(-1);
+    if (form == -1) g_wo_abl.store(0), g_wo_twopass.store(-1), g_wo_skinny.store(1);
     if (form >= -1 && form <= 4) g_wo_form.store(form);
     if (ks >= -1) g_wo_ks.store(ks);
 }
@@ -718,6 +835,24 @@ static size_t wo_wide_workspace(int M, int N, int K)
     return kSplitkWordsBytes + tiles * pl.ks * (size_t)rows * wo::BNW * sizeof(float);
 }
 
+// Skinny form (5..32 tokens): which shape, or 0 for the narrow form.  Its cost is weight bytes + token bytes through the
+// same L2 -> CU path (every wave reads the token rows of its K range: M / 16 bytes of tokens per weight byte with 32
+// columns per wave, M / 32 with 64), the narrow form's is flat in M but carries the K-split hand-over; crossovers measured
+// with tools/w8a16_bench.py (profiles/r02_w8a16_gemm.txt): 2 = 32 columns x 8 waves, 3 = 32 x 16, 4 = 64 x 8, 5 = 64 x 16.
+static int wo_skinny_pick(int M, int N, int K)
+{
+    const int v = g_wo_skinny.load();
+    if (v == 0 || M > 32 || M <= 4 || g_wo_form.load() >= 0 || g_wo_twopass.load() == 1) return 0; // (a forced form switches it off)
+    if (v > 1) return v;
+    const double mb = (double)N * K * 1e-6;
+    if (N >= 16384) return M <= 24 ? 4 : 0;
+    if (N >= 8192) return M <= 12 ? 2 : 5;
+    if (M <= 6 && K >= 8192) return 3;
+    if (M <= 16) return 2;
+    if (M <= 24) return mb <= 50. ? 2 : 0;
+    return mb <= 20. ? 2 : 0;
+}
+
 // Two-pass form: for large problems, if the
 // caller's scratch holds the fp16 image of W (N * K * 2 bytes) and the rows of the output are 16-byte aligned (N % 8 == 0).
 // Measured crossover (profiles/r02_w8a16_gemm.txt): the second pass runs 256 x 256 tiles only, so it needs about a full
@@ -735,6 +870,7 @@ static size_t wo_two_pass_bytes(int N, int K) { return kSplitkWordsBytes + (size
 size_t w8a16_gemm_workspace_size(int M, int N, int K)
 {
     if (M <= 4 || N <= 0 || K <= 0) return 0;
+    if (wo_skinny_pick(M, N, K) != 0) return 0; // (K is split inside the workgroup)
     if (wo_two_pass_wanted(M, N, K)) { // (a smaller scratch still serves the wide form's K split, or none)
         const size_t wide = wo_wide_plan(M, N, K, true).cfg != 0 ? wo_wide_workspace(M, N, K) : 0;
         return wo_two_pass_bytes(N, K) > wide ? wo_two_pass_bytes(N, K) : wide;
@@ -758,6 +894,15 @@ static hipError_t launch_wo(const uint16_t* A, const uint8_t* Wq, const uint16_t
     const int ntiles = (N + wo::BN - 1) / wo::BN;
     hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles * ks)), dim3(256 * WM), lds, st, A, Wq, scale, Out, M, N, K, ks, scratch,
                        zeros);
+    return hipGetLastError();
+}
+
+template <int MT, int KW, int CG>
+static hipError_t launch_wo_skinny(const uint16_t* A, const uint8_t* Wq, const uint16_t* scale, uint16_t* Out, int M, int N,
+                                   int K, hipStream_t st)
+{
+    hipLaunchKernelGGL((w8a16_skinny_kernel<MT, KW, CG>), dim3((unsigned)((N + 16 * CG - 1) / (16 * CG))), dim3(KW * 64), 0, st,
+                       A, Wq, scale, Out, M, N, K);
     return hipGetLastError();
 }
 
@@ -789,6 +934,22 @@ hipError_t launch_w8a16_gemm(const void* A, const uint8_t* Wq, const void* scale
         hipLaunchKernelGGL(w8a16_dequant_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, Wq, s, wf, N, K);
         if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
         return launch_gemm_f16_pp(A, wf, Out, M, N, K, zeros, st);
+    }
+    if (const int pick = wo_skinny_pick(M, N, K); pick != 0) {
+        if (M <= 16) {
+            switch (pick) {
+            case 2: return launch_wo_skinny<1, 8, 2>(a, Wq, s, o, M, N, K, st);
+            case 3: return launch_wo_skinny<1, 16, 2>(a, Wq, s, o, M, N, K, st);
+            case 4: return launch_wo_skinny<1, 8, 4>(a, Wq, s, o, M, N, K, st);
+            default: return launch_wo_skinny<1, 16, 4>(a, Wq, s, o, M, N, K, st);
+            }
+        }
+        switch (pick) {
+        case 2: return launch_wo_skinny<2, 8, 2>(a, Wq, s, o, M, N, K, st);
+        case 3: return launch_wo_skinny<2, 16, 2>(a, Wq, s, o, M, N, K, st);
+        case 4: return launch_wo_skinny<2, 8, 4>(a, Wq, s, o, M, N, K, st);
+        default: return launch_wo_skinny<2, 16, 4>(a, Wq, s, o, M, N, K, st);
+        }
     }
     const size_t need_wide = wo_wide_workspace(M, N, K); // 0: the plan with scratch is the narrow form or does not split K
     const WoWidePlan pl = wo_wide_plan(M, N, K, need_wide == 0 || (scratch != nullptr && scratch_bytes >= need_wide));
