@@ -528,6 +528,10 @@ void set_gemm_variant(int v)
         g_variant.store(0);
         return;
     }
+    if (v >= 856 && v <= 858) { // decode batches (2..4 tokens) through the fpA_intB skinny form: 856 always, 857 never, 858 automatic
+        set_wo_force(306 + (v - 856), -2);
+        return;
+    }
     if (v >= 850 && v <= 855) { // fpA_intB skinny form (5..32 tokens): 850 automatic, 851 off, 852..855 a fixed shape
         set_wo_force(300 + (v - 850), -2);
         return;

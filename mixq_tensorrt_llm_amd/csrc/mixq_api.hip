@@ -607,7 +607,8 @@ int mixq_w8a16_gemm_forward_ws(const void* input, const uint8_t* weight, const v
     if (!aligned16(input) || !aligned16(weight)) return MIXQ_E_ALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
     // fpA_intB_gemm_wrapper.cu:45-70: m <= SMALL_M_FAST_PATH -> the batched GEMV, else the mixed-input tensor-core GEMM
-    if (m <= kSmallMFastPath) return hip_rc(mixq::launch_w8a16(input, weight, scale, output, m, n, k, st));
+    if (m <= kSmallMFastPath && !mixq::w8a16_skinny_takes(m, n, k))
+        return hip_rc(mixq::launch_w8a16(input, weight, scale, output, m, n, k, st));
     if (k % 8 || (reinterpret_cast<uintptr_t>(output) & 3u)) return MIXQ_E_ALIGN;
     const void* zeros = mixq::zero_page();
     if (!zeros) return MIXQ_E_HIP;

@@ -89,6 +89,7 @@ bool gemm_skinny_supported(const GemmParams& p);
 hipError_t launch_gemm_skinny(const GemmParams& p, int epi, hipStream_t st); // M <= 64: GEMV-like, HBM-bound on W
 hipError_t launch_gemm_pp_ablate(const GemmParams& p, int abl, hipStream_t st);  // timing experiments only
 void set_gemm_variant(int v);
+bool w8a16_skinny_takes(int M, int N, int K); // the fpA_intB skinny form serves this shape (w8a16_gemm_kernels.hip)
 void set_wo_force(int form, int ks); // fpA_intB GEMM form (measurements): -1 automatic | 0 narrow | 2 | 4; ks: -1 automatic | n; -2 keeps
 const char* last_gemm_kernel(); // kernel family launch_gemm chose last (reporting only)
 void set_skinny_kw(int kw); // measurement knob: K-split width of the skinny kernel (0 = auto)

@@ -762,12 +762,17 @@ struct WoWidePlan {
 };
 
 static std::atomic<int> g_wo_abl{0};
+static std::atomic<int> g_wo_skinny_decode{-1}; // 2..4 tokens through the skinny form: -1 where it wins (measured), 0 never, 1 always
 static std::atomic<int> g_wo_skinny{1}; // the skinny form up to 32 tokens: 1 automatic, 0 off, 2..5 a fixed shape (measurements)
 static std::atomic<int> g_wo_twopass{-1}; // -1 automatic, 0 never, 1 whenever the shape allows it (measurements, tests)
 static std::atomic<int> g_wo_form{-1}; // measurement knob: -1 automatic, else the configuration index
 static std::atomic<int> g_wo_ks{-1};   // -1 automatic, else the K split of the wide form (where K allows)
 void set_wo_force(int form, int ks)
 {
+    if (form >= 306 && form <= 308) { // decode batches of 2..4 tokens through the skinny form: always / never / automatic
+        g_wo_skinny_decode.store(form == 306 ? 1 : form == 307 ? 0 : -1);
+        return;
+    }
     if (form >= 300 && form <= 305) { // skinny form: 300 automatic, 301 off, 302..305 a fixed shape
         g_wo_skinny.store(form == 300 ? 1 : form == 301 ? 0 : form - 300);
         return;
@@ -780,7 +785,7 @@ void set_wo_force(int form, int ks)
         g_wo_abl.store(form - 100);
         return;
     }
-    if (form == -1) g_wo_abl.store(0), g_wo_twopass.store(-1), g_wo_skinny.store(1);
+    if (form == -1) g_wo_abl.store(0), g_wo_twopass.store(-1), g_wo_skinny.store(1), g_wo_skinny_decode.store(-1);
     if (form >= -1 && form <= 4) g_wo_form.store(form);
     if (ks >= -1) g_wo_ks.store(ks);
 }
@@ -842,7 +847,13 @@ static size_t wo_wide_workspace(int M, int N, int K)
 static int wo_skinny_pick(int M, int N, int K)
 {
     const int v = g_wo_skinny.load();
-    if (v == 0 || M > 32 || M <= 4 || g_wo_form.load() >= 0 || g_wo_twopass.load() == 1) return 0; // (a forced form switches it off)
+    if (v == 0 || M > 32 || M < 2 || g_wo_form.load() >= 0 || g_wo_twopass.load() == 1) return 0; // (a forced form switches it off)
+    if (M <= 4) { // decode batches: the reference's GEMV band (decode_kernels.hip), whose cost grows ~1.4 us per token on wide
+                  // outputs (12288 x 4096: 9.4 / 10.6 / 11.9 / 13.4 us for 1..4 tokens against 8.3 / 8.6 / 9.1 here)
+        const int d = g_wo_skinny_decode.load();
+        if (d == 0) return 0;
+        if (d < 0 && !(N >= 8192 || (M >= 3 && (double)N * K >= 40e6))) return 0;
+    }
     if (v > 1) return v;
     const double mb = (double)N * K * 1e-6;
     if (N >= 16384) return M <= 24 ? 4 : 0;
@@ -867,10 +878,13 @@ static bool wo_two_pass_wanted(int M, int N, int K)
 // (the image sits BEHIND the hand-over words of the K splits, which every call must leave zero)
 static size_t wo_two_pass_bytes(int N, int K) { return kSplitkWordsBytes + (size_t)N * K * 2; }
 
+bool w8a16_skinny_takes(int M, int N, int K) { return wo_skinny_pick(M, N, K) != 0; }
+
 size_t w8a16_gemm_workspace_size(int M, int N, int K)
 {
-    if (M <= 4 || N <= 0 || K <= 0) return 0;
+    if (N <= 0 || K <= 0) return 0;
     if (wo_skinny_pick(M, N, K) != 0) return 0; // (K is split inside the workgroup)
+    if (M <= 4) return 0;
     if (wo_two_pass_wanted(M, N, K)) { // (a smaller scratch still serves the wide form's K split, or none)
         const size_t wide = wo_wide_plan(M, N, K, true).cfg != 0 ? wo_wide_workspace(M, N, K) : 0;
         return wo_two_pass_bytes(N, K) > wide ? wo_two_pass_bytes(N, K) : wide;

@@ -487,6 +487,30 @@ def test_enqueue_decode_path(oracle, M, N, K):
     assert rel_err(got, exact.astype(np.float32)) <= ref_vs_exact + 2e-4   # at least as close to exact as the reference order
 
 
+@pytest.mark.parametrize("route", [856, 857, 858])
+@pytest.mark.parametrize("M", [2, 3, 4])
+@pytest.mark.parametrize("N,K", [(384, 1024), (8200, 512)])
+def test_enqueue_decode_batches_both_routes(oracle, variant, route, M, N, K):
+    """Decode batches of 2..4 tokens: the GEMV (857), the MFMA skinny form (856: decode_kernels.hip's per-token cost made
+    it slower than the 5-token kernel on wide outputs) and the automatic choice (858; N >= 8192 takes the skinny form),
+    all against the same two oracles and bounds as test_enqueue_decode_path."""
+    A, W, act = make_layer(M, N, K, seed=N + M + route, outlier_gain=1.0)
+    p = oracle.pack_linear_weights(W, act)
+    variant(route)
+    try:
+        got = run_enqueue(A, p)
+    finally:
+        variant(858)
+    q_un = oracle.eetq_symmetric_quantize(W.T.copy())[0]
+    want = oracle.w8a16_gemv(A, q_un, p["weights_scaling_factor"])
+    assert rel_err(got, want) < REL_TOL
+    ref_order = oracle.w8a16_gemv_reforder(A, q_un, p["weights_scaling_factor"])
+    exact = A.astype(np.float64) @ (q_un.astype(np.float64) * p["weights_scaling_factor"].astype(np.float64))
+    ref_vs_exact = rel_err(ref_order, exact.astype(np.float32))
+    assert rel_err(got, ref_order) < ref_vs_exact + REL_TOL
+    assert rel_err(got, exact.astype(np.float32)) <= ref_vs_exact + 2e-4
+
+
 def test_tp_shards_compose(oracle):
     """Row-sharded W on one GPU: concatenating the shards' outputs equals the unsharded operator bit for bit."""
     from mixq_tensorrt_llm_amd import pack, parallel
