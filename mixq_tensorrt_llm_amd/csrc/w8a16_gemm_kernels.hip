@@ -847,9 +847,10 @@ static size_t wo_wide_workspace(int M, int N, int K)
 static int wo_skinny_pick(int M, int N, int K)
 {
     const int v = g_wo_skinny.load();
-    if (v == 0 || M > 32 || M < 2 || g_wo_form.load() >= 0 || g_wo_twopass.load() == 1) return 0; // (a forced form switches it off)
-    if (M <= 4) { // decode batches: the reference's GEMV band (decode_kernels.hip), whose cost grows ~1.4 us per token on wide
-                  // outputs (12288 x 4096: 9.4 / 10.6 / 11.9 / 13.4 us for 1..4 tokens against 8.3 / 8.6 / 9.1 here)
+    if (v == 0 || M > 32 || M < 1 || g_wo_form.load() >= 0 || g_wo_twopass.load() == 1) return 0; // (a forced form switches it off)
+    if (M <= 4) { // decode: the reference's GEMV band (decode_kernels.hip), whose cost grows ~1.4 us per token on wide
+                  // outputs (12288 x 4096: 9.4 / 10.6 / 11.9 / 13.4 us for 1..4 tokens against 8.1 / 8.5 / 8.6 / 9.1 here;
+                  // narrow outputs stay on the GEMV: 4096 x 4096 3.9 vs 5.6 us at one token)
         const int d = g_wo_skinny_decode.load();
         if (d == 0) return 0;
         if (d < 0 && !(N >= 8192 || (M >= 3 && (double)N * K >= 40e6))) return 0;

@@ -488,10 +488,10 @@ def test_enqueue_decode_path(oracle, M, N, K):
 
 
 @pytest.mark.parametrize("route", [856, 857, 858])
-@pytest.mark.parametrize("M", [2, 3, 4])
+@pytest.mark.parametrize("M", [1, 2, 3, 4])
 @pytest.mark.parametrize("N,K", [(384, 1024), (8200, 512)])
 def test_enqueue_decode_batches_both_routes(oracle, variant, route, M, N, K):
-    """Decode batches of 2..4 tokens: the GEMV (857), the MFMA skinny form (856: decode_kernels.hip's per-token cost made
+    """Decode, 1..4 tokens: the GEMV (857), the MFMA skinny form (856: decode_kernels.hip's per-token cost made
     it slower than the 5-token kernel on wide outputs) and the automatic choice (858; N >= 8192 takes the skinny form),
     all against the same two oracles and bounds as test_enqueue_decode_path."""
     A, W, act = make_layer(M, N, K, seed=N + M + route, outlier_gain=1.0)
