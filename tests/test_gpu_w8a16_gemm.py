@@ -249,6 +249,37 @@ def test_mixlib_twin_and_small_m_boundary(oracle):
     assert rel_err(o8[:4], o4) < REL_TOL
 
 
+@pytest.mark.parametrize("M,N,K,knobs", [(3, 8200, 512, ()), (20, 640, 1088, ()), (100, 384, 4160, ()), (300, 1032, 1600, ()),
+                                         (300, 1032, 1600, (842,))])
+def test_w8_a16_gemm_is_capturable_in_a_hip_graph(form, M, N, K, knobs):
+    """Every form is a fixed sequence of launches on the caller's stream (skinny: one; narrow / wide with a K split: one,
+    with hand-over words it re-arms itself; two-pass: two): after one warm call (function attributes, scratch) it is
+    captured into a HIP graph and replayed on new data in the same buffers, with the eager result as the yardstick."""
+    from mixq_tensorrt_llm_amd import mixlib
+    for k in knobs:
+        form(k)
+    A, q, sc = make(M, N, K, 31 * M + N)
+    dev = torch.device("cuda:0")
+    w, s = torch.from_numpy(interleave(q)).to(dev), torch.from_numpy(sc).to(dev)
+    x = torch.zeros((M, K), dtype=torch.float16, device=dev)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        out = mixlib.w8_a16_gemm(x, w, s)        # warm-up on the capture stream: scratch of (device, stream)
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            out = mixlib.w8_a16_gemm(x, w, s)
+    torch.cuda.current_stream().wait_stream(side)
+    for trial in range(3):
+        A2 = np.ascontiguousarray(np.roll(A, trial * 3, axis=0))
+        x.copy_(torch.from_numpy(A2).to(dev))
+        graph.replay()
+        torch.cuda.synchronize()
+        eager = mixlib.w8_a16_gemm(torch.from_numpy(A2).to(dev), w, s)
+        assert torch.equal(out, eager), "graph replay == eager launch"
+
+
 def test_argument_validation():
     from mixq_tensorrt_llm_amd import _lib
     lib = _lib.load()
