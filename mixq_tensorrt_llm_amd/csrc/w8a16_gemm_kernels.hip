@@ -569,7 +569,7 @@ __global__ __launch_bounds__(256 * WMH) void w8a16_gemm_wide_kernel(const uint16
         }
 }
 
-// ---- the skinny form (5 .. 32 tokens): an MFMA GEMV ------------------------------------------------------------------------
+// ---- the skinny form (1 .. 48 tokens): an MFMA GEMV ------------------------------------------------------------------------
 // Up to 32 tokens the operator is a weight stream (N K bytes) with almost no arithmetic; the narrow form spends its time on
 // launch + first-byte latency + the cross-workgroup K split it needs to fill the chip with 128-column tiles.  Built like
 // the decode GEMV and the int8 skinny kernel instead: a workgroup = 32 output columns x KW waves that split K (partials meet
@@ -847,7 +847,7 @@ static size_t wo_wide_workspace(int M, int N, int K)
 static int wo_skinny_pick(int M, int N, int K)
 {
     const int v = g_wo_skinny.load();
-    if (v == 0 || M > 32 || M < 1 || g_wo_form.load() >= 0 || g_wo_twopass.load() == 1) return 0; // (a forced form switches it off)
+    if (v == 0 || M > (v > 1 ? 64 : 48) || M < 1 || g_wo_form.load() >= 0 || g_wo_twopass.load() == 1) return 0; // (a forced form switches it off)
     if (M <= 4) { // decode: the reference's GEMV band (decode_kernels.hip), whose cost grows ~1.4 us per token on wide
                   // outputs (12288 x 4096: 9.4 / 10.6 / 11.9 / 13.4 us for 1..4 tokens against 8.1 / 8.5 / 8.6 / 9.1 here;
                   // narrow outputs stay on the GEMV: 4096 x 4096 3.9 vs 5.6 us at one token)
@@ -857,6 +857,8 @@ static int wo_skinny_pick(int M, int N, int K)
     }
     if (v > 1) return v;
     const double mb = (double)N * K * 1e-6;
+    if (M > 32) // 33..48 tokens, three token tiles: 12288 x 4096 24 -> 16-19 us, 4096 x 4096 17 -> 12-15; slower elsewhere
+        return N >= 8192 && N < 16384 ? 4 : N < 8192 && mb <= 20. ? 2 : 0;
     if (N >= 16384) return M <= 24 ? 4 : 0;
     if (N >= 8192) return M <= 12 ? 2 : 5;
     if (M <= 6 && K >= 8192) return 3;
@@ -959,12 +961,16 @@ hipError_t launch_w8a16_gemm(const void* A, const uint8_t* Wq, const void* scale
             default: return launch_wo_skinny<1, 16, 4>(a, Wq, s, o, M, N, K, st);
             }
         }
-        switch (pick) {
-        case 2: return launch_wo_skinny<2, 8, 2>(a, Wq, s, o, M, N, K, st);
-        case 3: return launch_wo_skinny<2, 16, 2>(a, Wq, s, o, M, N, K, st);
-        case 4: return launch_wo_skinny<2, 8, 4>(a, Wq, s, o, M, N, K, st);
-        default: return launch_wo_skinny<2, 16, 4>(a, Wq, s, o, M, N, K, st);
+        if (M <= 32) {
+            switch (pick) {
+            case 2: return launch_wo_skinny<2, 8, 2>(a, Wq, s, o, M, N, K, st);
+            case 3: return launch_wo_skinny<2, 16, 2>(a, Wq, s, o, M, N, K, st);
+            case 4: return launch_wo_skinny<2, 8, 4>(a, Wq, s, o, M, N, K, st);
+            default: return launch_wo_skinny<2, 16, 4>(a, Wq, s, o, M, N, K, st);
+            }
         }
+        if (M <= 48) return pick <= 3 ? launch_wo_skinny<3, 8, 2>(a, Wq, s, o, M, N, K, st) : launch_wo_skinny<3, 8, 4>(a, Wq, s, o, M, N, K, st);
+        return pick <= 3 ? launch_wo_skinny<4, 8, 2>(a, Wq, s, o, M, N, K, st) : launch_wo_skinny<4, 8, 4>(a, Wq, s, o, M, N, K, st);
     }
     const size_t need_wide = wo_wide_workspace(M, N, K); // 0: the plan with scratch is the narrow form or does not split K
     const WoWidePlan pl = wo_wide_plan(M, N, K, need_wide == 0 || (scratch != nullptr && scratch_bytes >= need_wide));

@@ -159,9 +159,10 @@ def test_two_pass_form(oracle, form, M, N, K):
 
 
 @pytest.mark.parametrize("shape", [852, 853, 854, 855])
-@pytest.mark.parametrize("M,N,K", [(5, 2, 64), (7, 130, 192), (16, 258, 320), (17, 64, 4160), (31, 1026, 1088), (32, 96, 704)])
+@pytest.mark.parametrize("M,N,K", [(5, 2, 64), (7, 130, 192), (16, 258, 320), (17, 64, 4160), (31, 1026, 1088), (32, 96, 704),
+                                   (33, 130, 320), (48, 258, 1088), (49, 64, 704), (64, 1026, 192)])
 def test_skinny_form(oracle, form, shape, M, N, K):
-    """5..32 tokens: the MFMA GEMV (32 / 64 columns per wave, 8 / 16 waves splitting K inside the workgroup) against the
+    """5..64 tokens (1 .. 4 token tiles): the MFMA GEMV (32 / 64 columns per wave, 8 / 16 waves splitting K inside the workgroup) against the
     oracle: N below / across the column group, N % 4 == 2, one and two token tiles, K of one block and of more blocks than
     waves; no scratch involved; twice the same bits (fixed summation order)."""
     A, q, sc = make(M, N, K, M + 5 * N + K + shape)
