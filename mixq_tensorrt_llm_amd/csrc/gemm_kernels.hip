@@ -536,6 +536,10 @@ void set_gemm_variant(int v)
         set_wo_force(300 + (v - 850), -2);
         return;
     }
+    if (v == 843 || v == 844) { // second pass of the two-pass form on 256- / 128-row tiles
+        set_wo_force(v == 843 ? 203 : 204, -2);
+        return;
+    }
     if (v >= 840 && v <= 842) { // fpA_intB two-pass form: 840 automatic (from 1280 tokens), 841 never, 842 whenever the shape allows
         set_wo_force(200 + (v - 840), -2);
         return;

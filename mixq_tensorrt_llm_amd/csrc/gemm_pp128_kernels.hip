@@ -172,7 +172,12 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp128_kernel(const GemmParam
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int jy = 0; jy < 2; ++jy)
-                acc[xi][jy] = __builtin_amdgcn_mfma_i32_32x32x32_i8(X[ks], Y[jy][ks], acc[xi][jy], 0, 0, 0);
+                if constexpr (EPI == EPI_F16GEMM) // fp16 operands, fp32 sums kept as bit patterns (see gemm_pp_kernels.hip)
+                    acc[xi][jy] = __builtin_bit_cast(
+                        v16i, __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, X[ks]), __builtin_bit_cast(v8h, Y[jy][ks]),
+                                                                     __builtin_bit_cast(v16f, acc[xi][jy]), 0, 0, 0));
+                else
+                    acc[xi][jy] = __builtin_amdgcn_mfma_i32_32x32x32_i8(X[ks], Y[jy][ks], acc[xi][jy], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     };
 
@@ -279,7 +284,8 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp128_kernel(const GemmParam
     const int obase = (lh ^ (lr & 15)) << 4; // 16-B slot of k-step ks = obase ^ (ks << 5)
     float sa[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) sa[j] = h2f(p.sA[min(m0 + wm * 64 + j * 32 + lr, p.M - 1)]); // (clamped rows are never stored)
+    for (int j = 0; j < 2; ++j) // (clamped rows are never stored)
+        sa[j] = EPI == EPI_F16GEMM ? 1.f : h2f(p.sA[min(m0 + wm * 64 + j * 32 + lr, p.M - 1)]);
 
     auto side = [&](int i, int j) __attribute__((always_inline)) {
         v16f P;
@@ -308,7 +314,8 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp128_kernel(const GemmParam
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-            swq[i][g] = *reinterpret_cast<const uint2*>(p.sW + min(n0 + wn * 64 + i * 32 + 4 * lh + 8 * g, p.N - 4));
+            swq[i][g] = EPI == EPI_F16GEMM ? make_uint2(0u, 0u)
+                                           : *reinterpret_cast<const uint2*>(p.sW + min(n0 + wn * 64 + i * 32 + 4 * lh + 8 * g, p.N - 4));
     constexpr bool HAS_MUL = EPI == EPI_DEQUANT_SILU_MUL;
     uint2 yq[2][4], mq[2][4];
     uint4 ypre[4], mpre[4];
@@ -366,8 +373,15 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp128_kernel(const GemmParam
                 } else {
                     c2 = v2f{h2f(yh[e2]), h2f(yh[e2 + 1])};
                 }
-                float v0 = __builtin_fmaf((float)acc[i][j][4 * g + e2], s2[0], c2[0]);
-                float v1 = __builtin_fmaf((float)acc[i][j][4 * g + e2 + 1], s2[1], c2[1]);
+                float v0, v1;
+                if constexpr (EPI == EPI_F16GEMM) { // (named ints: __builtin_bit_cast on a vector ELEMENT expression reads element 0)
+                    const int b0 = acc[i][j][4 * g + e2], b1 = acc[i][j][4 * g + e2 + 1];
+                    v0 = __builtin_bit_cast(float, b0);
+                    v1 = __builtin_bit_cast(float, b1);
+                } else {
+                    v0 = __builtin_fmaf((float)acc[i][j][4 * g + e2], s2[0], c2[0]);
+                    v1 = __builtin_fmaf((float)acc[i][j][4 * g + e2 + 1], s2[1], c2[1]);
+                }
                 if (epi_has_silu(EPI)) {
                     v0 = silu_f32(v0);
                     v1 = silu_f32(v1);
@@ -441,6 +455,16 @@ static hipError_t launch_pp128_epi(const GemmParams& p, hipStream_t st)
     if (p.O > 0) return launch_pp128_cfg<EPI, true, false>(p, st); // the API never passes both an addend and outliers
     if (p.Y != nullptr) return launch_pp128_cfg<EPI, false, true>(p, st);
     return launch_pp128_cfg<EPI, false, false>(p, st);
+}
+
+hipError_t launch_gemm_f16_pp128(const void* A, const void* B, void* D, int M, int N, int K, const void* zeros, hipStream_t st)
+{
+    if (K % 8 || N % 8) return hipErrorInvalidValue;
+    if (M <= 0 || N <= 0) return hipSuccess;
+    GemmParams p{};
+    p.A = static_cast<const int8_t*>(A), p.B = static_cast<const int8_t*>(B), p.D = D, p.zeros = zeros;
+    p.M = M, p.N = N, p.K = 2 * K; // the kernel counts K in bytes
+    return launch_pp128_cfg<EPI_F16GEMM, false, false>(p, st);
 }
 
 hipError_t launch_gemm_pp128(const GemmParams& p, int epi, hipStream_t st)

@@ -66,7 +66,8 @@ hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st);
 hipError_t launch_gemm_pp(const GemmParams& p, int epi, hipStream_t st);  // 256x256 ping-pong schedule
 hipError_t launch_gemm_pp128(const GemmParams& p, int epi, hipStream_t st);
 // D[M,N] fp16 = A[M,K] B[N,K]^T, fp16 operands (K % 8 == 0, N % 8 == 0, 16-byte aligned rows), fp32 accumulation
-hipError_t launch_gemm_f16_pp(const void* A, const void* B, void* D, int M, int N, int K, const void* zeros, hipStream_t st); // 128x256 ping-pong schedule (mid-size problems)
+hipError_t launch_gemm_f16_pp(const void* A, const void* B, void* D, int M, int N, int K, const void* zeros, hipStream_t st);
+hipError_t launch_gemm_f16_pp128(const void* A, const void* B, void* D, int M, int N, int K, const void* zeros, hipStream_t st); // 128 x 256 tiles // 128x256 ping-pong schedule (mid-size problems)
 bool gemm_pp128_wins(int M, int N, int K); // launch_gemm's rule for taking the 128x256 tiles (then no K split, no scratch)
 constexpr size_t kSplitkWordsBytes = 16384; // hand-over words (64 B per tile) of up to 256 split tiles, at the start of the scratch
 struct SplitPlan {

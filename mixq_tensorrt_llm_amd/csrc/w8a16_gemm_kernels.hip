@@ -764,6 +764,7 @@ struct WoWidePlan {
 static std::atomic<int> g_wo_abl{0};
 static std::atomic<int> g_wo_skinny_decode{-1}; // 2..4 tokens through the skinny form: -1 where it wins (measured), 0 never, 1 always
 static std::atomic<int> g_wo_skinny{1}; // the skinny form up to 32 tokens: 1 automatic, 0 off, 2..5 a fixed shape (measurements)
+static std::atomic<int> g_wo_twopass_tile{0}; // (measurements, with the form forced) row height of the second pass's tiles; 0: 256
 static std::atomic<int> g_wo_twopass{-1}; // -1 automatic, 0 never, 1 whenever the shape allows it (measurements, tests)
 static std::atomic<int> g_wo_form{-1}; // measurement knob: -1 automatic, else the configuration index
 static std::atomic<int> g_wo_ks{-1};   // -1 automatic, else the K split of the wide form (where K allows)
@@ -777,6 +778,10 @@ void set_wo_force(int form, int ks)
         g_wo_skinny.store(form == 300 ? 1 : form == 301 ? 0 : form - 300);
         return;
     }
+    if (form == 203 || form == 204) { // second pass of the two-pass form on 256- / 128-row tiles
+        g_wo_twopass_tile.store(form == 203 ? 256 : 128);
+        return;
+    }
     if (form >= 200) { // 200 automatic, 201 never, 202 always
         g_wo_twopass.store(form == 200 ? -1 : form - 201);
         return;
@@ -785,7 +790,7 @@ void set_wo_force(int form, int ks)
         g_wo_abl.store(form - 100);
         return;
     }
-    if (form == -1) g_wo_abl.store(0), g_wo_twopass.store(-1), g_wo_skinny.store(1), g_wo_skinny_decode.store(-1);
+    if (form == -1) g_wo_abl.store(0), g_wo_twopass.store(-1), g_wo_twopass_tile.store(0), g_wo_skinny.store(1), g_wo_skinny_decode.store(-1);
     if (form >= -1 && form <= 4) g_wo_form.store(form);
     if (ks >= -1) g_wo_ks.store(ks);
 }
@@ -872,12 +877,20 @@ static int wo_skinny_pick(int M, int N, int K)
 // Measured crossover (profiles/r02_w8a16_gemm.txt): the second pass runs 256 x 256 tiles only, so it needs about a full
 // wave of them (>= 200) besides enough rows to amortise the dequantisation pass.
 constexpr int kTwoPassMinM = 1280;
-static bool wo_two_pass_wanted(int M, int N, int K)
+// Row height of the second pass's tiles, or 0: not the two-pass form.  128-row tiles (gemm_w8a8o16_pp128_kernel) where
+// they fill one wave of the chip (160..256 tiles) at K <= 12288: 4096 x 4096 at 1536 / 2048 tokens 70 -> 66 / 81 -> 78 us,
+// 5120 x 5120 at 1024: 82 -> 75, 12288 x 4096 at 512: 85 -> 81 (-4..-9 %).
+static int wo_two_pass_tile(int M, int N, int K)
 {
     const int f = g_wo_twopass.load();
-    if (f == 0 || M <= 4 || N % 8 || K % 64) return false;
-    return f == 1 || (M >= kTwoPassMinM && (int64_t)((M + 255) / 256) * ((N + 255) / 256) >= 200);
+    if (f == 0 || M <= 4 || N % 8 || K % 64) return 0;
+    const int forced_tile = g_wo_twopass_tile.load();
+    if (f == 1) return forced_tile ? forced_tile : 256;
+    const int64_t tn = (N + 255) / 256, t128 = (int64_t)((M + 127) / 128) * tn, t256 = (int64_t)((M + 255) / 256) * tn;
+    if (M >= 512 && K <= 12288 && t128 >= 160 && t128 <= 256) return 128;
+    return M >= kTwoPassMinM && t256 >= 200 ? 256 : 0;
 }
+static bool wo_two_pass_wanted(int M, int N, int K) { return wo_two_pass_tile(M, N, K) != 0; }
 // (the image sits BEHIND the hand-over words of the K splits, which every call must leave zero)
 static size_t wo_two_pass_bytes(int N, int K) { return kSplitkWordsBytes + (size_t)N * K * 2; }
 
@@ -950,6 +963,7 @@ hipError_t launch_w8a16_gemm(const void* A, const uint8_t* Wq, const void* scale
         uint16_t* const wf = reinterpret_cast<uint16_t*>(static_cast<char*>(scratch) + kSplitkWordsBytes);
         hipLaunchKernelGGL(w8a16_dequant_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, Wq, s, wf, N, K);
         if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+        if (wo_two_pass_tile(M, N, K) == 128) return launch_gemm_f16_pp128(A, wf, Out, M, N, K, zeros, st);
         return launch_gemm_f16_pp(A, wf, Out, M, N, K, zeros, st);
     }
     if (const int pick = wo_skinny_pick(M, N, K); pick != 0) {

@@ -102,6 +102,7 @@ def form():
     from mixq_tensorrt_llm_amd import _lib
     lib = _lib.load()
     yield lib.mixq_debug_set_gemm_variant
+    lib.mixq_debug_set_gemm_variant(843)
     lib.mixq_debug_set_gemm_variant(80)   # (also: two-pass form automatic again)
     lib.mixq_debug_set_gemm_variant(85)
 
@@ -142,7 +143,8 @@ def test_every_configuration_of_the_wide_form(oracle, form, cfg, ks, M, N, K):
 
 @pytest.mark.parametrize("M,N,K", [(5, 8, 64), (33, 264, 320), (300, 1032, 1600), (700, 136, 448), (1300, 2304, 1088),
                                    (2048, 512, 4096)])
-def test_two_pass_form(oracle, form, M, N, K):
+@pytest.mark.parametrize("tile", [843, 844])
+def test_two_pass_form(oracle, form, tile, M, N, K):
     """Dequantise-once + fp16 ping-pong GEMM (automatic from 1280 tokens; forced here on every size): the weights it
     multiplies are the fused forms' fp16((q - 128) * scale), so the same tolerance holds; ragged M / N tiles, N % 256,
     K of 1 .. 64 slices; a second call on the same scratch gives the same bits and leaves the hand-over words zero."""
@@ -150,6 +152,7 @@ def test_two_pass_form(oracle, form, M, N, K):
     qi = interleave(q)
     want = oracle.w8a16_gemv(A, q, sc)
     form(842)
+    form(tile)   # second pass on 256- / 128-row tiles
     got, nws = run(A, qi, sc, N, scratch=True)
     assert nws >= 16384 + 2 * N * K
     assert np.isfinite(got).all() and rel_err(got, want) < REL_TOL
