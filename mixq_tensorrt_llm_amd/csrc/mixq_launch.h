@@ -96,7 +96,12 @@ bool w8a16_skinny_takes(int M, int N, int K); // the fpA_intB skinny form serves
 //   256-row form | 200 / 201 / 202 two-pass form automatic / never / always, 203 / 204 its second pass on 256- / 128-row tiles
 //   | 300 / 301 skinny form automatic / off, 302..305 one of its shapes | 306 / 307 / 308 1..4 tokens through the skinny form
 //   always / never / automatic;  `ks`: -2 keep, -1 automatic, n = workgroups per tile along K.
-void set_wo_force(int form, int ks); // fpA_intB GEMM form (measurements): -1 automatic | 0 narrow | 2 | 4; ks: -1 automatic | n; -2 keeps
+// fpA_intB measurement / test knobs (mixq_debug_set_gemm_variant 80..89, 831..834, 840..844, 850..858, 800 + ABL); `form`:
+//   -1 everything automatic | 0 narrow form | 1..4 wide form with 32 / 64 / 128 / 256-row tiles | 100 + ABL ablation of the
+//   256-row form | 200 / 201 / 202 two-pass form automatic / never / always, 203 / 204 its second pass on 256- / 128-row tiles
+//   | 300 / 301 skinny form automatic / off, 302..305 one of its shapes | 306 / 307 / 308 1..4 tokens through the skinny form
+//   always / never / automatic;  `ks`: -2 keep, -1 automatic, n = workgroups per tile along K.
+void set_wo_force(int form, int ks);
 const char* last_gemm_kernel(); // kernel family launch_gemm chose last (reporting only)
 void set_skinny_kw(int kw); // measurement knob: K-split width of the skinny kernel (0 = auto)
 hipError_t launch_gemm_fp16(const void* fpA, const void* fpW, void* Out, int M, int N, int O, hipStream_t st);
