@@ -527,23 +527,52 @@ __global__ __launch_bounds__(256 * WMH) void w8a16_gemm_wide_kernel(const uint16
         if (arrived_s != (unsigned)(ks - 1)) return;
         if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // re-armed
         // rank order, whichever workgroup is last; the own part is read back like the others (it was parked above with
-        // write-through stores): no second register copy of the tile, and all loads of a rank are in flight together
+        // write-through stores): no second register copy of the tile.
+        constexpr int NE = 2 * MTW * 16; // floats per lane
+        if constexpr (NE <= 64) {
+            // short tiles (32 / 64 rows, split up to 16 ways): the NEXT rank's loads are in flight while this rank's are
+            // added -- a rank at a time costs one memory round trip per rank (~1.3 us x ks on a 25-us launch)
+            float* const accf = reinterpret_cast<float*>(&acc[0][0]); // element q <-> parked word q * T, q = (cb * MTW + t) * 16 + e
+            float cur[NE], nxt[NE], sum[NE];
+            auto fetch = [&](float (&dst)[NE], int r) __attribute__((always_inline)) {
+                const float* const theirs = slots + (size_t)r * TILE + tid;
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+                for (int q = 0; q < NE; ++q)
+                    dst[q] = __hip_atomic_load(theirs + q * T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            };
 #pragma unroll
-            for (int t = 0; t < MTW; ++t)
+            for (int q = 0; q < NE; ++q) sum[q] = 0.f;
+            fetch(cur, 0);
+            for (int r = 0; r < ks; r += 2) {
+                if (r + 1 < ks) fetch(nxt, r + 1);
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[cb][t][e] = 0.f;
-        for (int r = 0; r < ks; ++r) {
-            const float* const theirs = slots + (size_t)r * TILE + tid;
+                for (int q = 0; q < NE; ++q) sum[q] += cur[q];
+                if (r + 2 < ks) fetch(cur, r + 2);
+                if (r + 1 < ks) {
+#pragma unroll
+                    for (int q = 0; q < NE; ++q) sum[q] += nxt[q];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NE; ++q) accf[q] = sum[q];
+        } else {
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
                 for (int t = 0; t < MTW; ++t)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e)
-                        acc[cb][t][e] += __hip_atomic_load(theirs + ((cb * MTW + t) * 16 + e) * T, __ATOMIC_RELAXED,
-                                                           __HIP_MEMORY_SCOPE_AGENT);
+                    for (int e = 0; e < 16; ++e) acc[cb][t][e] = 0.f;
+            for (int r = 0; r < ks; ++r) { // (tall tiles: all loads of a rank in flight together; the registers hold no more)
+                const float* const theirs = slots + (size_t)r * TILE + tid;
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int t = 0; t < MTW; ++t)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e)
+                            acc[cb][t][e] += __hip_atomic_load(theirs + ((cb * MTW + t) * 16 + e) * T, __ATOMIC_RELAXED,
+                                                               __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 
