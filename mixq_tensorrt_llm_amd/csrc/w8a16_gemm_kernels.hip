@@ -279,15 +279,20 @@ constexpr int WSTAGE = BNW * KBW; // weight bytes per stage
 } // namespace wo
 
 // ABL (measurement only, wrong results): 1 no copies in the loop, 2 no dequantisation, 4 token fragments read once, 8 no MFMAs
+// WMH = 3 ("K halves"): 8 waves like WMH = 2, but the second four take the SECOND k step of every stage for the same rows
+// instead of other rows; the two partial tiles meet in LDS after the loop.  For short tiles: two waves per SIMD (one's
+// dequantisation and LDS waits under the other's MFMAs) where a 4-wave workgroup leaves each SIMD a single wave.
 template <int MTW, int WMH, int NST, int ABL = 0>
-__global__ __launch_bounds__(256 * WMH) void w8a16_gemm_wide_kernel(const uint16_t* __restrict__ A, const uint8_t* __restrict__ Wq,
+__global__ __launch_bounds__(256 * (WMH == 3 ? 2 : WMH)) void w8a16_gemm_wide_kernel(const uint16_t* __restrict__ A, const uint8_t* __restrict__ Wq,
                                                                const uint16_t* __restrict__ scale,
                                                                uint16_t* __restrict__ Out, int M, int N, int K, int ks,
                                                                void* __restrict__ scratch)
 {
     using namespace wo;
-    constexpr int T = 256 * WMH;                  // WMH = 1: 4 waves (one per SIMD, each all rows), 2: 8 waves (two row halves)
-    constexpr int ROWS = WMH * MTW * 32;          // token rows of the workgroup tile
+    constexpr bool KH = WMH == 3;
+    constexpr int T = 256 * (KH ? 2 : WMH);       // WMH = 1: 4 waves (one per SIMD, each all rows), 2: 8 waves (two row halves)
+    constexpr int ROWS = (KH ? 1 : WMH) * MTW * 32; // token rows of the workgroup tile
+    constexpr int TA = KH ? 256 : T;              // threads that hold finished accumulators (K halves: waves 0-3 after the merge)
     constexpr int ASTAGE = ROWS * ROWBW;          // token bytes of one stage
     constexpr int STAGE = ASTAGE + WSTAGE;        // [tokens | raw weights]
     constexpr int AL = ROWS * 8 / T;              // token copies (16 B) per thread per stage
@@ -319,7 +324,7 @@ __global__ __launch_bounds__(256 * WMH) void w8a16_gemm_wide_kernel(const uint16
     }
     const int m0 = tile_m * ROWS;
     const int n0w = tile_n * BNW + wn * 64;       // first column of this wave
-    const int trow0 = wmh * MTW * 32;             // first token row of this wave inside the tile
+    const int trow0 = KH ? 0 : wmh * MTW * 32;    // first token row of this wave inside the tile
 
     const int nst_all = K / KBW;
     const int s_begin = (int)((int64_t)nst_all * krank / ks), s_end = (int)((int64_t)nst_all * (krank + 1) / ks);
@@ -371,6 +376,12 @@ __global__ __launch_bounds__(256 * WMH) void w8a16_gemm_wide_kernel(const uint16
             const int pl = wn * 32 + cb * 16 + (lr >> 1), g = (lr & 1) * 4 + 2 * j + lh;
             woff[cb][j] = ASTAGE + ((pl * 8 + (g ^ ((pl >> 1) & 3))) << 4);
         }
+    }
+    if (KH && wmh == 1) { // this wave's k step is the second of every stage: its offsets take the place of step 0's
+#pragma unroll
+        for (int o = 0; o < 2; ++o) aoff[0][o] = aoff[1][o];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) woff[cb][0] = woff[cb][1];
     }
     v2h scale2[2];
 #pragma unroll
@@ -483,6 +494,7 @@ __global__ __launch_bounds__(256 * WMH) void w8a16_gemm_wide_kernel(const uint16
             uint4 wr[2];
             {
                 // stage i certified at its top; step 0's weights are dequantised in the open, step 1's under step 0's MFMAs
+                // (K halves: each wave runs ONE step per stage, its own)
                 certify(i);
                 if (i + NST - 1 < nst) issue(i + NST - 1, (u + NST - 1) % NST);
                 uint4 w0[2];
@@ -496,30 +508,60 @@ __global__ __launch_bounds__(256 * WMH) void w8a16_gemm_wide_kernel(const uint16
 #pragma unroll
                     for (int h = 0; h < 2; ++h) dequant_half(w0[cb], h, scale2[cb], E[0][cb], O[0][cb]);
                 __builtin_amdgcn_sched_barrier(0);
-                step(base, std::integral_constant<int, 0>{}, wr, std::true_type{});
-                __builtin_amdgcn_sched_barrier(0);
-                step(base, std::integral_constant<int, 1>{}, wr, std::false_type{});
+                if constexpr (KH) {
+                    step(base, std::integral_constant<int, 0>{}, wr, std::false_type{});
+                } else {
+                    step(base, std::integral_constant<int, 0>{}, wr, std::true_type{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    step(base, std::integral_constant<int, 1>{}, wr, std::false_type{});
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
 
+    // ---- K halves: waves 4-7 hand their partial tile to waves 0-3 through LDS (the stage buffers are dead) ---------------
+    if constexpr (KH) {
+        __syncthreads();
+        float* const xch = reinterpret_cast<float*>(smem) + (tid & 255);
+        if (wmh == 1) {
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int t = 0; t < MTW; ++t)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) xch[((cb * MTW + t) * 16 + e) * 256] = acc[cb][t][e];
+        }
+        __syncthreads();
+        if (wmh == 0) {
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int t = 0; t < MTW; ++t)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[cb][t][e] += xch[((cb * MTW + t) * 16 + e) * 256];
+        }
+    }
+    const bool holder = !KH || wmh == 0; // this wave holds finished accumulators (the others only keep the barrier count)
+
     // ---- K split over workgroups: park, count in, the last one to arrive adds the parts in rank order -----------------
     if (ks > 1) {
         __shared__ unsigned arrived_s;
-        constexpr int TILE = 2 * MTW * 16 * T; // floats of one parked tile: [column block][row tile][16][thread]
+        constexpr int TILE = 2 * MTW * 16 * TA; // floats of one parked tile: [column block][row tile][16][thread]
         unsigned* const counter = static_cast<unsigned*>(scratch) + (tile_m * tiles_n + tile_n);
         float* const slots = reinterpret_cast<float*>(static_cast<char*>(scratch) + kSplitkWordsBytes) +
                              (size_t)(tile_m * tiles_n + tile_n) * ks * TILE;
         float* const mine = slots + (size_t)krank * TILE + tid;
+        if (holder) {
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+            for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-            for (int t = 0; t < MTW; ++t)
+                for (int t = 0; t < MTW; ++t)
 #pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    __hip_atomic_store(mine + ((cb * MTW + t) * 16 + e) * T, acc[cb][t][e], __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
+                    for (int e = 0; e < 16; ++e)
+                        __hip_atomic_store(mine + ((cb * MTW + t) * 16 + e) * TA, acc[cb][t][e], __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every write-through acknowledged
         __syncthreads();
         if (tid == 0) arrived_s = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -529,16 +571,18 @@ __global__ __launch_bounds__(256 * WMH) void w8a16_gemm_wide_kernel(const uint16
         // rank order, whichever workgroup is last; the own part is read back like the others (it was parked above with
         // write-through stores): no second register copy of the tile.
         constexpr int NE = 2 * MTW * 16; // floats per lane
-        if constexpr (NE <= 64) {
+        if (!holder) {
+            // (K halves: waves 4-7 have nothing left to do)
+        } else if constexpr (NE <= 64) {
             // short tiles (32 / 64 rows, split up to 16 ways): the NEXT rank's loads are in flight while this rank's are
             // added -- a rank at a time costs one memory round trip per rank (~1.3 us x ks on a 25-us launch)
-            float* const accf = reinterpret_cast<float*>(&acc[0][0]); // element q <-> parked word q * T, q = (cb * MTW + t) * 16 + e
+            float* const accf = reinterpret_cast<float*>(&acc[0][0]); // element q <-> parked word q * TA, q = (cb * MTW + t) * 16 + e
             float cur[NE], nxt[NE], sum[NE];
             auto fetch = [&](float (&dst)[NE], int r) __attribute__((always_inline)) {
                 const float* const theirs = slots + (size_t)r * TILE + tid;
 #pragma unroll
                 for (int q = 0; q < NE; ++q)
-                    dst[q] = __hip_atomic_load(theirs + q * T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    dst[q] = __hip_atomic_load(theirs + q * TA, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             };
 #pragma unroll
             for (int q = 0; q < NE; ++q) sum[q] = 0.f;
@@ -570,7 +614,7 @@ __global__ __launch_bounds__(256 * WMH) void w8a16_gemm_wide_kernel(const uint16
                     for (int t = 0; t < MTW; ++t)
 #pragma unroll
                         for (int e = 0; e < 16; ++e)
-                            acc[cb][t][e] += __hip_atomic_load(theirs + ((cb * MTW + t) * 16 + e) * T, __ATOMIC_RELAXED,
+                            acc[cb][t][e] += __hip_atomic_load(theirs + ((cb * MTW + t) * 16 + e) * TA, __ATOMIC_RELAXED,
                                                                __HIP_MEMORY_SCOPE_AGENT);
             }
         }
@@ -582,7 +626,7 @@ __global__ __launch_bounds__(256 * WMH) void w8a16_gemm_wide_kernel(const uint16
 #pragma unroll
         for (int t = 0; t < MTW; ++t) {
             const int m = m0 + trow0 + t * 32 + lr;
-            if (m >= M) continue;
+            if (m >= M || !holder) continue;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int n = n0w + cb * 32 + 8 * g + 4 * lh;
@@ -776,12 +820,13 @@ static size_t wo_narrow_workspace(int rows, int N, int K)
 struct WoCfg {
     int rows, mtw, wmh;
 };
-static constexpr WoCfg kWoCfg[5] = {
+static constexpr WoCfg kWoCfg[6] = {
     {0, 0, 0},    // 0: the narrow form above, in passes of 256 tokens
     {32, 1, 1},   // 1: 4 waves x (32 rows x 64 columns)
     {64, 2, 1},   // 2: 4 waves x (64 x 64)
     {128, 2, 2},  // 3: 8 waves x (64 x 64)
     {256, 4, 2},  // 4: 8 waves x (128 x 64)
+    {64, 2, 3},   // 5: 8 waves x (64 x 64), the second four on the second k step of every stage ("K halves")
 };
 // (Measured and dropped: 4 "fat" waves x (128 x 64) and 4 x (256 x 64), one wave per SIMD, every weight dequantised once
 // per workgroup instead of once per row half -- equal to / 5-8 % slower than the 8-wave forms of the same height.)
@@ -820,7 +865,7 @@ void set_wo_force(int form, int ks)
         return;
     }
     if (form == -1) g_wo_abl.store(0), g_wo_twopass.store(-1), g_wo_twopass_tile.store(0), g_wo_skinny.store(1), g_wo_skinny_decode.store(-1);
-    if (form >= -1 && form <= 4) g_wo_form.store(form);
+    if (form >= -1 && form <= 5) g_wo_form.store(form);
     if (ks >= -1) g_wo_ks.store(ks);
 }
 
@@ -837,11 +882,11 @@ static WoWidePlan wo_wide_plan(int M, int N, int K, bool have_scratch)
     const int form = g_wo_form.load(), fks = g_wo_ks.load();
     if (form == 0 || (form < 0 && (M <= 32 || (M <= 256 && !have_scratch)))) return {0, 1};
     const int cus = num_cus(), tn = (N + wo::BNW - 1) / wo::BNW, nst = K / wo::KBW;
-    static constexpr float kStage[5] = {0.f, 0.61f, 0.75f, 1.25f, 2.1f};
-    static constexpr float kHand0[5] = {0.f, 2.f, 3.f, 6.f, 12.f}, kHand1[5] = {0.f, 0.8f, 1.3f, 2.5f, 4.3f};
+    static constexpr float kStage[6] = {0.f, 0.61f, 0.75f, 1.25f, 2.1f, 0.75f};
+    static constexpr float kHand0[6] = {0.f, 2.f, 3.f, 6.f, 12.f, 3.f}, kHand1[6] = {0.f, 0.8f, 1.3f, 2.5f, 4.3f, 1.3f};
     WoWidePlan best{3, 1};
     float best_t = 1e30f;
-    for (int cfg = 1; cfg <= 4; ++cfg) {
+    for (int cfg = 1; cfg <= (form == 5 ? 5 : 4); ++cfg) {
         if (form > 0 && cfg != form) continue;
         const int rows = kWoCfg[cfg].rows, tiles = ((M + rows - 1) / rows) * tn;
         if (form < 0 && rows >= 2 * M && cfg > 1) break; // (a tile twice as tall as the problem)
@@ -862,6 +907,10 @@ static WoWidePlan wo_wide_plan(int M, int N, int K, bool have_scratch)
             if (t < best_t) best_t = t, best = WoWidePlan{cfg, ks};
         }
     }
+    // 64-row tiles that are split at most 2 ways run their 8-wave form (the second four waves on the second k step of every
+    // stage): -8 % at 192 / 256 tokens on 12288 x 4096, -4..-7 % on 28672 x 8192, level elsewhere; with deeper splits the
+    // 4-wave form stays (4096 x 4096 at 64 tokens: 20.2 vs 20.7 us).
+    if (form < 0 && best.cfg == 2 && best.ks <= 2) best.cfg = 5;
     return best;
 }
 
@@ -969,14 +1018,15 @@ template <int MTW, int WMH, int NST, int ABL = 0>
 static hipError_t launch_wo_wide(const uint16_t* A, const uint8_t* Wq, const uint16_t* scale, uint16_t* Out, int M, int N,
                                  int K, int ks, void* scratch, hipStream_t st)
 {
-    constexpr int rows = 32 * MTW * WMH;
+    constexpr int rows = 32 * MTW * (WMH == 3 ? 1 : WMH);
     constexpr size_t lds = (size_t)NST * (rows * wo::ROWBW + wo::WSTAGE);
     static_assert(lds <= 160 * 1024 - 64, "LDS budget");
     auto kern = w8a16_gemm_wide_kernel<MTW, WMH, NST, ABL>;
     static DeviceOnce once;
     if (hipError_t e = ensure_dynamic_lds(kern, lds, once); e != hipSuccess) return e;
     const int tiles = ((M + rows - 1) / rows) * ((N + wo::BNW - 1) / wo::BNW);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * ks)), dim3(256 * WMH), lds, st, A, Wq, scale, Out, M, N, K, ks, scratch);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * ks)), dim3(256 * (WMH == 3 ? 2 : WMH)), lds, st, A, Wq, scale, Out, M, N, K, ks,
+                       scratch);
     return hipGetLastError();
 }
 
@@ -1033,6 +1083,7 @@ hipError_t launch_w8a16_gemm(const void* A, const uint8_t* Wq, const void* scale
         case 1: return launch_wo_wide<1, 1, 6>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
         case 2: return launch_wo_wide<2, 1, 6>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
         case 3: return launch_wo_wide<2, 2, 4>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
+        case 5: return launch_wo_wide<2, 3, 6>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
         default: return launch_wo_wide<4, 2, 3>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
         }
     }

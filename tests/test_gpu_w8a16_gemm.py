@@ -125,12 +125,13 @@ def test_large_m_forms(oracle, form, which, ks, M, N, K):
     assert np.isfinite(got2).all() and rel_err(got2, want) < REL_TOL
 
 
-@pytest.mark.parametrize("cfg", [831, 832, 833, 834])
+@pytest.mark.parametrize("cfg", [831, 832, 833, 834, 835])
 @pytest.mark.parametrize("ks", [85, 86, 88])
 @pytest.mark.parametrize("M,N,K", [(5, 130, 192), (33, 258, 320), (64, 128, 4160), (129, 640, 1088), (257, 256, 2048),
                                    (300, 1026, 1600)])
 def test_every_configuration_of_the_wide_form(oracle, form, cfg, ks, M, N, K):
-    """The four workgroup shapes of the wide form (32 / 64 rows: 4 waves, 128 / 256 rows: 8 waves), each on shapes smaller and
+    """The workgroup shapes of the wide form (32 / 64 rows: 4 waves, 128 / 256 rows: 8 waves, 835 = 64 rows with 8 waves on
+    alternate k steps), each on shapes smaller and
     larger than its tile, with K unsplit / split automatically / split 4 ways."""
     A, q, sc = make(M, N, K, M + 3 * N + K + cfg)
     qi = interleave(q)
@@ -182,7 +183,7 @@ def test_randomised_soak_over_forms_and_shapes(oracle, form):
     """120 random (M, N, K) x a random form (narrow / one of the four wide tile heights / two-pass / automatic) x a random
     K split, against the oracle: ragged everything, N % 4 == 2 included, K from one 64-k stage up."""
     rng = np.random.default_rng(2024)
-    knobs_form = [80, 81, 831, 832, 833, 834, 842, 851, 853, 855]
+    knobs_form = [80, 81, 831, 832, 833, 834, 835, 842, 851, 853, 855]
     knobs_ks = [85, 86, 87, 88, 89]
     for it in range(120):
         M = int(rng.integers(5, 420)) if it % 4 else int(rng.integers(5, 40))
