@@ -955,17 +955,16 @@ static int wo_skinny_pick(int M, int N, int K)
 // Measured crossover (profiles/r02_w8a16_gemm.txt): the second pass runs 256 x 256 tiles only, so it needs about a full
 // wave of them (>= 200) besides enough rows to amortise the dequantisation pass.
 constexpr int kTwoPassMinM = 1280;
-// Row height of the second pass's tiles, or 0: not the two-pass form.  128-row tiles (gemm_w8a8o16_pp128_kernel) where
-// they fill one wave of the chip (160..256 tiles) at K <= 12288: 4096 x 4096 at 1536 / 2048 tokens 70 -> 66 / 81 -> 78 us,
-// 5120 x 5120 at 1024: 82 -> 75, 12288 x 4096 at 512: 85 -> 81 (-4..-9 %).
+// Row height of the second pass's tiles, or 0: not the two-pass form.  (128-row tiles -- gemm_w8a8o16_pp128_kernel -- are
+// wired for measurements only: where they fill one wave of the chip they measured -8 % once (5120 x 5120 at 1024 tokens),
+// +-2 % elsewhere and +9 % on 12288 x 4096 at 512 tokens, inside the run-to-run spread of back-to-back timings.)
 static int wo_two_pass_tile(int M, int N, int K)
 {
     const int f = g_wo_twopass.load();
     if (f == 0 || M <= 4 || N % 8 || K % 64) return 0;
     const int forced_tile = g_wo_twopass_tile.load();
     if (f == 1) return forced_tile ? forced_tile : 256;
-    const int64_t tn = (N + 255) / 256, t128 = (int64_t)((M + 127) / 128) * tn, t256 = (int64_t)((M + 255) / 256) * tn;
-    if (M >= 512 && K <= 12288 && t128 >= 160 && t128 <= 256) return 128;
+    const int64_t t256 = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
     return M >= kTwoPassMinM && t256 >= 200 ? 256 : 0;
 }
 static bool wo_two_pass_wanted(int M, int N, int K) { return wo_two_pass_tile(M, N, K) != 0; }
