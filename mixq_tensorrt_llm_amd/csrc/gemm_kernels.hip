@@ -528,6 +528,10 @@ void set_gemm_variant(int v)
         g_variant.store(0);
         return;
     }
+    if (v == 859 || v == 8590) { // fpA_intB skinny form, 16 columns per wave x 8 / 16 waves (measurements, up to 16 tokens)
+        set_wo_force(v == 859 ? 309 : 310, -2);
+        return;
+    }
     if (v >= 856 && v <= 858) { // decode batches (2..4 tokens) through the fpA_intB skinny form: 856 always, 857 never, 858 automatic
         set_wo_force(306 + (v - 856), -2);
         return;

@@ -690,7 +690,7 @@ __global__ __launch_bounds__(KW * 64) void w8a16_skinny_kernel(const uint16_t* _
 #pragma unroll
         for (int t = 0; t < MT; ++t) acc[cg][t] = v4f_{0.f, 0.f, 0.f, 0.f};
 
-    constexpr int UB = CG == 2 ? 4 : 2; // blocks per batch: 8 weight loads + 2 UB MT token loads in flight per lane
+    constexpr int UB = CG == 1 ? 8 : CG == 2 ? 4 : 2; // blocks per batch: 8 weight loads + 2 UB MT token loads in flight per lane
     for (int b0 = b_begin; b0 < b_end; b0 += UB) {
         uint4 wv[UB][CG];
         uint4 av[UB][MT][2];
@@ -844,11 +844,15 @@ static std::atomic<int> g_wo_form{-1}; // measurement knob: -1 automatic, else t
 static std::atomic<int> g_wo_ks{-1};   // -1 automatic, else the K split of the wide form (where K allows)
 void set_wo_force(int form, int ks)
 {
+    if (form == 309 || form == 310) { // (measurements, up to 16 tokens) 16 columns per wave x 8 / 16 waves
+        g_wo_skinny.store(form == 309 ? 6 : 7);
+        return;
+    }
     if (form >= 306 && form <= 308) { // decode batches of 2..4 tokens through the skinny form: always / never / automatic
         g_wo_skinny_decode.store(form == 306 ? 1 : form == 307 ? 0 : -1);
         return;
     }
-    if (form >= 300 && form <= 305) { // skinny form: 300 automatic, 301 off, 302..305 a fixed shape
+    if (form >= 300 && form <= 305) { // skinny form: 300 automatic, 301 off, 302..305 a fixed shape (32x8, 32x16, 64x8, 64x16)
         g_wo_skinny.store(form == 300 ? 1 : form == 301 ? 0 : form - 300);
         return;
     }
@@ -931,12 +935,14 @@ static int wo_skinny_pick(int M, int N, int K)
 {
     const int v = g_wo_skinny.load();
     if (v == 0 || M > (v > 1 ? 64 : 48) || M < 1 || g_wo_form.load() >= 0 || g_wo_twopass.load() == 1) return 0; // (a forced form switches it off)
+    const bool cols16 = N >= 2048 && (N + 15) / 16 <= 288; // 16 columns per wave give one workgroup per CU or a little less
     if (M <= 4) { // decode: the reference's GEMV band (decode_kernels.hip), whose cost grows ~1.4 us per token on wide
-                  // outputs (12288 x 4096: 9.4 / 10.6 / 11.9 / 13.4 us for 1..4 tokens against 8.1 / 8.5 / 8.6 / 9.1 here;
-                  // narrow outputs stay on the GEMV: 4096 x 4096 3.9 vs 5.6 us at one token)
+                  // outputs (12288 x 4096: 9.4 / 10.7 / 12.0 / 13.3 us for 1..4 tokens against 8.2 / 8.4 / 8.6 / 9.1 here) and
+                  // on long K (4096 x 11008: 8.6 / 9.9 / - / 13.3 against 8.1 / 8.3 / - / 9.0 with 16 columns x 16 waves);
+                  // short narrow shapes stay on the GEMV for one or two tokens (4096 x 4096: 4.0 / 4.6 vs 4.1 / 4.4)
         const int d = g_wo_skinny_decode.load();
         if (d == 0) return 0;
-        if (d < 0 && !(N >= 8192 || (M >= 3 && (double)N * K >= 40e6))) return 0;
+        if (d < 0 && !(N >= 8192 || (cols16 && (K >= 8192 || M >= 3)) || (!cols16 && N >= 4608 && M >= 2))) return 0;
     }
     if (v > 1) return v;
     const double mb = (double)N * K * 1e-6;
@@ -944,6 +950,7 @@ static int wo_skinny_pick(int M, int N, int K)
         return N >= 8192 && N < 16384 ? 4 : N < 8192 && mb <= 20. ? 2 : 0;
     if (N >= 16384) return M <= 24 ? 4 : 0;
     if (N >= 8192) return M <= 12 ? 2 : 5;
+    if (M <= 16 && (N + 15) / 16 <= 288) return 7; // 16 columns x 16 waves (1280 x 8192 at 8 tokens: 9.7 -> 8.0 us too): 4096 x 4096 6.3 -> 5.5 us at 8 tokens, 4096 x 11008 13.0 -> 10.6
     if (M <= 6 && K >= 8192) return 3;
     if (M <= 16) return 2;
     if (M <= 24) return mb <= 50. ? 2 : 0;
@@ -1050,6 +1057,8 @@ hipError_t launch_w8a16_gemm(const void* A, const uint8_t* Wq, const void* scale
             case 2: return launch_wo_skinny<1, 8, 2>(a, Wq, s, o, M, N, K, st);
             case 3: return launch_wo_skinny<1, 16, 2>(a, Wq, s, o, M, N, K, st);
             case 4: return launch_wo_skinny<1, 8, 4>(a, Wq, s, o, M, N, K, st);
+            case 6: return launch_wo_skinny<1, 8, 1>(a, Wq, s, o, M, N, K, st);
+            case 7: return launch_wo_skinny<1, 16, 1>(a, Wq, s, o, M, N, K, st);
             default: return launch_wo_skinny<1, 16, 4>(a, Wq, s, o, M, N, K, st);
             }
         }

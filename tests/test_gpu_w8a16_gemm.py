@@ -162,7 +162,7 @@ def test_two_pass_form(oracle, form, tile, M, N, K):
     assert rel_err(got, ref) < REL_TOL
 
 
-@pytest.mark.parametrize("shape", [852, 853, 854, 855])
+@pytest.mark.parametrize("shape", [852, 853, 854, 855, 859, 8590])
 @pytest.mark.parametrize("M,N,K", [(5, 2, 64), (7, 130, 192), (16, 258, 320), (17, 64, 4160), (31, 1026, 1088), (32, 96, 704),
                                    (33, 130, 320), (48, 258, 1088), (49, 64, 704), (64, 1026, 192)])
 def test_skinny_form(oracle, form, shape, M, N, K):
