@@ -86,12 +86,16 @@ def synth_activation(M, K, ind, dev, gen):
 
 def small_m_points(lib, TensorDesc, dev, gen, st_ptr, iters=300):
     """Informational (never part of `value`): the HBM-bound end of the same operator, SURVEY §8d -- BASELINE config 0
-    (one 4096 x 4096 MixQ linear, bs = 32) and a decode step (bs = 1, W8A16 GEMV on `qweight`) through mixq_enqueue,
-    as weight bytes / time against the HBM peak."""
+    (one 4096 x 4096 MixQ linear, bs = 32) and decode steps (bs = 1 / 4: the W8A16 path on `qweight`, GEMV or MFMA skinny
+    form) through mixq_enqueue, as weight bytes / time against the HBM peak."""
     out = {}
-    N = K = 4096
-    t = synth_layer(N, K, dev, gen)
-    for name, M in (("config0_bs32_4096x4096", 32), ("decode_bs1_4096x4096", 1)):
+    layers = {}
+    for name, M, N, K in (("config0_bs32_4096x4096", 32, 4096, 4096), ("decode_bs1_4096x4096", 1, 4096, 4096),
+                          ("decode_bs1_qkv_12288x4096", 1, 12288, 4096), ("decode_bs4_qkv_12288x4096", 4, 12288, 4096),
+                          ("decode_bs4_proj_4096x11008", 4, 4096, 11008)):
+        if (N, K) not in layers:
+            layers[(N, K)] = synth_layer(N, K, dev, gen)
+        t = layers[(N, K)]
         A = synth_activation(M, K, t["ind_i32"], dev, gen)
         o = torch.empty((M, N), dtype=torch.float16, device=dev)
         ins = [A, t["weight"], t["weights_scaling_factor"], t["fp_weight"], t["fp_ind"], t["qweight"],
