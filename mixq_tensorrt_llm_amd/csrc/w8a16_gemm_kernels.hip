@@ -359,6 +359,12 @@ __global__ __launch_bounds__(256 * (WMH == 3 ? 2 : WMH)) void w8a16_gemm_wide_ke
 #pragma unroll
         for (int i = 0; i < WL; ++i) glds16_sbase(wb, woffv[i], lds0 + buf * STAGE + ASTAGE + i * T * 16);
     };
+    // the same copies one piece at a time (p < GROUP_OPS: token pieces first), for spreading them over a stage's MFMA groups
+    auto issue_piece = [&](int rel, int buf, int pc) __attribute__((always_inline)) {
+        if ((ABL & 1) && rel >= NST - 1) return;
+        if (pc < AL) glds16_sbase(abase + (int64_t)rel * (KBW * 2), aoffv[pc], lds0 + buf * STAGE + pc * T * 16);
+        else glds16_sbase(wbase + (int64_t)rel * 128, woffv[pc - AL], lds0 + buf * STAGE + ASTAGE + (pc - AL) * T * 16);
+    };
 
     // ---- fragment read offsets ----------------------------------------------------------------------------------------
     // tokens: lane (row t*32 + lr, kg): chunk = 2*(2j + kg) + odd;  weights: lane (column, kg): group 2j + kg of its column
@@ -429,7 +435,8 @@ __global__ __launch_bounds__(256 * (WMH == 3 ? 2 : WMH)) void w8a16_gemm_wide_ke
     };
     // one k step: MFMAs of (j, all row tiles) with the operands E[j] / O[j]; meanwhile `wnext` ([cb] raw groups) is
     // dequantised into E[j ^ 1] / O[j ^ 1] (DEQ) and the token fragments of the next (j, t) are read
-    auto step = [&](const char* base, auto j_tag, const uint4 (&wnext)[2], auto deq_tag) __attribute__((always_inline)) {
+    auto step = [&](const char* base, auto j_tag, const uint4 (&wnext)[2], auto deq_tag, auto&& before_tile)
+                    __attribute__((always_inline)) {
         constexpr int j = decltype(j_tag)::value;
         constexpr bool DEQ = decltype(deq_tag)::value;
         v8h fa[2], fo[2];
@@ -438,6 +445,7 @@ __global__ __launch_bounds__(256 * (WMH == 3 ? 2 : WMH)) void w8a16_gemm_wide_ke
 #pragma unroll
         for (int t = 0; t < MTW; ++t) {
             const int cur = t & 1;
+            before_tile(j, t); // (this stage's share of the NEXT copies: issued while the previous tile's MFMAs drain)
             if (t + 1 < MTW && !(ABL & 4)) {
                 fa[cur ^ 1] = *reinterpret_cast<const v8h*>(base + (t + 1) * 32 * ROWBW + aoff[j][0]);
                 fo[cur ^ 1] = *reinterpret_cast<const v8h*>(base + (t + 1) * 32 * ROWBW + aoff[j][1]);
@@ -496,7 +504,20 @@ __global__ __launch_bounds__(256 * (WMH == 3 ? 2 : WMH)) void w8a16_gemm_wide_ke
                 // stage i certified at its top; step 0's weights are dequantised in the open, step 1's under step 0's MFMAs
                 // (K halves: each wave runs ONE step per stage, its own)
                 certify(i);
-                if (i + NST - 1 < nst) issue(i + NST - 1, (u + NST - 1) % NST);
+                // the copies of stage i + NST - 1 are spread over this stage's tile steps: a global_load_lds costs the issuing
+                // wave 60-185 cycles, six or more of them in a row at the top of a stage are a third of a short tile's stage
+                const bool more = i + NST - 1 < nst;
+                constexpr int TS = (KH ? 1 : 2) * MTW; // tile steps of a stage (per wave)
+                auto before_tile = [&](int jj, int tt) __attribute__((always_inline)) {
+                    const int ts = (KH ? 0 : jj) * MTW + tt;
+                    if (more) {
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int pc = 0; pc < GROUP_OPS; ++pc)
+                            if (pc * TS / GROUP_OPS == ts) issue_piece(i + NST - 1, (u + NST - 1) % NST, pc);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                };
                 uint4 w0[2];
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb) {
@@ -509,11 +530,11 @@ __global__ __launch_bounds__(256 * (WMH == 3 ? 2 : WMH)) void w8a16_gemm_wide_ke
                     for (int h = 0; h < 2; ++h) dequant_half(w0[cb], h, scale2[cb], E[0][cb], O[0][cb]);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (KH) {
-                    step(base, std::integral_constant<int, 0>{}, wr, std::false_type{});
+                    step(base, std::integral_constant<int, 0>{}, wr, std::false_type{}, before_tile);
                 } else {
-                    step(base, std::integral_constant<int, 0>{}, wr, std::true_type{});
+                    step(base, std::integral_constant<int, 0>{}, wr, std::true_type{}, before_tile);
                     __builtin_amdgcn_sched_barrier(0);
-                    step(base, std::integral_constant<int, 1>{}, wr, std::false_type{});
+                    step(base, std::integral_constant<int, 1>{}, wr, std::false_type{}, before_tile);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
