@@ -207,6 +207,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KG * 64) void gemm_w8a8o16_kernel
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * (XL + YL)) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads(); // slice kt has landed for every wave; everyone is done reading the previous slice's buffer
+        // (all copies of slice it + NSTAGE - 1 at once, as early as possible: spreading them over the four k-steps -- which
+        //  pays in the fpA_intB wide form -- measured +4..+8 % here on wide / long-K shapes, -3 % on 4096 x 4096: round 2)
         if ((it + NSTAGE - 1) * KG + group < nk) stage((it + NSTAGE - 1) % NSTAGE, (it + NSTAGE - 1) * KG + group);
         if (KG > 1 && kt >= nk) continue; // (K groups past the end only keep the barrier count)
         const char* base = smem + (it % NSTAGE) * STAGE_BYTES;
