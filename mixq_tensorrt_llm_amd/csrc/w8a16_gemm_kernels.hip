@@ -906,6 +906,9 @@ static WoWidePlan wo_wide_plan(int M, int N, int K, bool have_scratch)
 {
     const int form = g_wo_form.load(), fks = g_wo_ks.load();
     if (form == 0 || (form < 0 && (M <= 32 || (M <= 256 && !have_scratch)))) return {0, 1};
+    // (49..64 tokens on wide outputs with short K: the narrow form's two 32-row MFMA tiles per wave still beat the 64-row wide
+    //  tiles by ~8 %: 12288 x 4096 22.1 vs 24.1 us, 16384 x 4096 24.0 vs 26.0; not at K = 8192)
+    if (form < 0 && M > 48 && M <= 64 && N >= 10240 && K <= 6144) return {0, 1};
     const int cus = num_cus(), tn = (N + wo::BNW - 1) / wo::BNW, nst = K / wo::KBW;
     static constexpr float kStage[6] = {0.f, 0.61f, 0.75f, 1.25f, 2.1f, 0.75f};
     static constexpr float kHand0[6] = {0.f, 2.f, 3.f, 6.f, 12.f, 3.f}, kHand1[6] = {0.f, 0.8f, 1.3f, 2.5f, 4.3f, 1.3f};
