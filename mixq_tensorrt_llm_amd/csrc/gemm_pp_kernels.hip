@@ -254,7 +254,15 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
                         v16i, __builtin_amdgcn_mfma_f32_32x32x16_f16(
                                   __builtin_bit_cast(v8h, X[ks]), __builtin_bit_cast(v8h, Y[jy][ks]),
                                   __builtin_bit_cast(v16f, acc[xi][yhalf * 2 + jy]), 0, 0, 0));
-                else
+                else if constexpr ((ABL & 64) != 0) { // timing probe (wrong results): the same operand registers and the same
+                    // number of integer operations through TWO v_mfma_i32_16x16x64_i8 per 32x32x32 (power per operation)
+                    v16i& c = acc[xi][yhalf * 2 + jy];
+                    v4i c0 = {c[0], c[1], c[2], c[3]}, c1 = {c[4], c[5], c[6], c[7]};
+                    c0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(X[ks], Y[jy][ks], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(X[ks], Y[jy][ks], c1, 0, 0, 0);
+                    c[0] = c0[0], c[1] = c0[1], c[2] = c0[2], c[3] = c0[3];
+                    c[4] = c1[0], c[5] = c1[1], c[6] = c1[2], c[7] = c1[3];
+                } else
                 acc[xi][yhalf * 2 + jy] =
                     (ABL & 32) ? __builtin_amdgcn_mfma_i32_32x32x32_i8(Y[jy][ks], X[ks], acc[xi][yhalf * 2 + jy], 0, 0, 0)
                                : __builtin_amdgcn_mfma_i32_32x32x32_i8(X[ks], Y[jy][ks], acc[xi][yhalf * 2 + jy], 0, 0, 0);
@@ -938,6 +946,7 @@ hipError_t launch_gemm_pp_ablate(const GemmParams& p, int abl, hipStream_t st)
     case 24: return launch_pp_cfg<EPI_DEQUANT, true, false, 24>(p, st);
     case 21: return launch_pp_cfg<EPI_DEQUANT, true, false, 21>(p, st);
     case 32: return launch_pp_cfg<EPI_DEQUANT, true, false, 32>(p, st); // MFMA operands swapped (transposed tiles: timing only)
+    case 64: return launch_pp_cfg<EPI_DEQUANT, true, false, 64>(p, st); // 2 x 16x16x64 per 32x32x32 (timing only)
     default: return launch_pp_cfg<EPI_DEQUANT, true, false, 0>(p, st);
     }
 }
