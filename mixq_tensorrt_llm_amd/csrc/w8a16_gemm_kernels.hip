@@ -841,13 +841,14 @@ static size_t wo_narrow_workspace(int rows, int N, int K)
 struct WoCfg {
     int rows, mtw, wmh;
 };
-static constexpr WoCfg kWoCfg[6] = {
+static constexpr WoCfg kWoCfg[7] = {
     {0, 0, 0},    // 0: the narrow form above, in passes of 256 tokens
     {32, 1, 1},   // 1: 4 waves x (32 rows x 64 columns)
     {64, 2, 1},   // 2: 4 waves x (64 x 64)
     {128, 2, 2},  // 3: 8 waves x (64 x 64)
     {256, 4, 2},  // 4: 8 waves x (128 x 64)
     {64, 2, 3},   // 5: 8 waves x (64 x 64), the second four on the second k step of every stage ("K halves")
+    {128, 4, 3},  // 6: 8 waves x (128 x 64), K halves: every weight dequantised once per workgroup
 };
 // (Measured and dropped: 4 "fat" waves x (128 x 64) and 4 x (256 x 64), one wave per SIMD, every weight dequantised once
 // per workgroup instead of once per row half -- equal to / 5-8 % slower than the 8-wave forms of the same height.)
@@ -890,7 +891,7 @@ void set_wo_force(int form, int ks)
         return;
     }
     if (form == -1) g_wo_abl.store(0), g_wo_twopass.store(-1), g_wo_twopass_tile.store(0), g_wo_skinny.store(1), g_wo_skinny_decode.store(-1);
-    if (form >= -1 && form <= 5) g_wo_form.store(form);
+    if (form >= -1 && form <= 6) g_wo_form.store(form);
     if (ks >= -1) g_wo_ks.store(ks);
 }
 
@@ -910,11 +911,14 @@ static WoWidePlan wo_wide_plan(int M, int N, int K, bool have_scratch)
     //  tiles by ~8 %: 12288 x 4096 22.1 vs 24.1 us, 16384 x 4096 24.0 vs 26.0; not at K = 8192)
     if (form < 0 && M > 48 && M <= 64 && N >= 10240 && K <= 6144) return {0, 1};
     const int cus = num_cus(), tn = (N + wo::BNW - 1) / wo::BNW, nst = K / wo::KBW;
-    static constexpr float kStage[6] = {0.f, 0.61f, 0.75f, 1.25f, 2.1f, 0.75f};
-    static constexpr float kHand0[6] = {0.f, 2.f, 3.f, 6.f, 12.f, 3.f}, kHand1[6] = {0.f, 0.8f, 1.3f, 2.5f, 4.3f, 1.3f};
+    static constexpr float kStage[7] = {0.f, 0.61f, 0.75f, 1.25f, 2.1f, 0.75f, 1.13f};
+    static constexpr float kHand0[7] = {0.f, 2.f, 3.f, 6.f, 12.f, 3.f, 6.f}, kHand1[7] = {0.f, 0.8f, 1.3f, 2.5f, 4.3f, 1.3f, 2.5f};
     WoWidePlan best{3, 1};
     float best_t = 1e30f;
-    for (int cfg = 1; cfg <= (form == 5 ? 5 : 4); ++cfg) {
+    for (int c = 1; c <= (form >= 5 ? form : 4); ++c) {
+        // (automatic: the 128-row tiles run their K-halves form, configuration 6 -- every weight dequantised once per workgroup:
+        //  -7..-11 % against configuration 3 from 257 to 1024 tokens on the long / wide shapes, level on 4096 x 4096)
+        const int cfg = form < 0 && c == 3 ? 6 : c;
         if (form > 0 && cfg != form) continue;
         const int rows = kWoCfg[cfg].rows, tiles = ((M + rows - 1) / rows) * tn;
         if (form < 0 && rows >= 2 * M && cfg > 1) break; // (a tile twice as tall as the problem)
@@ -1116,6 +1120,7 @@ hipError_t launch_w8a16_gemm(const void* A, const uint8_t* Wq, const void* scale
         case 2: return launch_wo_wide<2, 1, 6>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
         case 3: return launch_wo_wide<2, 2, 4>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
         case 5: return launch_wo_wide<2, 3, 6>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
+        case 6: return launch_wo_wide<4, 3, 4>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
         default: return launch_wo_wide<4, 2, 3>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
         }
     }

@@ -125,7 +125,7 @@ def test_large_m_forms(oracle, form, which, ks, M, N, K):
     assert np.isfinite(got2).all() and rel_err(got2, want) < REL_TOL
 
 
-@pytest.mark.parametrize("cfg", [831, 832, 833, 834, 835])
+@pytest.mark.parametrize("cfg", [831, 832, 833, 834, 835, 836])
 @pytest.mark.parametrize("ks", [85, 86, 88])
 @pytest.mark.parametrize("M,N,K", [(5, 130, 192), (33, 258, 320), (64, 128, 4160), (129, 640, 1088), (257, 256, 2048),
                                    (300, 1026, 1600)])
@@ -183,7 +183,7 @@ def test_randomised_soak_over_forms_and_shapes(oracle, form):
     """120 random (M, N, K) x a random form (narrow / one of the four wide tile heights / two-pass / automatic) x a random
     K split, against the oracle: ragged everything, N % 4 == 2 included, K from one 64-k stage up."""
     rng = np.random.default_rng(2024)
-    knobs_form = [80, 81, 831, 832, 833, 834, 835, 842, 851, 853, 855]
+    knobs_form = [80, 81, 831, 832, 833, 834, 835, 836, 842, 851, 853, 855]
     knobs_ks = [85, 86, 87, 88, 89]
     for it in range(120):
         M = int(rng.integers(5, 420)) if it % 4 else int(rng.integers(5, 40))
