@@ -912,7 +912,7 @@ static WoWidePlan wo_wide_plan(int M, int N, int K, bool have_scratch)
     if (form < 0 && M > 48 && M <= 64 && N >= 10240 && K <= 6144) return {0, 1};
     const int cus = num_cus(), tn = (N + wo::BNW - 1) / wo::BNW, nst = K / wo::KBW;
     static constexpr float kStage[7] = {0.f, 0.61f, 0.75f, 1.25f, 2.1f, 0.75f, 1.13f};
-    static constexpr float kHand0[7] = {0.f, 2.f, 3.f, 6.f, 12.f, 3.f, 6.f}, kHand1[7] = {0.f, 0.8f, 1.3f, 2.5f, 4.3f, 1.3f, 2.5f};
+    static constexpr float kHand0[7] = {0.f, 2.f, 3.f, 10.f, 12.f, 3.f, 10.f}, kHand1[7] = {0.f, 0.8f, 1.3f, 2.5f, 4.3f, 1.3f, 2.5f};
     WoWidePlan best{3, 1};
     float best_t = 1e30f;
     for (int c = 1; c <= (form >= 5 ? form : 4); ++c) {
@@ -940,9 +940,9 @@ static WoWidePlan wo_wide_plan(int M, int N, int K, bool have_scratch)
         }
     }
     // 64-row tiles that are split at most 2 ways run their 8-wave form (the second four waves on the second k step of every
-    // stage): -8 % at 192 / 256 tokens on 12288 x 4096, -4..-7 % on 28672 x 8192, level elsewhere; with deeper splits the
-    // 4-wave form stays (4096 x 4096 at 64 tokens: 20.2 vs 20.7 us).
-    if (form < 0 && best.cfg == 2 && best.ks <= 2) best.cfg = 5;
+    // stage): -8 % at 192 / 256 tokens on 12288 x 4096, -4..-7 % on 28672 x 8192, -8..-13 % from 384 tokens on the 4096-wide
+    // shapes whatever the split; below 128 tokens with deeper splits the 4-wave form stays (4096 x 4096 at 64: 20.2 vs 20.7 us).
+    if (form < 0 && best.cfg == 2 && (best.ks <= 2 || M >= 128)) best.cfg = 5;
     return best;
 }
 
