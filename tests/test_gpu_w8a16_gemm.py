@@ -179,6 +179,21 @@ def test_skinny_form(oracle, form, shape, M, N, K):
     assert nws == 0 and np.array_equal(got.view(np.uint16), got2.view(np.uint16))
 
 
+@pytest.mark.parametrize("M,N,K", [(48, 12288, 256), (49, 12288, 256), (64, 10240, 192), (200, 4096, 512), (384, 12288, 128),
+                                   (700, 3584, 704), (1024, 4096, 256), (1300, 8704, 128), (4096, 4096, 64), (2048, 2048, 320)])
+def test_automatic_plan_at_scale(oracle, M, N, K):
+    """The automatic plan on shapes large enough to reach every branch of it (skinny with three token tiles, narrow form
+    at 49..64 tokens on wide outputs, 64- / 128-row K-halves tiles, 256-row tiles, the two-pass form from 1280 tokens with
+    >= 200 tiles), K kept short so that the oracle stays cheap."""
+    A, q, sc = make(M, N, K, M + N + 13 * K)
+    qi = interleave(q)
+    want = oracle.w8a16_gemv(A, q, sc)
+    got, _ = run(A, qi, sc, N, scratch=True)
+    assert np.isfinite(got).all() and rel_err(got, want) < REL_TOL
+    got2, _ = run(A, qi, sc, N, scratch=False)
+    assert np.isfinite(got2).all() and rel_err(got2, want) < REL_TOL
+
+
 def test_randomised_soak_over_forms_and_shapes(oracle, form):
     """120 random (M, N, K) x a random form (narrow / one of the four wide tile heights / two-pass / automatic) x a random
     K split, against the oracle: ragged everything, N % 4 == 2 included, K from one 64-k stage up."""
