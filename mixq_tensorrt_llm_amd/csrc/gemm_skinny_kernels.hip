@@ -202,7 +202,9 @@ static hipError_t launch_skinny_epi(const GemmParams& p, hipStream_t st)
     // where KW = 4 leaves one wave per SIMD -- the kernel is bound by the qA re-reads through L1, not by occupancy.
     // (Round 2: 2 / 4 sixteen-column groups per wave sharing each qA fragment -- what made the fpA_intB twin of this kernel,
     //  w8a16_skinny_kernel, fast -- measured 25-100 % SLOWER here at every M <= 64 on five shapes: a quarter of the workgroups,
-    //  four times the weight registers in flight per wave; the int8 fragments are half the bytes of the fp16 ones to begin with.)
+    //  four times the weight registers in flight per wave; the int8 fragments are half the bytes of the fp16 ones to begin with.
+    //  Rotating the K-step order per workgroup, so that the workgroups do not all ask for the same qA lines at the same moment:
+    //  no change either -- 7.9-8.2 vs 8.3-8.7 us at M = 32 on 4096 x 4096 -- the L2 serves the broadcast.)
     int kw = g_skinny_kw.load();
     if (EPI == EPI_DEQUANT && kw >= 21 && kw <= 27) { // measurement-only ablations (variant 40 + 20 + ABL): wrong results
         switch (kw - 20) {
