@@ -1115,6 +1115,17 @@ hipError_t launch_w8a16_gemm(const void* A, const uint8_t* Wq, const void* scale
             default: break;
             }
         }
+        if (pl.cfg == 6) {
+            switch (g_wo_abl.load()) { // the same ablations for the 128-row K-halves form
+            case 1: return launch_wo_wide<4, 3, 4, 1>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
+            case 2: return launch_wo_wide<4, 3, 4, 2>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
+            case 4: return launch_wo_wide<4, 3, 4, 4>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
+            case 8: return launch_wo_wide<4, 3, 4, 8>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
+            case 7: return launch_wo_wide<4, 3, 4, 7>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
+            case 14: return launch_wo_wide<4, 3, 4, 14>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
+            default: break;
+            }
+        }
         switch (pl.cfg) {
         case 1: return launch_wo_wide<1, 1, 6>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
         case 2: return launch_wo_wide<2, 1, 6>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
