@@ -99,6 +99,10 @@ MIXQ_API int mixq_get_output_data_type(const mixq_handle* h, int index); /* MIXQ
  *   qA int8 [maxM*K] | sA fp16 [maxM] | fpA fp16 [maxM*128], each carved at 128-B alignment like
  *   nextWorkspacePtr (.cpp:206-215).  size_t-clean (the reference overflows int). */
 MIXQ_API size_t mixq_workspace_size(const mixq_handle* h, int64_t maxM, int64_t N, int64_t K);
+/* Exchange scratch that ONE mixq_enqueue call with exactly M rows carves behind fpA (K splits over workgroups; 0 for
+ * most shapes).  Not monotone in M; mixq_workspace_size(maxM, N, K) covers the maximum over every M <= maxM (a caller
+ * that sizes once, like TensorRT's getWorkspaceSize, is safe for every later M). */
+MIXQ_API size_t mixq_enqueue_scratch_size(int64_t M, int64_t N, int64_t K);
 /* The reference's own (larger) formula, for callers that size buffers by it:
  *   max(maxM*K + 2*maxM + 2*K*N, 16*maxM*N), 32 MiB if that is 0. */
 MIXQ_API size_t mixq_reference_workspace_size(int64_t maxM, int64_t N, int64_t K);

@@ -75,6 +75,7 @@ SIGNATURES = {
     "mixq_get_output_data_type": (_i, [_vp, _i]),
     "mixq_workspace_size": (_sz, [_vp, _i64, _i64, _i64]),
     "mixq_reference_workspace_size": (_sz, [_i64, _i64, _i64]),
+    "mixq_enqueue_scratch_size": (_sz, [_i64, _i64, _i64]),
     "mixq_enqueue": (_i, [_vp, ctypes.POINTER(TensorDesc), ctypes.POINTER(TensorDesc), ctypes.POINTER(_vp),
                           ctypes.POINTER(_vp), _vp, _vp]),
     "mixq_enqueue_profiled": (_i, [_vp, ctypes.POINTER(TensorDesc), ctypes.POINTER(TensorDesc), ctypes.POINTER(_vp),

@@ -238,36 +238,44 @@ int mixq_supports_format_combination(const mixq_handle*, int pos, const mixq_ten
 int mixq_get_output_data_type(const mixq_handle*, int) { return MIXQ_TYPE_HALF; }
 
 // ------------------------------------------------------------------------------------------ workspace ---
-static size_t gemm_scratch_bytes_fwd(int M, int N, int K)
+// Exchange scratch ONE mixq_enqueue call with exactly M rows carves behind fpA (the K splits over workgroups of
+// gemm_pp_kernels.hip / gemm_kernels.hip): the 256x256 form's from 256 rows on, the small-tile form's below that.
+// enqueue_impl and the workspace bound below both go through this function, so they cannot disagree.
+static size_t enqueue_scratch_bytes(int64_t M, int64_t N, int64_t K)
 {
-    const size_t a = mixq::gemm_splitk_workspace_size(M, N, K);
-    return a ? a : mixq::gemm_xsplit_workspace_size(M, N, K);
+    if (M <= 4 || N <= 0 || K <= 0 || M > INT32_MAX || N > INT32_MAX || K > INT32_MAX) return 0;
+    if (M >= 256) {
+        const size_t a = mixq::gemm_splitk_workspace_size((int)M, (int)N, (int)K);
+        if (a) return a;
+    }
+    return mixq::gemm_xsplit_workspace_size((int)M, (int)N, (int)K);
 }
-// Largest exchange scratch mixq_enqueue can ask for with these N, K and any M <= maxM (the plan depends on M only through
-// the tile counts, so one probe per 256-row / 32-row step covers it); N <= 0: the shape-independent bound.
+// Largest exchange scratch mixq_enqueue can carve with these N, K and ANY M <= maxM.  The plans (gemm_splitk_plan incl. its
+// gemm_pp128_wins gate, xsplit_plan) see M only through ceil(M / 32 | 64 | 128 | 256) and the thresholds 4 / 16 / 32 / 128 /
+// 255, and are not monotone in M, so every 32-row step is probed at its right end (where all those ceilings are constant
+// over the step) plus the thresholds; N <= 0 or a huge maxM: the shape-independent bound.
 static size_t enqueue_scratch_bound(int64_t maxM, int64_t N, int64_t K)
 {
     if (maxM <= 4) return 0;
-    if (N <= 0 || N > INT32_MAX || K > INT32_MAX || maxM > INT32_MAX)
-        return maxM >= 256 ? mixq::gemm_splitk_workspace_bound() : mixq::gemm_xsplit_workspace_bound();
+    const size_t any = mixq::gemm_splitk_workspace_bound() > mixq::gemm_xsplit_workspace_bound()
+                           ? mixq::gemm_splitk_workspace_bound()
+                           : mixq::gemm_xsplit_workspace_bound();
+    if (N <= 0 || N > INT32_MAX || K > INT32_MAX || maxM > INT32_MAX) return any;
+    const int64_t steps = (maxM + 31) / 32;
+    if (steps > (int64_t)1 << 20) return any;
     size_t best = 0;
     auto probe = [&](int64_t m) {
         if (m < 5 || m > maxM) return;
-        const size_t b = m >= 256 ? gemm_scratch_bytes_fwd((int)m, (int)N, (int)K)
-                                  : mixq::gemm_xsplit_workspace_size((int)m, (int)N, (int)K);
+        const size_t b = enqueue_scratch_bytes(m, N, K);
         if (b > best) best = b;
     };
-    for (int64_t m = 32; m < 256 && m <= maxM + 31; m += 32) probe(m < maxM ? m : maxM);
-    const int64_t steps = (maxM + 255) / 256;
-    if (steps <= 4096) {
-        for (int64_t t = 1; t <= steps; ++t) probe(t * 256 < maxM ? t * 256 : maxM);
-    } else {
-        const size_t b = mixq::gemm_splitk_workspace_bound();
-        if (b > best) best = b;
-    }
+    for (int64_t m : {5, 8, 16, 17}) probe(m);
+    for (int64_t t = 1; t <= steps; ++t) probe(t * 32 < maxM ? t * 32 : maxM);
     probe(maxM);
     return best;
 }
+
+size_t mixq_enqueue_scratch_size(int64_t M, int64_t N, int64_t K) { return enqueue_scratch_bytes(M, N, K); }
 
 size_t mixq_workspace_size(const mixq_handle*, int64_t maxM, int64_t N, int64_t K)
 {
@@ -665,9 +673,7 @@ static int enqueue_impl(const mixq_handle* h, const mixq_tensor_desc* inputDesc,
         // runs one launch earlier anyway.
         hipStream_t st = static_cast<hipStream_t>(stream);
         void* scratch = nullptr;
-        const size_t scratch_bytes = M >= 256   ? gemm_scratch_bytes((int)M, (int)N, (int)K)
-                                     : M > 4   ? mixq::gemm_xsplit_workspace_size((int)M, (int)N, (int)K)
-                                                : 0;
+        const size_t scratch_bytes = enqueue_scratch_bytes(M, N, K);
         if (scratch_bytes) {
             base = align_up(base + (size_t)M * (size_t)kNumOutliers * sizeof(uint16_t), kWorkspaceAlign);
             scratch = reinterpret_cast<void*>(base);

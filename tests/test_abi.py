@@ -119,6 +119,41 @@ def test_workspace_sizes_are_size_t_clean(lib):
     lib.mixq_destroy(h)
 
 
+@pytest.mark.parametrize("N,K", [(7168, 7168), (6144, 6144), (4096, 5120), (12288, 4096), (4096, 11008), (1024, 28672),
+                                 (3584, 18944), (4608, 3584), (8192, 28672), (5120, 13824)])
+@pytest.mark.parametrize("maxM", [255, 256, 1024, 2048, 3000])
+def test_workspace_sized_once_covers_every_smaller_m(lib, N, K, maxM):
+    """the split plans are not monotone in M (the 128 x 256 tiles gate the K split through ceil(M / 128)),
+    so a caller that sizes the workspace once for maxM (getWorkspaceSize, TsinghuaMixQPlugin.cpp:351-378) must still be
+    covered for EVERY M <= maxM: the per-M carve of enqueue_impl, byte for byte, against the bound."""
+    h = lib.mixq_create(0, 0, 0)
+    ws = lib.mixq_workspace_size(h, maxM, N, K)
+
+    def up(v, a=128):
+        return (v + a - 1) // a * a
+
+    worst = 0
+    for m in range(5, maxM + 1):
+        scratch = lib.mixq_enqueue_scratch_size(m, N, K)
+        carve = 127 + up(m * K) + up(2 * m) + up(2 * 128 * m) + scratch   # unaligned base, 128-B carve of each region
+        assert carve <= ws, (m, scratch, ws)
+        worst = max(worst, scratch)
+    # and the bound is tight: it is the largest per-M scratch, not the shape-independent 64 MiB
+    assert ws <= 128 + up(maxM * K) + up(2 * maxM) + up(2 * 128 * maxM) + up(worst) + 128
+    lib.mixq_destroy(h)
+
+
+def test_scratch_plan_is_not_monotone_in_m(lib):
+    """The shapes ADVICE r2 named: M = 257 needs a K-split scratch that M = 1024 / 2048 does not."""
+    assert lib.mixq_enqueue_scratch_size(257, 7168, 7168) > 0 == lib.mixq_enqueue_scratch_size(1024, 7168, 7168) or \
+        lib.mixq_enqueue_scratch_size(257, 6144, 6144) > 0
+    h = lib.mixq_create(0, 0, 0)
+    for n, k in ((7168, 7168), (6144, 6144)):
+        need = lib.mixq_enqueue_scratch_size(257, n, k)
+        assert lib.mixq_workspace_size(h, 2048, n, k) >= 2048 * k + need
+    lib.mixq_destroy(h)
+
+
 def test_enqueue_rejects_bad_arguments_without_touching_the_gpu(lib):
     h = lib.mixq_create(0, 0, 0)
     d = (TensorDesc * 7)(*[TensorDesc.make((8, 64))] * 7)
