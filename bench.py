@@ -310,6 +310,18 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="GEMM schedule: 0 auto, 1 two-barrier, 2 ping-pong (A/B runs)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # `python bench.py --gpus N ...` typed as is (the reference's multi-GPU scripts self-launch too,
+        # mix_qwen_mpi.sh:17-27): re-run under torch.distributed.run, one rank per GPU; rank 0 of the child prints the
+        # ONE JSON line on our stdout.
+        import socket
+        import subprocess
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -561,6 +573,9 @@ def main():
                                     "the next GEMM)", "transport": tmodel.transport, "peer_wait_timed_out": timed_out,
                       "allgather_recv_GB_per_gpu_per_step": recv / 1e9,
                       "tokens_per_step": args.tokens}
+            if timed_out:  # a stale gather is not a measurement
+                tp_obj = {"tp": world, "world_size": world, "transport": tmodel.transport,
+                          "error": "a peer-write wait timed out: the gathered outputs of this leg are not valid"}
         except Exception as e:  # noqa: BLE001 -- the main measurement must survive
             tp_obj = {"tp": world, "error": repr(e)}
         wd.cancel()

@@ -272,22 +272,38 @@ MIXQ_API int mixq_unpack_int4_to_int8(const uint8_t* src, int8_t* dst, size_t pa
 /* The path's ONE collective -- all-gather of the fp16 output columns, only where TP > 1 -- as one-sided peer writes over
  * xGMI (csrc/tp_kernels.hip).  The reference has no working counterpart (plugin.py:155-156 calls allreduce after an
  * N-split and is guarded off by `assert tp_size == 1`, tensorrt_llm/quantization/quantize.py:342).
- * One process per GPU.  Every rank allocates its destination buffer(s) with mixq_tp_buffer_alloc (hipMalloc, zeroed;
- * returns the device pointer and a 64-byte hipIpcMemHandle_t), ships the handle to its peers over any host channel
- * (torch.distributed in parallel.PeerGather), and opens the peers' handles with mixq_tp_buffer_open: from then on the
- * peers' buffers are plain device pointers in this process. */
-MIXQ_API int mixq_tp_buffer_alloc(size_t bytes, void** dev_ptr, void* ipc_handle_64);
+ * One process per GPU.  Every rank allocates its destination buffers and its flag block with mixq_tp_buffer_alloc
+ * (zeroed; returns the device pointer and a 64-byte hipIpcMemHandle_t), ships the handles to its peers over any host
+ * channel (torch.distributed in parallel.PeerGather), and opens the peers' handles with mixq_tp_buffer_open: from then
+ * on the peers' buffers are plain device pointers in this process.
+ * mem_kind: memory that a REMOTE GPU writes while the local GPU reads / polls it must be FINEGRAINED or UNCACHED
+ * (hipExtMallocWithFlags; what RCCL allocates its own flags and buffers with) -- system-scope atomics are only specified
+ * on such allocations; COARSE (plain hipMalloc) is for single-GPU experiments only. */
+#define MIXQ_TP_MEM_COARSE 0
+#define MIXQ_TP_MEM_FINEGRAINED 1
+#define MIXQ_TP_MEM_UNCACHED 2
+#define MIXQ_TP_FLAG_WORDS 64 /* flag words per (buffer parity, producer) */
+MIXQ_API int mixq_tp_buffer_alloc(size_t bytes, int mem_kind, void** dev_ptr, void* ipc_handle_64);
 MIXQ_API int mixq_tp_buffer_open(const void* ipc_handle_64, void** dev_ptr);
 MIXQ_API int mixq_tp_buffer_close(void* dev_ptr); /* a pointer from mixq_tp_buffer_open */
 MIXQ_API int mixq_tp_buffer_free(void* dev_ptr);  /* a pointer from mixq_tp_buffer_alloc */
+/* 64 bytes of host-mapped, coherent status words: [0] != 0 = a wait gave up (sticky), [1] = the sequence number it was
+ * waiting for.  The host reads *host_ptr without synchronising the device; kernels get dev_ptr. */
+MIXQ_API int mixq_tp_status_alloc(void** host_ptr, void** dev_ptr);
+MIXQ_API int mixq_tp_status_free(void* host_ptr);
 /* src fp16 [M, n_local] (this rank's operator output) -> columns [col0, col0 + n_local) of the fp16 [M, N] buffer of each
- * of the ndst <= 8 destinations (own rank included), then dst_flags[r][0] = seq (system-scope release) for every r.
+ * of the ndst <= 8 destinations (own rank included), then dst_flags[r][0 .. nflags) = seq (system scope, after a system
+ * fence) for every r -- also when M == 0 (every consumer's wait of this call expects the flags).
  * done_counter: one zeroed device word of this rank (left zero).  n_local, N, col0 multiples of 8. */
 MIXQ_API int mixq_tp_push_columns(const void* src, void* const* dst_bases, void* const* dst_flags, int ndst, int M,
-                                  int n_local, int N, int col0, uint32_t seq, void* done_counter, void* stream);
-/* Makes `stream` wait until flags[0 .. n) (this rank's flag array, one word per producer) all equal seq; gives up after
- * ~2 s and sets *timeout_flag = 1 (a device word the host may poll) rather than hanging the stream. */
-MIXQ_API int mixq_tp_wait(const void* flags, int n, uint32_t seq, void* timeout_flag, void* stream);
+                                  int n_local, int N, int col0, uint32_t seq, int nflags, void* done_counter,
+                                  void* stream);
+/* Makes `stream` wait until flags[r * MIXQ_TP_FLAG_WORDS + w] == seq for every producer r < nprod and word0 <= w < word0 +
+ * nwords (this rank's flag block of the call's parity).  Gives up after patience_ms (0: 2000) and raises status[0]
+ * (sticky: later waits return at once); trap_on_timeout != 0 additionally traps, so that nothing queued behind the wait
+ * runs on a stale tensor (the stream's next synchronisation fails). */
+MIXQ_API int mixq_tp_wait(const void* flags, int nprod, int word0, int nwords, uint32_t seq, void* status_dev,
+                          int trap_on_timeout, uint32_t patience_ms, void* stream);
 
 /* ---- host helpers ----------------------------------------------------------------------------- */
 /* preprocess_weights (weightonlykernel/cutlass_kernels/cutlass_preprocessors.cc:536-545), int8, arch 80-90:

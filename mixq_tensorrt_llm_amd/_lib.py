@@ -111,13 +111,15 @@ SIGNATURES = {
     "mixq_w8a16_gemm_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "mixq_w8a16_gemm_workspace_size": (ctypes.c_size_t, [_i, _i, _i]),
     "mixq_w8a16_gemm_forward_ws": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, ctypes.c_size_t, _vp]),
-    "mixq_tp_buffer_alloc": (_i, [_sz, ctypes.POINTER(_vp), _vp]),
+    "mixq_tp_buffer_alloc": (_i, [_sz, _i, ctypes.POINTER(_vp), _vp]),
     "mixq_tp_buffer_open": (_i, [_vp, ctypes.POINTER(_vp)]),
     "mixq_tp_buffer_close": (_i, [_vp]),
     "mixq_tp_buffer_free": (_i, [_vp]),
-    "mixq_tp_push_columns": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i, _i, _i, _i, _i, ctypes.c_uint32, _vp,
-                                  _vp]),
-    "mixq_tp_wait": (_i, [_vp, _i, ctypes.c_uint32, _vp, _vp]),
+    "mixq_tp_status_alloc": (_i, [ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
+    "mixq_tp_status_free": (_i, [_vp]),
+    "mixq_tp_push_columns": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i, _i, _i, _i, _i, ctypes.c_uint32, _i,
+                                  _vp, _vp]),
+    "mixq_tp_wait": (_i, [_vp, _i, _i, _i, ctypes.c_uint32, _vp, _i, ctypes.c_uint32, _vp]),
     "mixq_preprocess_weights_int8": (_i, [_vp, _vp, _sz, _sz]),
     "mixq_unprocess_weights_int8": (_i, [_vp, _vp, _sz, _sz]),
     "mixq_debug_set_gemm_variant": (None, [_i]),

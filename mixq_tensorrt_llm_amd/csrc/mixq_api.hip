@@ -706,12 +706,22 @@ int mixq_enqueue_profiled(const mixq_handle* h, const mixq_tensor_desc* inputDes
 }
 
 // ------------------------------------------------------------------------------ multi-GPU ----
-int mixq_tp_buffer_alloc(size_t bytes, void** dev_ptr, void* ipc_handle_64)
+int mixq_tp_buffer_alloc(size_t bytes, int mem_kind, void** dev_ptr, void* ipc_handle_64)
 {
     if (!dev_ptr || !ipc_handle_64 || bytes == 0) return MIXQ_E_BADARG;
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size is part of the ABI");
     void* p = nullptr;
-    if (hipMalloc(&p, bytes) != hipSuccess) return MIXQ_E_HIP;
+    // Memory a REMOTE GPU writes while the local GPU reads / polls it must be fine-grained (or uncached): system-scope
+    // atomics are only specified there; plain hipMalloc memory is coarse-grained (coherent at kernel boundaries only).
+    // No silent downgrade: the caller asked for a kind and gets it or an error.
+    hipError_t e;
+    switch (mem_kind) {
+    case MIXQ_TP_MEM_COARSE: e = hipMalloc(&p, bytes); break;
+    case MIXQ_TP_MEM_FINEGRAINED: e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained); break;
+    case MIXQ_TP_MEM_UNCACHED: e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached); break;
+    default: return MIXQ_E_BADARG;
+    }
+    if (e != hipSuccess) return MIXQ_E_HIP;
     if (hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
         (void)hipFree(p);
         return MIXQ_E_HIP;
@@ -740,27 +750,46 @@ int mixq_tp_buffer_open(const void* ipc_handle_64, void** dev_ptr)
 int mixq_tp_buffer_close(void* dev_ptr) { return dev_ptr ? hip_rc(hipIpcCloseMemHandle(dev_ptr)) : MIXQ_E_BADARG; }
 int mixq_tp_buffer_free(void* dev_ptr) { return dev_ptr ? hip_rc(hipFree(dev_ptr)) : MIXQ_E_BADARG; }
 
-int mixq_tp_push_columns(const void* src, void* const* dst_bases, void* const* dst_flags, int ndst, int M, int n_local,
-                         int N, int col0, uint32_t seq, void* done_counter, void* stream)
+int mixq_tp_status_alloc(void** host_ptr, void** dev_ptr)
 {
-    if (!src || !dst_bases || !dst_flags || !done_counter || ndst < 1 || ndst > 8 || M < 0 || n_local <= 0 || N <= 0 ||
-        col0 < 0 || col0 + n_local > N)
+    if (!host_ptr || !dev_ptr) return MIXQ_E_BADARG;
+    void *h = nullptr, *d = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return MIXQ_E_HIP;
+    std::memset(h, 0, 64);
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+        (void)hipHostFree(h);
+        return MIXQ_E_HIP;
+    }
+    *host_ptr = h, *dev_ptr = d;
+    return MIXQ_OK;
+}
+
+int mixq_tp_status_free(void* host_ptr) { return host_ptr ? hip_rc(hipHostFree(host_ptr)) : MIXQ_E_BADARG; }
+
+int mixq_tp_push_columns(const void* src, void* const* dst_bases, void* const* dst_flags, int ndst, int M, int n_local,
+                         int N, int col0, uint32_t seq, int nflags, void* done_counter, void* stream)
+{
+    if (!dst_bases || !dst_flags || !done_counter || ndst < 1 || ndst > 8 || M < 0 || n_local <= 0 || N <= 0 ||
+        col0 < 0 || col0 + n_local > N || nflags < 1 || nflags > mixq::kTpFlagWords || (M > 0 && !src))
         return MIXQ_E_BADARG;
     if (n_local % 8 || N % 8 || col0 % 8) return MIXQ_E_SHAPE;
-    if (!aligned16(src)) return MIXQ_E_ALIGN;
+    if (M > 0 && !aligned16(src)) return MIXQ_E_ALIGN;
     unsigned* flags[8];
     for (int r = 0; r < ndst; ++r) {
         if (!dst_bases[r] || !dst_flags[r] || !aligned16(dst_bases[r])) return MIXQ_E_BADARG;
         flags[r] = static_cast<unsigned*>(dst_flags[r]);
     }
-    return hip_rc(mixq::launch_tp_push(src, dst_bases, flags, ndst, M, n_local, N, col0, seq,
+    return hip_rc(mixq::launch_tp_push(src, dst_bases, flags, ndst, M, n_local, N, col0, seq, nflags,
                                        static_cast<unsigned*>(done_counter), static_cast<hipStream_t>(stream)));
 }
 
-int mixq_tp_wait(const void* flags, int n, uint32_t seq, void* timeout_flag, void* stream)
+int mixq_tp_wait(const void* flags, int nprod, int word0, int nwords, uint32_t seq, void* status_dev, int trap_on_timeout,
+                 uint32_t patience_ms, void* stream)
 {
-    if (!flags || !timeout_flag || n < 1 || n > 8) return MIXQ_E_BADARG;
-    return hip_rc(mixq::launch_tp_wait(static_cast<const unsigned*>(flags), n, seq, static_cast<unsigned*>(timeout_flag),
+    if (!flags || !status_dev || nprod < 1 || nprod > 8 || word0 < 0 || nwords < 1 || word0 + nwords > mixq::kTpFlagWords)
+        return MIXQ_E_BADARG;
+    return hip_rc(mixq::launch_tp_wait(static_cast<const unsigned*>(flags), nprod, word0, nwords, seq,
+                                       static_cast<unsigned*>(status_dev), trap_on_timeout, patience_ms,
                                        static_cast<hipStream_t>(stream)));
 }
 

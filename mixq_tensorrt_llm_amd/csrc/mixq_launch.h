@@ -129,9 +129,12 @@ hipError_t launch_w8a16(const void* A, const uint8_t* Wq, const void* scale, voi
 
 void note_gemm_kernel(const char* name);
 // TP all-gather of the output columns as one-sided peer writes + flags (tp_kernels.hip)
+constexpr int kTpMaxPeers = 8;
+constexpr int kTpFlagWords = 64; // flag words per (parity, producer): word 0 = stand-alone push, one per M chunk when fused
 hipError_t launch_tp_push(const void* src, void* const* dst_bases, unsigned* const* dst_flags, int ndst, int M, int n_loc,
-                          int N, int col0, unsigned seq, unsigned* done_counter, hipStream_t st);
-hipError_t launch_tp_wait(const unsigned* flags, int n, unsigned seq, unsigned* timeout_flag, hipStream_t st);
+                          int N, int col0, unsigned seq, int nflags, unsigned* done_counter, hipStream_t st);
+hipError_t launch_tp_wait(const unsigned* flags, int nprod, int word0, int nwords, unsigned seq, unsigned* status, int trap,
+                          unsigned patience_ms, hipStream_t st);
 // fpA_intB GEMM (M > 4) on the interleaved qweight (w8a16_gemm_kernels.hip); scratch may be null (no K split)
 size_t w8a16_gemm_workspace_size(int M, int N, int K);
 hipError_t launch_w8a16_gemm(const void* A, const uint8_t* Wq, const void* scale, void* Out, int M, int N, int K,

@@ -84,80 +84,152 @@ class _RawDeviceBuffer:
         self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
 
 
+class PeerGatherTimeout(RuntimeError):
+    """A peer never published its flags: the gathered tensor of that call (and of every later one) is not valid."""
+
+
+_MEM_KINDS = {"coarse": 0, "finegrained": 1, "uncached": 2}
+
+
 class PeerGather:
     """All-gather of the output columns as ONE-SIDED PEER WRITES over xGMI (csrc/tp_kernels.hip, include/mixq.h
     ``mixq_tp_*``): every rank writes its [M, N/tp] block straight into its column block of every rank's [M, N] buffer,
     so the gathered tensor lands in its final layout -- no rank-major staging, no permute pass -- and all 7 links of a GPU
-    carry traffic at once.  Completion travels as a sequence number in the consumer's flag array; the consumer's STREAM
-    waits for it (no host sync), so the call is graph-capturable and overlaps with whatever runs on other streams.
+    carry traffic at once.  Completion travels as a sequence number in the consumer's flag words; the consumer's STREAM
+    waits for it (no host sync), so the call overlaps with whatever runs on other streams.
+
+    Memory: the destination buffers are fine-grained and the flag block uncached device memory (``hipExtMallocWithFlags``,
+    like RCCL's own buffers / flags) -- a remote GPU writes them while this GPU polls and reads; system-scope atomics are
+    only specified on such allocations.  ``MIXQ_TP_DATA_MEM`` / ``MIXQ_TP_FLAG_MEM`` = coarse | finegrained | uncached
+    override the kinds (experiments only).
 
     Two destination buffers alternate by call parity.  Contract: whatever reads the tensor returned by call i must be
     enqueued on the same stream before call i + 1 (then a fast rank can never overwrite data a slow rank still reads:
     it needs the slow rank's flag of call i + 1 before its own call i + 2 is pushed, and the slow rank publishes that
     flag only after its readers of call i, which are earlier in its stream).
 
+    NOT capturable in a HIP graph: the sequence number and the buffer parity are host-side state baked into the kernel
+    arguments, so a replay would find the flags of the captured call already set and read a half-written buffer.
+    ``gather`` refuses a capturing stream.
+
+    Failure: a wait gives up after ``patience_ms`` (lost / hung peer) and raises a STICKY status word in host-mapped
+    memory; every later ``gather`` (and ``check()``) raises ``PeerGatherTimeout`` without synchronising the device, and
+    later waits return at once instead of spinning again.  With ``trap_on_timeout`` the waiting kernel also traps, so that
+    nothing queued behind it consumes the stale tensor (the stream's next synchronisation fails) -- the production
+    setting; the self-test of ``bench.py`` keeps it off so that it can fall back to RCCL.
+
     One process per GPU; the buffers are exchanged as 64-byte IPC handles through ``torch.distributed`` (any backend)."""
 
-    def __init__(self, max_m: int, n_total: int, tp_size: int, rank: int, device, group=None):
+    FLAG_WORDS = 64   # per (parity, producer): include/mixq.h MIXQ_TP_FLAG_WORDS
+
+    def __init__(self, max_m: int, n_total: int, tp_size: int, rank: int, device, group=None, trap_on_timeout=False,
+                 patience_ms: int = 2000):
+        import os
         from . import _lib
         assert n_total % tp_size == 0 and (n_total // tp_size) % 8 == 0 and 1 < tp_size <= 8
         self.lib = _lib.load()
         self.dev = torch.device(device)
         self.M, self.N, self.tp, self.rank = int(max_m), int(n_total), int(tp_size), int(rank)
         self.n_loc = self.N // self.tp
+        self.trap, self.patience_ms = int(bool(trap_on_timeout)), int(patience_ms)
+        self.data_kind = os.environ.get("MIXQ_TP_DATA_MEM", "finegrained")
+        self.flag_kind = os.environ.get("MIXQ_TP_FLAG_MEM", "uncached")
         self.data_bytes = (self.M * self.N * 2 + 255) // 256 * 256
-        self.nbytes = self.data_bytes + 256                 # + the flag array (one word per producer)
+        self.flag_bytes = 2 * 8 * self.FLAG_WORDS * 4          # [parity][producer][FLAG_WORDS] uint32
         self.seq = 0
         self.own, handles = [], []
+
+        def alloc(nbytes, kind):
+            ptr = ctypes.c_void_p()
+            h = ctypes.create_string_buffer(64)
+            _lib.check(self.lib.mixq_tp_buffer_alloc(nbytes, _MEM_KINDS[kind], ctypes.byref(ptr), h),
+                       f"mixq_tp_buffer_alloc({kind})")
+            self.own.append(ptr.value)
+            handles.append(h.raw)
+
         with torch.cuda.device(self.dev):
-            for _ in range(2):
-                ptr = ctypes.c_void_p()
-                h = ctypes.create_string_buffer(64)
-                _lib.check(self.lib.mixq_tp_buffer_alloc(self.nbytes, ctypes.byref(ptr), h), "mixq_tp_buffer_alloc")
-                self.own.append(ptr.value)
-                handles.append(h.raw)
+            alloc(self.data_bytes, self.data_kind)
+            alloc(self.data_bytes, self.data_kind)
+            alloc(self.flag_bytes, self.flag_kind)
+            hp, dp = ctypes.c_void_p(), ctypes.c_void_p()
+            _lib.check(self.lib.mixq_tp_status_alloc(ctypes.byref(hp), ctypes.byref(dp)), "mixq_tp_status_alloc")
+        self._status_host_ptr, self._status_dev = hp.value, dp.value
+        self._status = (ctypes.c_uint32 * 16).from_address(hp.value)
         everyone = [None] * self.tp
         dist.all_gather_object(everyone, handles, group=group)
-        self.peer = [[None, None] for _ in range(self.tp)]  # [rank][parity] -> device pointer in THIS process
+        self.peer = [[None, None, None] for _ in range(self.tp)]  # [rank][data 0 | data 1 | flags] -> pointer in THIS process
         self._opened = []
         with torch.cuda.device(self.dev):
             for r in range(self.tp):
-                for par in range(2):
+                for which in range(3):
                     if r == self.rank:
-                        self.peer[r][par] = self.own[par]
+                        self.peer[r][which] = self.own[which]
                         continue
                     ptr = ctypes.c_void_p()
-                    buf = ctypes.create_string_buffer(everyone[r][par], 64)
+                    buf = ctypes.create_string_buffer(everyone[r][which], 64)
                     _lib.check(self.lib.mixq_tp_buffer_open(buf, ctypes.byref(ptr)), "mixq_tp_buffer_open")
-                    self.peer[r][par] = ptr.value
+                    self.peer[r][which] = ptr.value
                     self._opened.append(ptr.value)
-        self.views = [torch.as_tensor(_RawDeviceBuffer(p, self.nbytes), device=self.dev) for p in self.own]
-        self.small = torch.zeros(2, dtype=torch.int32, device=self.dev)   # [0] done counter, [1] time-out flag
+        self.views = [torch.as_tensor(_RawDeviceBuffer(p, self.data_bytes), device=self.dev) for p in self.own[:2]]
+        self.small = torch.zeros(self.FLAG_WORDS + 1, dtype=torch.int32, device=self.dev)   # [0] push counter, [1..] chunk counters
         dist.barrier(group=group)  # every rank has every buffer mapped before the first push
+
+    # flag words of producer `prod` in rank r's block of parity `par`
+    def _flag_ptr(self, r: int, par: int, prod: int) -> int:
+        return self.peer[r][2] + 4 * self.FLAG_WORDS * (8 * par + prod)
+
+    def check(self, sync: bool = False):
+        """Raises PeerGatherTimeout if any wait so far gave up.  sync=False reads the host-mapped status word as it is
+        (no device synchronisation: a failure of a call still in flight shows at the next check)."""
+        if sync:
+            torch.cuda.synchronize(self.dev)
+        if self._status[0] != 0:
+            raise PeerGatherTimeout(f"rank {self.rank}: a peer never published its flags for gather call "
+                                    f"{int(self._status[1])} (tp={self.tp}, N={self.N}); results from that call on are invalid")
+
+    def _begin(self, m: int):
+        assert m <= self.M
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("PeerGather.gather is not graph-capturable (host-side sequence number / buffer parity)")
+        self.check()
+        self.seq += 1
+        return self.seq & 1
+
+    def destinations(self, par: int):
+        """(bases, flags) ctypes arrays of this call: every rank's buffer of parity `par` and, in it, THIS producer's words."""
+        bases = (ctypes.c_void_p * self.tp)(*[self.peer[r][par] for r in range(self.tp)])
+        flags = (ctypes.c_void_p * self.tp)(*[self._flag_ptr(r, par, self.rank) for r in range(self.tp)])
+        return bases, flags
+
+    def _wait(self, par: int, nwords: int, st):
+        from . import _lib
+        _lib.check(self.lib.mixq_tp_wait(self._flag_ptr(self.rank, par, 0), self.tp, 0, nwords, self.seq,
+                                         self._status_dev, self.trap, self.patience_ms, st), "mixq_tp_wait")
+
+    def _view(self, par: int, m: int) -> torch.Tensor:
+        return self.views[par][: m * self.N * 2].view(torch.float16).view(m, self.N)
 
     def gather(self, x_local: torch.Tensor) -> torch.Tensor:
         """x_local fp16 [m, N/tp] (m <= max_m, contiguous) -> fp16 [m, N] view of this rank's buffer of the call's parity,
         valid on the current stream once the returned tensor's producer kernels (push + wait) have run."""
         assert x_local.is_cuda and x_local.dtype == torch.float16 and x_local.is_contiguous()
         m = x_local.numel() // self.n_loc
-        assert m <= self.M and x_local.shape[-1] == self.n_loc
+        assert x_local.shape[-1] == self.n_loc
         from . import _lib
-        self.seq += 1
-        par = self.seq & 1
+        par = self._begin(m)
         st = ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
-        bases = (ctypes.c_void_p * self.tp)(*[self.peer[r][par] for r in range(self.tp)])
-        flags = (ctypes.c_void_p * self.tp)(*[self.peer[r][par] + self.data_bytes + 4 * self.rank for r in range(self.tp)])
+        bases, flags = self.destinations(par)
         with torch.cuda.device(self.dev):
-            _lib.check(self.lib.mixq_tp_push_columns(x_local.data_ptr(), bases, flags, self.tp, m, self.n_loc, self.N,
-                                                     self.rank * self.n_loc, self.seq, self.small.data_ptr(), st),
-                       "mixq_tp_push_columns")
-            _lib.check(self.lib.mixq_tp_wait(self.own[par] + self.data_bytes, self.tp, self.seq,
-                                             self.small.data_ptr() + 4, st), "mixq_tp_wait")
-        return self.views[par][: m * self.N * 2].view(torch.float16).view(m, self.N)
+            _lib.check(self.lib.mixq_tp_push_columns(x_local.data_ptr() if m else None, bases, flags, self.tp, m,
+                                                     self.n_loc, self.N, self.rank * self.n_loc, self.seq, 1,
+                                                     self.small.data_ptr(), st), "mixq_tp_push_columns")
+            self._wait(par, 1, st)
+        return self._view(par, m)
 
     def timed_out(self) -> bool:
-        """True if a wait gave up (a peer never published): host-side check, synchronises the device."""
-        return bool(int(self.small[1].item()) != 0)
+        """True if a wait gave up (a peer never published): synchronises the device first."""
+        torch.cuda.synchronize(self.dev)
+        return bool(self._status[0] != 0)
 
     def close(self, group=None):
         torch.cuda.synchronize(self.dev)
@@ -168,4 +240,8 @@ class PeerGather:
             self.views = []
             for p in self.own:
                 self.lib.mixq_tp_buffer_free(ctypes.c_void_p(p))
+            if self._status_host_ptr:
+                self._status = None
+                self.lib.mixq_tp_status_free(ctypes.c_void_p(self._status_host_ptr))
+                self._status_host_ptr = None
         self._opened, self.own = [], []

@@ -170,6 +170,7 @@ class MixQLinear:
         self.bias = torch.zeros(self.out_features, dtype=dtype or torch.float16, device=dev) if bias else None
         self._plugin = None
         self.peer_gather = None   # optional parallel.PeerGather: one-sided peer writes instead of the RCCL all-gather
+        self.peer_gather_alias = False  # True: forward() returns a VIEW of the gather buffer (valid until two more gathers)
 
     def load(self, packed: dict):
         """Install the tensors produced by ``pack.pack_linear_weights`` (true dtypes) as fp16 carriers."""
@@ -206,7 +207,12 @@ class MixQLinear:
             # guarded by assert tp_size==1 upstream; the row-sharded operator needs ONE all-gather of the fp16 output.
             if self.peer_gather is not None:   # the block lands in its column block of every rank's [M, N] buffer
                 lead = x.shape[:-1]
+                # gather() raises PeerGatherTimeout (sticky, no device sync) if an earlier wait gave up on a peer
                 x = self.peer_gather.gather(x.reshape(-1, x.shape[-1])).reshape(*lead, self.out_features * self.tp_size)
+                if not self.peer_gather_alias:
+                    # the gathered tensor lives in one of TWO IPC buffers and is overwritten two gather calls later; a
+                    # caller that keeps it (residual, KV projection) gets its own copy unless it opted into the alias
+                    x = x.clone()
             else:
                 from .parallel import all_gather_columns
                 x = all_gather_columns(x, self.tp_group, self.tp_size)

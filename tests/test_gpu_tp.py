@@ -139,7 +139,7 @@ def _peer_worker(rank, world, port, tmp):
         pg = parallel.PeerGather(max_m, N, world, rank, "cuda:0")
         n_loc = N // world
         g = torch.Generator(device="cpu").manual_seed(100)          # same stream of numbers on both ranks
-        for call, m in enumerate([700, 33, 256, 1, 699, 700, 512, 8]):  # both parities, m < max_m, repeated sizes
+        for call, m in enumerate([700, 33, 256, 1, 0, 699, 700, 512, 0, 8]):  # both parities, m < max_m, EMPTY calls (flags still published)
             full = torch.randn((m, N), generator=g).to(torch.float16)
             mine = full[:, rank * n_loc:(rank + 1) * n_loc].contiguous().cuda()
             got = pg.gather(mine)
@@ -151,6 +151,21 @@ def _peer_worker(rank, world, port, tmp):
             ref = parallel.all_gather_columns(mine, None, world)
             ok &= torch.equal(ref.cpu(), full)
         ok &= not pg.timed_out()
+        pg.check(sync=True)
+        ok &= pg.data_kind == "finegrained" and pg.flag_kind == "uncached"   # what a remote GPU writes is never coarse-grained
+        # a capturing stream is refused (host-side sequence number / parity: a replay would read stale flags)
+        gr = torch.cuda.CUDAGraph()
+        refused = False
+        try:
+            with torch.cuda.graph(gr):
+                pg.gather(mine)
+        except RuntimeError as e:
+            refused = "not graph-capturable" in str(e)
+        except Exception:  # noqa: BLE001
+            pass
+        ok &= refused
+        if not refused:
+            notes.append("gather under graph capture was not refused")
         # through the layer: MixQLinear(tp_size=2, gather_output=True) with the peer transport == the gloo transport
         from mixq_tensorrt_llm_amd import plugin
         A, full_p = exact_fixture(64, 512, 512, 5)
@@ -161,6 +176,11 @@ def _peer_worker(rank, world, port, tmp):
         got = layer(torch.from_numpy(A).cuda())
         torch.cuda.synchronize()
         ok &= torch.equal(got.cpu(), want)
+        # the layer's result is the caller's own tensor, not a view of a buffer overwritten two calls later
+        got2 = layer(torch.from_numpy(A * 0.5).cuda())
+        got3 = layer(torch.from_numpy(A * 0.25).cuda())
+        torch.cuda.synchronize()
+        ok &= torch.equal(got.cpu(), want) and got.data_ptr() not in (got2.data_ptr(), got3.data_ptr())
         layer.peer_gather.close()
         pg.close()
     except Exception as e:  # noqa: BLE001
@@ -182,3 +202,83 @@ def test_peer_write_allgather_two_ranks_one_gpu(tmp_path, oracle):
     for r in range(world):
         res = open(tmp_path / f"peer{r}").read()
         assert res == "1", f"rank {r}: {res}"
+
+
+def _timeout_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mixq_tensorrt_llm_amd import parallel
+    ok, notes = True, []
+    try:
+        pg = parallel.PeerGather(64, 256, world, rank, "cuda:0", patience_ms=300)
+        x = torch.full((64, 128), float(rank + 1), dtype=torch.float16, device="cuda:0")
+        got = pg.gather(x)                       # call 1: both ranks -> fine
+        torch.cuda.synchronize()
+        pg.check()
+        ok &= bool((got[:, :128] == 1).all() and (got[:, 128:] == 2).all())
+        dist.barrier()
+        if rank == 0:                            # call 2: rank 1 never pushes -> rank 0's wait gives up after 300 ms
+            import time
+            t0 = time.perf_counter()
+            pg.gather(x)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            ok &= 0.25 < dt < 5.0
+            raised = 0
+            try:
+                pg.check()
+            except parallel.PeerGatherTimeout as e:
+                raised += "call 2" in str(e)
+            try:                                  # sticky: the next gather refuses on the host, without a device sync
+                pg.gather(x)
+            except parallel.PeerGatherTimeout:
+                raised += 1
+            ok &= raised == 2 and pg.timed_out()
+            if raised != 2:
+                notes.append(f"timeout not surfaced (raised={raised}, dt={dt:.2f})")
+        dist.barrier()
+        pg.close()
+    except Exception:  # noqa: BLE001
+        import traceback
+        ok = False
+        notes.append(traceback.format_exc())
+    open(os.path.join(tmp, f"to{rank}"), "w").write("1" if ok else "0\n" + "\n".join(notes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_lost_peer_surfaces_as_an_error_not_a_stale_tensor(tmp_path):
+    """VERDICT r2 / ADVICE r2: a wait that gives up must not leave a silently stale tensor behind -- the status word is
+    sticky, host-visible without a device sync, and every later gather / check raises."""
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_timeout_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        res = open(tmp_path / f"to{r}").read()
+        assert res == "1", f"rank {r}: {res}"
+
+
+def test_bench_self_launches_at_two_ranks(tmp_path):
+    """`python bench.py --gpus 2 ...` exactly as the driver types it (no torch.distributed.run in front, no WORLD_SIZE):
+    bench.py spawns its own ranks; rank 0 prints the ONE JSON line; the north-star layout (tp = 2) ran with a named
+    transport and no error.  Both ranks share the one GPU of the box (MIXQ_BENCH_SINGLE_GPU_RANKS=1: gloo for the
+    harness collectives) -- control flow, not a measurement."""
+    import json
+    import subprocess
+    env = dict(os.environ, MIXQ_BENCH_SINGLE_GPU_RANKS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--tokens", "16384", "--steps", "1",
+                        "--warmup", "1"], capture_output=True, text=True, env=env, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["config"]["parallelism"] == "dp2"
+    tp = rec["tp"]
+    assert "error" not in tp, tp
+    assert tp["world_size"] == 2 and tp["tp"] == 2 and tp["transport"] and tp["peer_wait_timed_out"] is False
+    assert tp["value"] > 0
