@@ -33,3 +33,59 @@ def oracle():
     import oracle as o
     o.build()
     return o
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Element-wise parity bounds ("1e-3 relative" normalised by the output's maximum lets small-magnitude outputs
+# be far off).  Everything on the hot path is exact except two things: fp32 accumulation order (unspecified in the
+# reference too: cuBLAS / CUTLASS) and the fp16 rounding of a sum that straddles a rounding boundary.  So, per ELEMENT:
+#   |got - want| <= ulp16(want)  [one fp16 rounding step, <= 2^-10 |want| < 1e-3 |want|]  +  order slack
+# where the order slack of the prefill operator is one ulp of the fp16-rounded outlier product P16 that enters the dequant
+# FMA (the only order-dependent quantity: the int8 part is exact), and that of the fp16 x int8 GEMV / GEMM is GAMMA x
+# sum_k |a_k w_k| (fp32 accumulation of K products in two different orders).
+def ulp16(x):
+    """Spacing of fp16 numbers at magnitude |x| (2^-24 below the normal range)."""
+    a = np.abs(np.asarray(x, np.float64))
+    _, e = np.frexp(np.maximum(a, 2.0 ** -14))     # a = m 2^e, m in [0.5, 1)
+    return np.ldexp(1.0, e - 11)
+
+
+def elementwise_violations(got, want, slack):
+    g, w = got.astype(np.float64), want.astype(np.float64)
+    bound = ulp16(np.maximum(np.abs(g), np.abs(w))) + slack
+    with np.errstate(invalid="ignore"):
+        d = np.abs(g - w)
+        bad = ~((d <= bound) | (np.isnan(g) & np.isnan(w)) | (g == w))
+    return bad, d, bound
+
+
+def assert_elementwise(got, want, slack, what=""):
+    bad, d, bound = elementwise_violations(got, want, slack)
+    if bad.any():
+        i = tuple(np.argwhere(bad)[0])
+        raise AssertionError(f"{what}: {int(bad.sum())} of {bad.size} outputs outside the element-wise bound; first at {i}: "
+                             f"got {got[i]!r} want {want[i]!r} |diff| {d[i]:.3e} bound {bound[i]:.3e}")
+
+
+def ulp_histogram(got, want):
+    """Fractions of outputs that differ from the oracle by 0, <= 1, <= 2 and > 2 fp16 ulps (of the larger magnitude)."""
+    g, w = got.astype(np.float64), want.astype(np.float64)
+    with np.errstate(invalid="ignore"):
+        u = np.abs(g - w) / ulp16(np.maximum(np.abs(g), np.abs(w)))
+    u = u[np.isfinite(u)]
+    return {"0": float(np.mean(u == 0)), "<=1": float(np.mean(u <= 1)), "<=2": float(np.mean(u <= 2)),
+            ">2": float(np.mean(u > 2)), "max": float(u.max()) if u.size else 0.0}
+
+
+W8A16_GAMMA = 4e-6   # fp32 accumulation of <= 28672 fp16 x fp16 products in two different orders, relative to sum |a w|
+
+
+def prefill_slack(parts):
+    """Order slack of the W8A8O16 operator: one ulp of the fp16-rounded outlier product (oracle.linear_prefill parts)."""
+    return ulp16(parts["P"])
+
+
+def w8a16_slack(A, q_rm, scale):
+    """Order slack of the fp16 x int8 paths: GAMMA x sum_k |a_k| |fp16(q_k s)|."""
+    wd = np.abs((q_rm.astype(np.float32) * scale.astype(np.float32)[None, :]).astype(np.float16).astype(np.float32))
+    return W8A16_GAMMA * (np.abs(A.astype(np.float32)) @ wd).astype(np.float64)

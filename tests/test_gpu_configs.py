@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, assert_elementwise, prefill_slack, ulp16 as ulp16_of, ulp_histogram, w8a16_slack
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
@@ -47,6 +47,8 @@ def test_config0_single_4096_linear_bs32_real_act_scales(oracle):
                                         return_parts=True)
     got = run_layer(A, p)
     assert rel_err(got, want) < REL_TOL
+    assert_elementwise(got, want, prefill_slack(parts), "config 0")
+    assert ulp_histogram(got, want)["<=1"] > 0.999
     ref = A.astype(np.float64) @ W.astype(np.float64).T
     assert rel_err(got, ref) < 0.05
 
@@ -61,8 +63,11 @@ def test_config1_llama2_7b_shapes(oracle, name, N, K):
     p = oracle.pack_linear_weights(W, act)
     assert p["fp_ind"].max() < 4096
     got = run_layer(A, p)
-    want = oracle.linear_prefill(A, p["weight"], p["weights_scaling_factor"], p["fp_weight"], p["fp_ind"])
+    want, parts = oracle.linear_prefill(A, p["weight"], p["weights_scaling_factor"], p["fp_weight"], p["fp_ind"],
+                                        return_parts=True)
     assert rel_err(got, want) < REL_TOL
+    assert_elementwise(got, want, prefill_slack(parts), f"config 1 {name}")
+    assert ulp_histogram(got, want)["<=1"] > 0.999
 
 
 @pytest.mark.parametrize("name,N,K,bias", [("qkv", 4608, 3584, True), ("gate", 18944, 3584, False),
@@ -82,10 +87,14 @@ def test_config3_qwen2_7b_fpA_intB_outliers(oracle, name, N, K, bias):
     assert np.array_equal(p["fp_weight"].view(np.uint16), want_fpw.view(np.uint16))
     b = (rng.standard_normal(N) * 0.1).astype(np.float16) if bias else None
     got = run_layer(A, p, b)
-    want = oracle.linear_prefill(A, p["weight"], p["weights_scaling_factor"], p["fp_weight"], p["fp_ind"])
-    if bias:
+    want, parts = oracle.linear_prefill(A, p["weight"], p["weights_scaling_factor"], p["fp_weight"], p["fp_ind"],
+                                        return_parts=True)
+    slack = prefill_slack(parts)
+    if bias:   # one more fp16 addition per element after the operator: a 1-ulp difference before it can move its result by
+        slack = slack + ulp16_of(want)  # one ulp of the un-biased value
         want = (want.astype(np.float16) + b[None, :]).astype(np.float16)
     assert rel_err(got, want) < REL_TOL
+    assert_elementwise(got, want, slack, f"config 3 {name}")
 
 
 @pytest.mark.parametrize("name,N,K", [("qkv/8", 1280, 8192), ("gate/8", 3584, 8192), ("proj/8", 1024, 28672)])
@@ -96,10 +105,58 @@ def test_config4_llama2_70b_tp8_shard_shapes(oracle, name, N, K):
     A, W = synth(48, N, K, act, K)
     p = oracle.pack_linear_weights(W, act)
     got = run_layer(A, p)
-    want = oracle.linear_prefill(A, p["weight"], p["weights_scaling_factor"], p["fp_weight"], p["fp_ind"])
+    want, parts = oracle.linear_prefill(A, p["weight"], p["weights_scaling_factor"], p["fp_weight"], p["fp_ind"],
+                                        return_parts=True)
     assert rel_err(got, want) < REL_TOL
+    assert_elementwise(got, want, prefill_slack(parts), f"config 4 {name}")
     # decode on the same shard (M = 2) through the interleaved qweight
     got2 = run_layer(A[:2], p)
     q_un = oracle.eetq_symmetric_quantize(W.T.copy())[0]
     want2 = oracle.w8a16_gemv(A[:2], q_un, p["weights_scaling_factor"])
     assert rel_err(got2, want2) < REL_TOL
+    assert_elementwise(got2, want2, w8a16_slack(A[:2], q_un, p["weights_scaling_factor"]), f"config 4 decode {name}")
+
+
+@pytest.mark.parametrize("name,N,K", [("qkv", 12288, 4096), ("proj", 4096, 11008)])
+def test_bench_configuration_at_full_size_on_sampled_rows(oracle, name, N, K):
+    """The BENCH configuration itself (configs[2]: 65536-token chunks of Llama-2-7B; VERDICT r2: only property-checked so
+    far): ONE mixq_enqueue at 65536 x N x K on bench.py's own synthetic data -- whole rounds of 256 x 256 tiles, the XCD
+    remap over 12288 / 4096 tiles -- against the oracle on 64 sampled rows (rows are independent: TsinghuaMixQPlugin.cpp:
+    518-532 never mixes tokens).  On those rows: qA, sA and the int32 accumulators of the full-size GEMM bit-exact, the fp16
+    output within the element-wise bound and the north-star 1e-3."""
+    import bench
+    from mixq_tensorrt_llm_amd import mixlib, plugin
+    M = 65536
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev).manual_seed(99 + N)
+    t = bench.synth_layer(N, K, dev, gen)
+    A = bench.synth_activation(M, K, t["ind_i32"], dev, gen)
+    rng = np.random.default_rng(N)
+    rows = np.unique(np.concatenate([[0, 1, 255, 256, 257, 32767, 32768, 65279, 65280, 65534, 65535],
+                                     rng.integers(0, M, 53)]))[:64]
+    ridx = torch.from_numpy(rows).to(dev)
+    # the operator through the plugin object (same call as bench.py: mixq_enqueue on a 65536-row chunk)
+    plug = plugin.MixQPlugin.create(M, N, K)
+    out = plug.enqueue([A, t["weight"], t["weights_scaling_factor"], t["fp_weight"], t["fp_ind"], t["qweight"],
+                        t["weights_scaling_factor"]])
+    torch.cuda.synchronize()
+    got = out[ridx].cpu().numpy()
+    W8 = t["weight"].view(torch.int8).reshape(N, K)
+    # oracle on the sampled rows
+    A_s = A[ridx].cpu().numpy()
+    want, parts = oracle.linear_prefill(A_s, W8.cpu().numpy(), t["weights_scaling_factor"].cpu().numpy(),
+                                        t["fp_weight"].cpu().numpy(), t["ind_i32"].cpu().numpy(), return_parts=True)
+    assert rel_err(got, want) < REL_TOL
+    assert_elementwise(got, want, prefill_slack(parts), f"bench configuration {name}")
+    h = ulp_histogram(got, want)
+    assert h["<=1"] > 0.995, h
+    # integer half of the path at full size: quantiser rows and the int32 accumulators of the 65536-row GEMM, bit for bit
+    sA = torch.empty(M, dtype=torch.float16, device=dev)
+    qA = mixlib.FindRowScale(A, sA, M, K, 8)
+    assert np.array_equal(qA[ridx].cpu().numpy(), parts["qA"])
+    assert np.array_equal(sA[ridx].cpu().numpy().view(np.uint16), parts["sA"].view(np.uint16))
+    acc = mixlib.gemm(qA, W8, M, N, K)          # int32 [65536, N]: the same ping-pong main loop, raw accumulators
+    torch.cuda.synchronize()
+    assert np.array_equal(acc[ridx].cpu().numpy(), parts["acc"])
+    del acc, out
+    torch.cuda.empty_cache()

@@ -9,7 +9,7 @@ import ctypes
 import numpy as np
 import pytest
 
-from conftest import make_layer
+from conftest import assert_elementwise, make_layer, prefill_slack, ulp_histogram, w8a16_slack
 
 pytestmark = pytest.mark.gpu
 
@@ -418,6 +418,10 @@ def test_enqueue_prefill_matches_oracle(oracle, M, N, K):
     assert rel_err(got, ref.astype(np.float32)) < 0.05
     mism = np.mean(bits(got) != bits(want))
     assert mism < 0.02, f"{mism:.4f} of outputs differ from the oracle by >= 1 fp16 ulp"
+    # element by element: one fp16 rounding step + one ulp of the outlier product (the only order-dependent quantity)
+    assert_elementwise(got, want, prefill_slack(parts), f"enqueue {M}x{N}x{K}")
+    h = ulp_histogram(got, want)
+    assert h["<=1"] > 0.999 and h[">2"] < 1e-4, h
 
 
 def test_enqueue_gemm_stage_is_bit_exact_given_oracle_side_product(oracle):
@@ -480,6 +484,7 @@ def test_enqueue_decode_path(oracle, M, N, K):
     q_un = oracle.eetq_symmetric_quantize(W.T.copy())[0]
     want = oracle.w8a16_gemv(A, q_un, p["weights_scaling_factor"])   # plugin reuses max/127 scales
     assert rel_err(got, want) < REL_TOL
+    assert_elementwise(got, want, w8a16_slack(A, q_un, p["weights_scaling_factor"]), f"decode {M}x{N}x{K}")
     ref_order = oracle.w8a16_gemv_reforder(A, q_un, p["weights_scaling_factor"])
     exact = A.astype(np.float64) @ (q_un.astype(np.float64) * p["weights_scaling_factor"].astype(np.float64))
     ref_vs_exact = rel_err(ref_order, exact.astype(np.float32))
@@ -504,6 +509,7 @@ def test_enqueue_decode_batches_both_routes(oracle, variant, route, M, N, K):
     q_un = oracle.eetq_symmetric_quantize(W.T.copy())[0]
     want = oracle.w8a16_gemv(A, q_un, p["weights_scaling_factor"])
     assert rel_err(got, want) < REL_TOL
+    assert_elementwise(got, want, w8a16_slack(A, q_un, p["weights_scaling_factor"]), f"decode route {route} {M}x{N}x{K}")
     ref_order = oracle.w8a16_gemv_reforder(A, q_un, p["weights_scaling_factor"])
     exact = A.astype(np.float64) @ (q_un.astype(np.float64) * p["weights_scaling_factor"].astype(np.float64))
     ref_vs_exact = rel_err(ref_order, exact.astype(np.float32))
