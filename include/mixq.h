@@ -305,6 +305,31 @@ MIXQ_API int mixq_tp_push_columns(const void* src, void* const* dst_bases, void*
 MIXQ_API int mixq_tp_wait(const void* flags, int nprod, int word0, int nwords, uint32_t seq, void* status_dev,
                           int trap_on_timeout, uint32_t patience_ms, void* stream);
 
+/* The same all-gather FUSED INTO THE OPERATOR (round 3): mixq_enqueue's prefill path with the GEMM's store path writing
+ * every finished block straight into this rank's column block [col0, col0 + N_local) of all ndst destination buffers
+ * ([M, n_total] fp16, own rank included) -- no [M, N_local] output, no push launch, no second read of the block; the
+ * transfer runs under the GEMM.  Flag words: the M rows are cut into mixq_tp_flag_words(M) chunks (<= 64; whole groups of
+ * 256-row tile rows in the kernel's walk order) and word c of dst_flags[r] receives `seq` when the last tile of chunk c
+ * has been acknowledged by every destination, so a consumer may start on chunk c (mixq_tp_wait word0 = c) while later
+ * chunks are still being computed; waiting for words [0, mixq_tp_flag_words(M)) waits for the whole tensor.
+ * counters: MIXQ_TP_FLAG_WORDS zeroed device words of this rank (left zero).  inputs / inputDesc / workspace as
+ * mixq_enqueue (inputs[5], [6] unused).  Only shapes that take the plain 256 x 256 ping-pong kernel are served
+ * (mixq_tp_fused_supported); others return MIXQ_E_SHAPE before anything is launched: use mixq_enqueue +
+ * mixq_tp_push_columns.  Cannot be timed on one GPU (the 2-process IPC test covers the protocol, not xGMI). */
+typedef struct mixq_tp_epilogue {
+    int32_t ndst;          /* destinations, 1..8 */
+    int32_t n_total;       /* row stride of every destination in elements */
+    int32_t col0;          /* this rank's first column */
+    uint32_t seq;          /* sequence number of the call */
+    void* dst_bases[8];    /* [M, n_total] fp16 buffers (fine-grained / uncached: mixq_tp_buffer_alloc) */
+    void* dst_flags[8];    /* this producer's MIXQ_TP_FLAG_WORDS flag words in each destination */
+    void* counters;        /* MIXQ_TP_FLAG_WORDS zeroed uint32 of this rank */
+} mixq_tp_epilogue;
+MIXQ_API int mixq_tp_fused_supported(int64_t M, int64_t N_local, int64_t K);
+MIXQ_API int mixq_tp_flag_words(int64_t M);
+MIXQ_API int mixq_enqueue_tp(const mixq_handle* h, const mixq_tensor_desc* inputDesc, const void* const* inputs,
+                             void* workspace, const mixq_tp_epilogue* tp, void* stream);
+
 /* ---- host helpers ----------------------------------------------------------------------------- */
 /* preprocess_weights (weightonlykernel/cutlass_kernels/cutlass_preprocessors.cc:536-545), int8, arch 80-90:
  * row-major int8 [rows=K, cols=N] -> interleaved uint8.  Host memory.  And its inverse. */

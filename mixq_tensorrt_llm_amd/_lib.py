@@ -43,6 +43,12 @@ class TensorDesc(ctypes.Structure):
         return t
 
 
+class TpEpilogue(ctypes.Structure):
+    """include/mixq.h: mixq_tp_epilogue."""
+    _fields_ = [("ndst", ctypes.c_int32), ("n_total", ctypes.c_int32), ("col0", ctypes.c_int32), ("seq", ctypes.c_uint32),
+                ("dst_bases", ctypes.c_void_p * 8), ("dst_flags", ctypes.c_void_p * 8), ("counters", ctypes.c_void_p)]
+
+
 class PluginField(ctypes.Structure):
     _fields_ = [("name", ctypes.c_char_p), ("data", ctypes.c_void_p), ("type", ctypes.c_int32),
                 ("length", ctypes.c_int32)]
@@ -120,6 +126,9 @@ SIGNATURES = {
     "mixq_tp_push_columns": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i, _i, _i, _i, _i, ctypes.c_uint32, _i,
                                   _vp, _vp]),
     "mixq_tp_wait": (_i, [_vp, _i, _i, _i, ctypes.c_uint32, _vp, _i, ctypes.c_uint32, _vp]),
+    "mixq_tp_fused_supported": (_i, [_i64, _i64, _i64]),
+    "mixq_tp_flag_words": (_i, [_i64]),
+    "mixq_enqueue_tp": (_i, [_vp, ctypes.POINTER(TensorDesc), ctypes.POINTER(_vp), _vp, ctypes.POINTER(TpEpilogue), _vp]),
     "mixq_preprocess_weights_int8": (_i, [_vp, _vp, _sz, _sz]),
     "mixq_unprocess_weights_int8": (_i, [_vp, _vp, _sz, _sz]),
     "mixq_debug_set_gemm_variant": (None, [_i]),

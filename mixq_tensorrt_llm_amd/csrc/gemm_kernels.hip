@@ -627,6 +627,17 @@ static std::atomic<const char*> g_last_kernel{"none"}; // reporting only (bench.
 const char* last_gemm_kernel() { return g_last_kernel.load(std::memory_order_relaxed); }
 void note_gemm_kernel(const char* name) { g_last_kernel.store(name, std::memory_order_relaxed); }
 
+// The peer-write epilogue exists for the plain 256 x 256 ping-pong kernel: exactly the shapes for which launch_gemm below
+// (automatic selection, no scratch-dependent form) ends up there.
+bool gemm_tp_fused_supported(int M, int N, int K, int O)
+{
+    if (M <= 128 || N <= 0 || K <= 0 || O < 0 || O > 128 || gemm_variant() != 0) return false;
+    if (gemm_pp128_wins(M, N, K) || gemm_splitk_factor(M, N, K) != 0) return false;
+    const int64_t tiles256 = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
+    const int64_t wg64 = (int64_t)((M + 63) / 64) * ((N + 63) / 64);
+    return tiles256 >= 96 && wg64 > 768;
+}
+
 hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st)
 {
     if (p.M <= 0 || p.N <= 0) return hipSuccess;

@@ -99,9 +99,14 @@ __device__ __forceinline__ void wait_vmcnt()
 //   * The last arriver, after finishing its own share, finishes every DEFERRED share too: all S partial sums of such a
 //     share are in the scratch by then.  Every share is finished exactly once, by its owner or by the last arriver.
 // The last workgroup of a group to be done with the words re-arms them for the next launch.
-template <int EPI, bool HAS_O, bool HAS_Y, int ABL = 0, int SPLITK = 0>
+// TP = true (EPI_DEQUANT, no K split): the store path writes every finished block into this rank's column block of ALL
+// p.tp.ndst destination buffers (row stride p.tp.ldd) with system-scope write-through stores instead of into p.D, and the
+// last tile of an M chunk to be acknowledged publishes p.tp.seq in the chunk's flag word of every destination (TpEpilogue,
+// mixq_launch.h; protocol in tp_kernels.hip).
+template <int EPI, bool HAS_O, bool HAS_Y, int ABL = 0, int SPLITK = 0, bool TP = false>
 __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p)
 {
+    static_assert(!TP || (SPLITK == 0 && EPI == EPI_DEQUANT && ABL == 0), "the peer-write epilogue exists for the plain kernel");
     constexpr int S = SPLITK ? SPLITK : 1; // workgroups per tile
     constexpr int PJ = S >= 4 ? 1 : 4 / S; // 32-row m tiles (per wave) this workgroup finishes
     constexpr int NI = S == 8 ? 1 : 2;     // 32-column n tiles (per wave) it finishes: S = 8 splits the n pair as well
@@ -679,6 +684,9 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
     const int rd = (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4); // window read offset (rr & 7 == lane >> 3)
     const bool n_ok = n0 + wn * 64 + (lane & 7) * 8 < p.N;
     const bool interior = m0 + BM <= p.M && n0 + BN <= p.N; // wave-uniform: no store predicates needed
+    // TP: the same 128-byte row segments, once per destination, into [M, ldd] buffers (wave-uniform base per destination)
+    const int64_t tp_wave = TP ? ((int64_t)(m0 + wm * 128) * p.tp.ldd + n0 + wn * 64) * 2 : 0;
+    const unsigned tp_lane = TP ? ((unsigned)(lane >> 3) * (unsigned)p.tp.ldd + (lane & 7) * 8) * 2 : 0u;
     auto flush = [&](int j) __attribute__((always_inline)) {
         uint4 v[4];
 #pragma unroll
@@ -690,6 +698,17 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
         for (int q = 0; q < 4; ++q) {
             if (q & 1) v[q] = uint4{v[q].z, v[q].w, v[q].x, v[q].y}; // rows with bit 3 set hold their 8-B halves swapped
             const int row = jmap(j) * 32 + q * 8;     // wave-uniform
+            if constexpr (TP) {
+                const bool ok = interior || (n_ok && m0 + wm * 128 + row + (lane >> 3) < p.M);
+                const v4i val = {(int)v[q].x, (int)v[q].y, (int)v[q].z, (int)v[q].w};
+                for (int r = 0; r < p.tp.ndst; ++r) { // (uniform trip count; bases are scalars)
+                    char* dst = static_cast<char*>(p.tp.base[r]) + tp_wave + (int64_t)row * p.tp.ldd * 2 + tp_lane;
+                    // write-through at system scope: acknowledged = performed at the destination (local HBM or a peer's
+                    // over xGMI); no L2 write-back fence is needed before the flag (tp_kernels.hip)
+                    if (ok) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(val) : "memory");
+                }
+                continue;
+            }
             char* dst = dwave + (int64_t)row * p.N * 2 + dlane;
             if (interior) *reinterpret_cast<uint4*>(dst) = v[q];
             else if (n_ok && m0 + wm * 128 + row + (lane >> 3) < p.M) *reinterpret_cast<uint4*>(dst) = v[q];
@@ -719,6 +738,22 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
     }
     };
     epilogue();
+    if constexpr (TP) {
+        // every wave's peer stores acknowledged -> count this tile into its M chunk; the chunk's last tile publishes
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            const int ctr = p.tp.chunk_tile_rows;
+            const int chunk = tile_m / ctr;
+            const int rows_here = min(ctr, tiles_m - chunk * ctr);
+            const unsigned before = __hip_atomic_fetch_add(p.tp.counters + chunk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (before == (unsigned)(rows_here * tiles_n) - 1u) {
+                __hip_atomic_store(p.tp.counters + chunk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // re-armed
+                for (int r = 0; r < p.tp.ndst; ++r)
+                    __hip_atomic_store(p.tp.flag[r] + chunk, p.tp.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
     // ---- last arriver only: the shares whose owners deferred.  All S partial sums of such a share are parked (share
     // w ^ erank of workgroup w; share 0 = the owner's own); the epilogue runs once more with that rank's tile mapping.
     if (SPLITK && !solo && todo != 0u) {
@@ -787,6 +822,38 @@ static hipError_t launch_pp_cfg(const GemmParams& p, hipStream_t st)
 }
 
 hipError_t launch_gemm_f16_pp(const void* A, const void* B, void* D, int M, int N, int K, const void* zeros, hipStream_t st);
+
+// ---- peer-write epilogue (TpEpilogue) --------------------------------------------------------------------------------
+int tp_chunk_tile_rows(int M)
+{
+    const int tiles_m = (M + pp::BM - 1) / pp::BM;
+    const int groups = (tiles_m + 3) / 4;                        // the kernel walks the tile rows in groups of GROUP_M = 4
+    return 4 * ((groups + kTpFlagWords - 1) / kTpFlagWords);     // whole groups per flag word, at most kTpFlagWords words
+}
+int tp_flag_words(int M)
+{
+    const int tiles_m = (M + pp::BM - 1) / pp::BM, c = tp_chunk_tile_rows(M);
+    return M <= 0 ? 1 : (tiles_m + c - 1) / c;
+}
+template <bool HAS_O>
+static hipError_t launch_pp_tp_cfg(const GemmParams& p, hipStream_t st)
+{
+    constexpr size_t lds = 2 * (size_t)pp::BUF + 32768;
+    auto kern = gemm_w8a8o16_pp_kernel<EPI_DEQUANT, HAS_O, false, 0, 0, true>;
+    static DeviceOnce once;
+    if (hipError_t e = ensure_dynamic_lds(kern, lds, once); e != hipSuccess) return e;
+    const int tiles = ((p.M + pp::BM - 1) / pp::BM) * ((p.N + pp::BN - 1) / pp::BN);
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(pp::T), lds, st, p);
+    return hipGetLastError();
+}
+hipError_t launch_gemm_pp_tp(const GemmParams& p_in, hipStream_t st)
+{
+    if (p_in.tp.ndst < 1 || p_in.tp.ndst > kTpMaxPeers || p_in.Y != nullptr || p_in.M <= 0 || p_in.N <= 0) return hipErrorInvalidValue;
+    GemmParams p = p_in;
+    p.tp.chunk_tile_rows = tp_chunk_tile_rows(p.M);
+    note_gemm_kernel("gemm_w8a8o16_pp_kernel<TP> (256x256 ping-pong, peer-write epilogue)");
+    return p.O > 0 ? launch_pp_tp_cfg<true>(p, st) : launch_pp_tp_cfg<false>(p, st);
+}
 
 template <int EPI>
 static hipError_t launch_pp_epi(const GemmParams& p, hipStream_t st)

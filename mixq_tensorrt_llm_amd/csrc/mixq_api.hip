@@ -706,6 +706,61 @@ int mixq_enqueue_profiled(const mixq_handle* h, const mixq_tensor_desc* inputDes
 }
 
 // ------------------------------------------------------------------------------ multi-GPU ----
+int mixq_tp_fused_supported(int64_t M, int64_t N_local, int64_t K)
+{
+    if (M <= 0 || N_local <= 0 || K <= 0 || M > INT32_MAX || N_local > INT32_MAX || K > INT32_MAX) return 0;
+    return mixq::gemm_tp_fused_supported((int)M, (int)N_local, (int)K, kNumOutliers) ? 1 : 0;
+}
+
+int mixq_tp_flag_words(int64_t M) { return M > 0 && M <= INT32_MAX ? mixq::tp_flag_words((int)M) : 1; }
+
+int mixq_enqueue_tp(const mixq_handle* h, const mixq_tensor_desc* inputDesc, const void* const* inputs, void* workspace,
+                    const mixq_tp_epilogue* tp, void* stream)
+{
+    if (!h || !inputDesc || !inputs || !tp) return MIXQ_E_BADARG;
+    const mixq_tensor_desc& a = inputDesc[0];
+    if (a.nbDims < 1 || a.nbDims > MIXQ_MAX_DIMS || inputDesc[1].nbDims < 1) return MIXQ_E_BADARG;
+    int64_t M = 1;
+    for (int i = 0; i < a.nbDims - 1; ++i) M *= a.d[i];
+    const int64_t K = a.d[a.nbDims - 1], N = inputDesc[1].d[0];
+    if (M <= 0 || K <= 0 || N <= 0 || M > INT32_MAX || K > INT32_MAX || N > INT32_MAX) return MIXQ_E_BADARG;
+    if (tp->ndst < 1 || tp->ndst > mixq::kTpMaxPeers || tp->n_total <= 0 || tp->col0 < 0 || tp->col0 + N > tp->n_total ||
+        !tp->counters)
+        return MIXQ_E_BADARG;
+    if (tp->n_total % 8 || tp->col0 % 8 || N % 16 || K % 16) return MIXQ_E_SHAPE;
+    if (!mixq::gemm_tp_fused_supported((int)M, (int)N, (int)K, kNumOutliers)) return MIXQ_E_SHAPE; // caller: enqueue + push
+    for (int i = 0; i < 5; ++i)
+        if (!inputs[i]) return MIXQ_E_BADARG;
+    if (!workspace) return MIXQ_E_WORKSPACE;
+    if (!aligned16(inputs[0]) || !aligned16(inputs[1]) || !aligned16(inputs[2]) || !aligned16(inputs[3])) return MIXQ_E_ALIGN;
+    uintptr_t base = align_up(reinterpret_cast<uintptr_t>(workspace), kWorkspaceAlign);
+    int8_t* qA = reinterpret_cast<int8_t*>(base);
+    base = align_up(base + (size_t)M * (size_t)K, kWorkspaceAlign);
+    void* sA = reinterpret_cast<void*>(base);
+    base = align_up(base + (size_t)M * sizeof(uint16_t), kWorkspaceAlign);
+    void* fpA = reinterpret_cast<void*>(base);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    mixq::GemmParams p{};
+    p.A = qA, p.B = static_cast<const int8_t*>(inputs[1]);
+    p.sA = static_cast<const uint16_t*>(sA), p.sW = static_cast<const uint16_t*>(inputs[2]);
+    p.fpA = static_cast<const uint16_t*>(fpA), p.fpW = static_cast<const uint16_t*>(inputs[3]);
+    p.O = kNumOutliers, p.M = (int)M, p.N = (int)N, p.K = (int)K;
+    p.zeros = mixq::zero_page();
+    if (!p.zeros) return MIXQ_E_HIP;
+    p.tp.ndst = tp->ndst, p.tp.ldd = tp->n_total, p.tp.seq = tp->seq;
+    p.tp.counters = static_cast<unsigned*>(tp->counters);
+    for (int r = 0; r < tp->ndst; ++r) {
+        if (!tp->dst_bases[r] || !tp->dst_flags[r] || !aligned16(tp->dst_bases[r])) return MIXQ_E_BADARG;
+        p.tp.base[r] = static_cast<char*>(tp->dst_bases[r]) + (size_t)tp->col0 * sizeof(uint16_t);
+        p.tp.flag[r] = static_cast<unsigned*>(tp->dst_flags[r]);
+    }
+    int rc = hip_rc(mixq::launch_quant_extract(const_cast<void*>(inputs[0]), qA, sA, fpA, static_cast<const int32_t*>(inputs[4]),
+                                               (int)M, (int)K, kNumOutliers, false, st, nullptr));
+    if (rc != MIXQ_OK) return rc;
+    return hip_rc(mixq::launch_gemm_pp_tp(p, st));
+}
+
+
 int mixq_tp_buffer_alloc(size_t bytes, int mem_kind, void** dev_ptr, void* ipc_handle_64)
 {
     if (!dev_ptr || !ipc_handle_64 || bytes == 0) return MIXQ_E_BADARG;

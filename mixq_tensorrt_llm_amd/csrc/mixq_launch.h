@@ -40,6 +40,26 @@ enum { EPI_DEQUANT = 0, EPI_DEQUANT_SILU = 1, EPI_INT32 = 2, EPI_DEQUANT_SILU_MU
                           // with v_mfma_f32_32x32x16_f16 (second pass of the two-pass fpA_intB GEMM, w8a16_gemm_kernels.hip)
 constexpr bool epi_has_silu(int epi) { return epi == EPI_DEQUANT_SILU || epi == EPI_DEQUANT_SILU_MUL; }
 
+// TP all-gather fused into the GEMM's store path (gemm_pp_kernels.hip, TP = true): every finished 32-row block of a wave
+// tile is written straight into this rank's column block of EVERY destination's [M, n_total] buffer (one-sided peer writes
+// over xGMI, write-through at system scope), and when the last tile of an M chunk (`chunk_tile_rows` rows of 256 x 256
+// tiles) has been acknowledged the chunk's flag word in every destination receives `seq`.  No separate push launch, no
+// second read of the [M, N/tp] block, and the transfer runs under the GEMM itself.
+constexpr int kTpMaxPeers = 8;
+constexpr int kTpFlagWords = 64; // flag words per (parity, producer): word 0 = stand-alone push, one per M chunk when fused
+struct TpEpilogue {
+    int ndst;                      // 0: off
+    int ldd;                       // row stride of every destination in elements (= n_total)
+    void* base[kTpMaxPeers];       // destination r's [M, n_total] fp16 buffer + this rank's column offset
+    unsigned* flag[kTpMaxPeers];   // this producer's kTpFlagWords flag words in destination r
+    unsigned seq;
+    unsigned* counters;            // this rank's per-chunk tile counters (kTpFlagWords words, zero; left zero)
+    int chunk_tile_rows;           // tile rows (of 256 rows) per flag word
+};
+int tp_chunk_tile_rows(int M);     // tile rows per flag word for an M-row call: a multiple of the kernel's GROUP_M walk
+int tp_flag_words(int M);          // flag words a consumer must wait for = ceil(tile rows / chunk_tile_rows) <= kTpFlagWords
+bool gemm_tp_fused_supported(int M, int N, int K, int O); // launch_gemm would take the plain 256 x 256 ping-pong kernel
+
 struct GemmParams {
     const int8_t* A;      // qA [M,K]
     const int8_t* B;      // W  [N,K]
@@ -57,6 +77,7 @@ struct GemmParams {
     int splitk_solo;      // (set by launch_gemm_pp_splitk) leading tiles that are not split
     unsigned splitk_patience; // (set by launch_gemm_pp_splitk) wall-clock ticks a workgroup waits for its partners before
                               // it defers its share to the last arriver
+    TpEpilogue tp;        // (launch_gemm_pp_tp only) peer-write epilogue, else ndst == 0
     void* splitk_ws;      // device scratch of gemm_splitk_workspace_size bytes whose arrival words are zero, or null: lets
                           // launch_gemm split K over 2 / 4 workgroups per 256x256 tile when the tiles alone cover at
                           // most half / a quarter of the CUs (gemm_pp_kernels.hip)
@@ -65,6 +86,7 @@ struct GemmParams {
 hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st);
 hipError_t launch_gemm_pp(const GemmParams& p, int epi, hipStream_t st);  // 256x256 ping-pong schedule
 hipError_t launch_gemm_pp128(const GemmParams& p, int epi, hipStream_t st);
+hipError_t launch_gemm_pp_tp(const GemmParams& p, hipStream_t st); // EPI_DEQUANT with p.tp.ndst destinations instead of p.D
 // D[M,N] fp16 = A[M,K] B[N,K]^T, fp16 operands (K % 8 == 0, N % 8 == 0, 16-byte aligned rows), fp32 accumulation
 hipError_t launch_gemm_f16_pp(const void* A, const void* B, void* D, int M, int N, int K, const void* zeros, hipStream_t st);
 hipError_t launch_gemm_f16_pp128(const void* A, const void* B, void* D, int M, int N, int K, const void* zeros, hipStream_t st); // 128 x 256 tiles // 128x256 ping-pong schedule (mid-size problems)
@@ -129,8 +151,6 @@ hipError_t launch_w8a16(const void* A, const uint8_t* Wq, const void* scale, voi
 
 void note_gemm_kernel(const char* name);
 // TP all-gather of the output columns as one-sided peer writes + flags (tp_kernels.hip)
-constexpr int kTpMaxPeers = 8;
-constexpr int kTpFlagWords = 64; // flag words per (parity, producer): word 0 = stand-alone push, one per M chunk when fused
 hipError_t launch_tp_push(const void* src, void* const* dst_bases, unsigned* const* dst_flags, int ndst, int M, int n_loc,
                           int N, int col0, unsigned seq, int nflags, unsigned* done_counter, hipStream_t st);
 hipError_t launch_tp_wait(const unsigned* flags, int nprod, int word0, int nwords, unsigned seq, unsigned* status, int trap,

@@ -226,6 +226,37 @@ class PeerGather:
             self._wait(par, 1, st)
         return self._view(par, m)
 
+    def enqueue_gather(self, plug, inputs, workspace=None):
+        """The operator AND its all-gather in one pass (``mixq_enqueue_tp``): the GEMM's store path writes this rank's
+        column block straight into every rank's buffer, chunk flags are published as the M chunks retire -- no
+        [m, N/tp] output, no push launch, no second read.  ``plug``: plugin.MixQPlugin of the shard; ``inputs``: the 7
+        carriers of ``MixQPlugin.enqueue``.  Returns the gathered fp16 [m, N] view, or None when the shape does not take
+        the 256 x 256 ping-pong kernel (caller: ``plug.enqueue`` + ``gather``)."""
+        from . import _lib
+        A = inputs[0]
+        K = A.shape[-1]
+        m = A.numel() // K
+        assert inputs[1].shape[0] == self.n_loc and A.is_cuda and A.is_contiguous()
+        if not self.lib.mixq_tp_fused_supported(m, self.n_loc, K):
+            return None
+        par = self._begin(m)
+        st = ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+        tp = _lib.TpEpilogue()
+        tp.ndst, tp.n_total, tp.col0, tp.seq = self.tp, self.N, self.rank * self.n_loc, self.seq
+        for r in range(self.tp):
+            tp.dst_bases[r] = self.peer[r][par]
+            tp.dst_flags[r] = self._flag_ptr(r, par, self.rank)
+        tp.counters = self.small.data_ptr() + 4
+        in_desc = (_lib.TensorDesc * 7)(*[_lib.TensorDesc.make(t.shape) for t in inputs])
+        in_ptrs = (ctypes.c_void_p * 7)(*[t.data_ptr() for t in inputs])
+        if workspace is None:
+            workspace = plug._workspace(A.device, plug.workspace_size(max(m, 1), self.n_loc, K))
+        with torch.cuda.device(self.dev):
+            _lib.check(self.lib.mixq_enqueue_tp(plug._h, in_desc, in_ptrs, ctypes.c_void_p(workspace.data_ptr()),
+                                                ctypes.byref(tp), st), "mixq_enqueue_tp")
+            self._wait(par, int(self.lib.mixq_tp_flag_words(m)), st)
+        return self._view(par, m)
+
     def timed_out(self) -> bool:
         """True if a wait gave up (a peer never published): synchronises the device first."""
         torch.cuda.synchronize(self.dev)

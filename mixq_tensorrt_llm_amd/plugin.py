@@ -195,6 +195,16 @@ class MixQLinear:
     def forward(self, A: torch.Tensor) -> torch.Tensor:
         if self._plugin is None:
             self._plugin = MixQPlugin.create(A.shape[0], self.out_features, self.in_features)
+        if self.tp_size > 1 and self.gather_output and self.peer_gather is not None and self.bias is None:
+            # operator + all-gather in one pass: the GEMM's store path writes this rank's column block into every rank's
+            # buffer (mixq_enqueue_tp); shapes that do not take the 256 x 256 ping-pong kernel fall through to
+            # enqueue + push below
+            g = self.peer_gather.enqueue_gather(self._plugin, [A.contiguous(), self.weight, self.weights_scaling_factor,
+                                                               self.fp_weight, self.fp_ind, self.qweight,
+                                                               self.weights_scaling_factor])
+            if g is not None:
+                g = g.reshape(*A.shape[:-1], self.out_features * self.tp_size)
+                return g if self.peer_gather_alias else g.clone()
         x = self._plugin.enqueue([A, self.weight, self.weights_scaling_factor, self.fp_weight, self.fp_ind,
                                   self.qweight, self.weights_scaling_factor])   # plugin.py:141-151
         if self.bias is not None:

@@ -282,3 +282,67 @@ def test_bench_self_launches_at_two_ranks(tmp_path):
     assert "error" not in tp, tp
     assert tp["world_size"] == 2 and tp["tp"] == 2 and tp["transport"] and tp["peer_wait_timed_out"] is False
     assert tp["value"] > 0
+
+
+def _fused_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from mixq_tensorrt_llm_amd import _lib, parallel, plugin
+    lib = _lib.load()
+    ok, notes = True, []
+    try:
+        # (M, N, K): per-rank shards of 6144 / 4096 columns that take the plain 256 x 256 ping-pong kernel; ragged last
+        # tile row (2000), many flag words (M = 17000 -> 67 tile rows -> 4-row chunks -> 17 words)
+        for M, N, K in ((2048, 12288, 512), (2000, 12288, 256), (17000, 8192, 256)):
+            A, full = exact_fixture(M, N, K, 11 + M)
+            mine = parallel.shard_packed(full, world, rank)
+            assert lib.mixq_tp_fused_supported(M, N // world, K) == 1, (M, N, K)
+            want = oracle.linear_prefill(A, full["weight"], full["weights_scaling_factor"], full["fp_weight"], full["fp_ind"])
+            layer = plugin.MixQLinear(K, N, bias=False, tp_size=world, gather_output=True, device="cuda:0").load(mine)
+            layer.peer_gather = parallel.PeerGather(M, N, world, rank, "cuda:0")
+            Ad = torch.from_numpy(A).cuda()
+            for call in range(3):                      # both buffer parities, flags / counters re-armed
+                got = layer(Ad)
+                torch.cuda.synchronize()
+                layer.peer_gather.check()
+                kern = lib.mixq_debug_last_gemm_kernel().decode()
+                if "peer-write epilogue" not in kern:
+                    ok = False
+                    notes.append(f"{M}x{N}x{K}: fused path not taken ({kern})")
+                if not np.array_equal(got.cpu().numpy().view(np.uint16), want.view(np.uint16)):
+                    ok = False
+                    notes.append(f"{M}x{N}x{K} call {call}: gathered output differs from the unsharded oracle")
+            words = lib.mixq_tp_flag_words(M)
+            ok &= (words == 17) if M == 17000 else (words == 2)
+            ok &= int(layer.peer_gather.small.abs().sum()) == 0          # counters left zero
+            # unsupported shape (few tiles): the same layer object falls back to enqueue + push, same contract
+            small = layer(Ad[:40])
+            torch.cuda.synchronize()
+            ok &= np.array_equal(small.cpu().numpy().view(np.uint16), want[:40].view(np.uint16))
+            layer.peer_gather.close()
+            dist.barrier()
+    except Exception:  # noqa: BLE001
+        import traceback
+        ok = False
+        notes.append(traceback.format_exc())
+    open(os.path.join(tmp, f"fused{rank}"), "w").write("1" if ok else "0\n" + "\n".join(notes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_allgather_fused_into_the_gemm_epilogue_two_ranks_one_gpu(tmp_path, oracle):
+    """the peer writes issued from the GEMM's own store path (mixq_enqueue_tp), chunk flags published
+    as the M chunks retire; two processes on the one GPU (IPC-mapped fine-grained buffers), MixQLinear(tp_size=2)
+    bit-exact against the UNSHARDED oracle on the exact fixture, ragged M, several flag words, three calls per shape.
+    Cannot be timed here: both 'GPUs' are the same device."""
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_fused_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        res = open(tmp_path / f"fused{r}").read()
+        assert res == "1", f"rank {r}: {res}"
