@@ -248,6 +248,7 @@ class Model:
         self.workspace = torch.empty(max_ws, dtype=torch.uint8, device=dev)
         self.ws_ptr = ctypes.c_void_p(self.workspace.data_ptr())
         self.gatherers = {}    # N -> parallel.PeerGather (tp > 1, peer-write transport)
+        self.fused = {}        # (n_loc, K) -> True: the all-gather rides in the GEMM's store path (mixq_enqueue_tp)
         self.transport = None
         self.n_call = 0
         self.gather_done = [None, None]   # event of the last gather that READ output buffer 0 / 1
@@ -268,14 +269,35 @@ class Model:
                 want = torch.arange(1, self.tp + 1, dtype=torch.float16, device=self.dev).repeat_interleave(N // self.tp)
                 if g.timed_out() or not torch.equal(got, want.expand(64, N)):
                     raise RuntimeError(f"peer-write self-test failed for N={N} (timed out: {g.timed_out()})")
+            # second self-test: the all-gather FUSED into the GEMM's store path (mixq_enqueue_tp) must give the same tensor
+            # as operator + push on the first call of every shape that supports it
+            self.fused = {}
+            for (h, in_desc, out_desc, in_ptrs_list, out_ptrs, n_loc, K, outs, N) in self.calls[:3]:
+                if not self.lib.mixq_tp_fused_supported(self.chunk, n_loc, K):
+                    continue
+                g = self.gatherers[N]
+                st = ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+                rc = self.lib.mixq_enqueue(h, in_desc, ctypes.byref(out_desc), in_ptrs_list[0], out_ptrs[0], self.ws_ptr, st)
+                assert rc == 0
+                ref = g.gather(outs[0])
+                got = g.enqueue_gather_raw(h, in_desc, in_ptrs_list[0], self.ws_ptr, self.chunk, K)
+                torch.cuda.synchronize(self.dev)
+                if g.timed_out() or not torch.equal(got, ref):
+                    raise RuntimeError(f"fused peer-write self-test failed for N={N}, K={K}")
+                self.fused[(n_loc, K)] = True
+            if any((c[5], c[6]) not in self.fused for c in self.calls):
+                self.fused = {}   # all or nothing: one PeerGather is never driven from two streams
         except Exception as e:  # noqa: BLE001
             err = repr(e)
         verdicts = [None] * self.tp
         dist.all_gather_object(verdicts, err, group=group)
         if all(v is None for v in verdicts):
-            self.transport = "peer writes over xGMI (mixq_tp_push_columns + flags), data lands in place"
+            self.transport = "peer writes over xGMI, data lands in place: " + (
+                "issued from the GEMM's own store path (mixq_enqueue_tp, per-M-chunk flags)" if self.fused
+                else "mixq_tp_push_columns + flags")
         else:
             self.gatherers = {}
+            self.fused = {}
             first = next(v for v in verdicts if v is not None)
             self.transport = f"rccl all_gather_into_tensor + column placement (peer transport unavailable: {first})"
 
@@ -401,6 +423,11 @@ def main():
             if events is not None:
                 e0, e1 = events[ei]
                 ei += 1
+            if model.tp > 1 and model.fused.get((n_loc, K)) and events is None:
+                # operator + all-gather in ONE pass on the compute stream: the GEMM's epilogue writes this rank's column
+                # block into every rank's buffer and publishes per-chunk flags; the stream then waits for the peers' flags
+                model.full[N] = model.gatherers[N].enqueue_gather_raw(h, in_desc, in_ptrs, model.ws_ptr, model.chunk, K)
+                continue
             par = model.n_call & 1 if model.tp > 1 else 0
             model.n_call += 1
             if model.tp > 1 and model.gather_done[par] is not None:

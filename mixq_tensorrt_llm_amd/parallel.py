@@ -239,6 +239,15 @@ class PeerGather:
         assert inputs[1].shape[0] == self.n_loc and A.is_cuda and A.is_contiguous()
         if not self.lib.mixq_tp_fused_supported(m, self.n_loc, K):
             return None
+        in_desc = (_lib.TensorDesc * 7)(*[_lib.TensorDesc.make(t.shape) for t in inputs])
+        in_ptrs = (ctypes.c_void_p * 7)(*[t.data_ptr() for t in inputs])
+        if workspace is None:
+            workspace = plug._workspace(A.device, plug.workspace_size(max(m, 1), self.n_loc, K))
+        return self.enqueue_gather_raw(plug._h, in_desc, in_ptrs, ctypes.c_void_p(workspace.data_ptr()), m, K)
+
+    def enqueue_gather_raw(self, handle, in_desc, in_ptrs, ws_ptr, m: int, K: int):
+        """``enqueue_gather`` on prepared ctypes blocks (bench.py); the shape must be ``mixq_tp_fused_supported``."""
+        from . import _lib
         par = self._begin(m)
         st = ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
         tp = _lib.TpEpilogue()
@@ -247,13 +256,8 @@ class PeerGather:
             tp.dst_bases[r] = self.peer[r][par]
             tp.dst_flags[r] = self._flag_ptr(r, par, self.rank)
         tp.counters = self.small.data_ptr() + 4
-        in_desc = (_lib.TensorDesc * 7)(*[_lib.TensorDesc.make(t.shape) for t in inputs])
-        in_ptrs = (ctypes.c_void_p * 7)(*[t.data_ptr() for t in inputs])
-        if workspace is None:
-            workspace = plug._workspace(A.device, plug.workspace_size(max(m, 1), self.n_loc, K))
         with torch.cuda.device(self.dev):
-            _lib.check(self.lib.mixq_enqueue_tp(plug._h, in_desc, in_ptrs, ctypes.c_void_p(workspace.data_ptr()),
-                                                ctypes.byref(tp), st), "mixq_enqueue_tp")
+            _lib.check(self.lib.mixq_enqueue_tp(handle, in_desc, in_ptrs, ws_ptr, ctypes.byref(tp), st), "mixq_enqueue_tp")
             self._wait(par, int(self.lib.mixq_tp_flag_words(m)), st)
         return self._view(par, m)
 
