@@ -343,6 +343,11 @@ MIXQ_API void mixq_debug_set_gemm_variant(int variant);
  * shader-clock stamps (start, prologue done, main loop done, outlier operands staged, dequant math done, tile staged,
  * stores issued, stores drained) to buffer[block*8 ..].  NULL (default) disables it. */
 MIXQ_API void mixq_debug_set_stamp_buffer(void* device_u64_8_per_block);
+/* The same for the quantiser launch of mixq_enqueue / mixq_quant_extract and (through the buffer above) the skinny GEMM:
+ * 100 MHz wall-clock stamps (one time base across kernels): quantiser = entry, row loads issued, gather issued, amax
+ * reduced, stores issued, stores acknowledged; skinny GEMM = entry, epilogue operands requested, first 16 k-steps done,
+ * last MFMA, LDS hand-over, stores issued, stores acknowledged (tools/small_m_timeline.py). */
+MIXQ_API void mixq_debug_set_quant_stamp_buffer(void* device_u64_8_per_block);
 /* Reporting only: name of the kernel family the fused GEMM selected on its most recent launch in this process. */
 MIXQ_API const char* mixq_debug_last_gemm_kernel(void);
 MIXQ_API const char* mixq_version(void);

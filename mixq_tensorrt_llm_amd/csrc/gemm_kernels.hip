@@ -524,7 +524,7 @@ static std::atomic<int> g_variant{-1};
 
 void set_gemm_variant(int v)
 {
-    if (v >= 92 && v <= 98) { // skinny-kernel ablations (measurement only, wrong results): 92 + ABL - 1
+    if (v >= 92 && v <= 99) { // skinny-kernel ablations (measurement only, wrong results): 92 + ABL - 1
         set_skinny_kw(21 + (v - 92));
         g_force_cfg.store(-1);
         g_variant.store(0);

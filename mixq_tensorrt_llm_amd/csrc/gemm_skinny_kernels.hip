@@ -15,6 +15,7 @@
 #include "mixq_device.h"
 #include "mixq_launch.h"
 #include <atomic>
+#include <type_traits>
 
 namespace mixq {
 
@@ -23,6 +24,7 @@ template <int MT, int EPI, int KW, int ABL = 0>
 __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p)
 {
     __shared__ v4i part[KW][MT][64]; // [K part][m tile][lane]
+    dbg_stamp(p.dbg, 0); // (measurement only: p.dbg is NULL in production) entry
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n0 = blockIdx.x * 16;
@@ -37,7 +39,8 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
     const int8_t* wrow = p.B + (int64_t)min(n0 + lr, p.N - 1) * K + lq * 16;
     const int8_t* arow[MT];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) arow[t] = p.A + (int64_t)min(t * 16 + lr, p.M - 1) * K + lq * 16;
+    for (int t = 0; t < MT; ++t)
+        arow[t] = p.A + (int64_t)min(t * 16 + lr, p.M - 1) * K + lq * 16;
 
     v4i acc[MT];
 #pragma unroll
@@ -72,40 +75,59 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
     }
 
     const v4i zero4 = {0, 0, 0, 0};
-    // Weight loads are issued 16 steps (1 KiB per lane-row quarter) ahead: the kernel is latency-bound (each wave only
-    // streams K/4 bytes of 16 rows), so as much of W as the registers hold is put in flight before the first MFMA.
-    // (Round 2, ablations on 4096 x 4096, GEMM only, us: M = 32 full 7.8 | no qA loads 4.7 | no weight loads 5.9 | no
-    //  loads at all 4.6; M = 16: 5.8 | 4.8 | 5.3 | 4.7 -- the weight stream alone is free, the qA fragments are what a
-    //  second m tile pays for.  Requesting all 32 qA fragments up front instead of in groups of 4 steps: no change.)
-    auto do_steps = [&](int s0, int cnt) __attribute__((always_inline)) {
-        v4i wf[16];
+    // Main loop, round 3.  profiles/r03_small_m_timeline.txt: of the 6.8 us of this kernel at M = 32 on 4096 x 4096, 5.2 were
+    // the fragment phase -- and the ISA showed why: every fragment load sat behind its own exec-mask branch (the `ok ? load :
+    // 0` predicates), and the qA loads of a 4-step group were only ISSUED after the MFMAs of the group before had waited
+    // `vmcnt(0)`: four (eight) serialised memory round trips per wave.  Now a batch is branch-free and entirely in flight:
+    //   * addresses are clamped instead of predicated (a step past the wave's range re-reads its last valid step; a 16-byte
+    //     group past K re-reads the row's last group), and only the WEIGHT fragment of such a step / group is zeroed -- a zero
+    //     A operand makes the product zero whatever the qA lanes hold -- with selects on a wave-uniform / lane condition that
+    //     exist only in the tail instantiation of the batch;
+    //   * loads are issued in CONSUMPTION order (W_u, qA_u0, qA_u1, W_u+1, ...), all STEPS x (1 + MT) of a batch before the
+    //     first MFMA, so the compiler's counted `vmcnt(n)` lets step u multiply while steps u+1.. are still on their way.
+    // (Round 2's ablations of the old form, 4096 x 4096, GEMM only, us: M = 32 full 7.8 | no qA loads 4.7 | no weight loads
+    //  5.9 | no loads at all 4.6.)
+    constexpr int STEPS = MT <= 2 ? 16 : 8; // k-steps per batch: (1 + MT) x STEPS x 4 fragment registers
+    const bool ktail = (p.K & 63) != 0;     // the row's last step is partial (K % 16 == 0 is checked on the host)
+    const int koff_last = p.K - 16;
+    auto do_steps = [&](int s0, int cnt, auto full_tag) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value; // cnt == STEPS and no partial step: no clamps, no selects
+        v4i wf[STEPS], af[STEPS][MT];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int64_t kb = (int64_t)(s0 + u) * 64;
-            wf[u] = (!(ABL & 2) && u < cnt && kb + lq * 16 < K) ? *reinterpret_cast<const v4i*>(wrow + kb) : zero4;
+        for (int u = 0; u < STEPS; ++u) {
+            const int su = FULL ? s0 + u : min(s0 + u, s0 + cnt - 1); // (wave-uniform)
+            int off = su * 64;                                        // byte offset inside the row, + lq * 16 per lane
+            if (!FULL) off = min(off + lq * 16, koff_last) - lq * 16;
+            wf[u] = (ABL & 2) ? zero4 : *reinterpret_cast<const v4i*>(wrow + off);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) af[u][t] = (ABL & 1) ? zero4 : *reinterpret_cast<const v4i*>(arow[t] + off);
         }
+        __builtin_amdgcn_sched_barrier(0); // every load of the batch is issued before the first MFMA (the scheduler otherwise
+                                           // sinks loads between the MFMAs to save registers: ~10 in flight instead of 48)
 #pragma unroll
-        for (int u0 = 0; u0 < 16; u0 += 4) {
-            v4i af[4][MT];
-#pragma unroll
-            for (int u = u0; u < u0 + 4; ++u) {
-                const int64_t kb = (int64_t)(s0 + u) * 64;
-                const bool ok = !(ABL & 1) && u < cnt && kb + lq * 16 < K;
-#pragma unroll
-                for (int t = 0; t < MT; ++t) af[u - u0][t] = ok ? *reinterpret_cast<const v4i*>(arow[t] + kb) : zero4;
+        for (int u = 0; u < STEPS; ++u) {
+            v4i w = wf[u];
+            if (!FULL) {
+                const bool dead = u >= cnt || (ktail && (s0 + u) * 64 + lq * 16 >= p.K);
+                if (dead) w = zero4;
             }
 #pragma unroll
-            for (int u = u0; u < u0 + 4; ++u)
-#pragma unroll
-                for (int t = 0; t < MT; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[u], af[u - u0][t], acc[t], 0, 0, 0);
+            for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w, af[u][t], acc[t], 0, 0, 0);
         }
     };
-    for (int s = s_begin; s < s_end; s += 16) do_steps(s, min(16, s_end - s));
+    dbg_stamp(p.dbg, 1); // epilogue operands requested
+    for (int s = s_begin; s < s_end; s += STEPS) {
+        const int cnt = min(STEPS, s_end - s);
+        if (cnt == STEPS && !(ktail && s + STEPS == nsteps)) do_steps(s, cnt, std::true_type{});
+        else do_steps(s, cnt, std::false_type{});
+        if (s == s_begin) dbg_stamp(p.dbg, 2); // first batch: first weight / qA data arrived and multiplied
+    }
+    dbg_stamp(p.dbg, 3); // last MFMA issued
 
 #pragma unroll
     for (int t = 0; t < MT; ++t) part[wave][t][lane] = acc[t];
     __syncthreads();
+    dbg_stamp(p.dbg, 4); // LDS hand-over
 
     // wave t finishes m-tile t : C/D layout of the 16x16 MFMA: m = lane & 15, n = 4 * (lane >> 4) + r
     for (int t = wave; t < MT; t += KW) {
@@ -176,6 +198,11 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
             *reinterpret_cast<uint2*>(static_cast<uint16_t*>(p.D) + (int64_t)m * p.N + nb) = o;
         }
     }
+    if (p.dbg != nullptr) {
+        dbg_stamp(p.dbg, 5); // stores issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        dbg_stamp(p.dbg, 6); // stores acknowledged
+    }
 }
 
 static std::atomic<int> g_skinny_kw{0}; // measurement knob: force the K-split width (0 = auto)
@@ -206,7 +233,7 @@ static hipError_t launch_skinny_epi(const GemmParams& p, hipStream_t st)
     //  Rotating the K-step order per workgroup, so that the workgroups do not all ask for the same qA lines at the same moment:
     //  no change either -- 7.9-8.2 vs 8.3-8.7 us at M = 32 on 4096 x 4096 -- the L2 serves the broadcast.)
     int kw = g_skinny_kw.load();
-    if (EPI == EPI_DEQUANT && kw >= 21 && kw <= 27) { // measurement-only ablations (variant 40 + 20 + ABL): wrong results
+    if (EPI == EPI_DEQUANT && kw >= 21 && kw <= 28) { // measurement-only ablations (variant 40 + 20 + ABL): wrong results
         switch (kw - 20) {
         case 1: return launch_skinny_kw<EPI, 4, 1>(p, st);
         case 2: return launch_skinny_kw<EPI, 4, 2>(p, st);

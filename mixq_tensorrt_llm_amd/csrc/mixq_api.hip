@@ -108,6 +108,8 @@ const char* mixq_plugin_version(void) { return "1"; }
 static std::atomic<void*> g_dbg_stamps{nullptr}; // measurement knob only (NULL in production)
 void mixq_debug_set_stamp_buffer(void* device_u64_8_per_block) { g_dbg_stamps.store(device_u64_8_per_block); }
 
+void mixq_debug_set_quant_stamp_buffer(void* device_u64_8_per_block) { mixq::set_quant_stamp_buffer(device_u64_8_per_block); }
+
 void mixq_debug_set_gemm_variant(int variant) { mixq::set_gemm_variant(variant < 0 ? 0 : variant); }
 
 const char* mixq_debug_last_gemm_kernel(void) { return mixq::last_gemm_kernel(); }

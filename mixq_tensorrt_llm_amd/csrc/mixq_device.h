@@ -13,6 +13,14 @@ typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef _Float16 v4h __attribute__((ext_vector_type(4)));
 typedef _Float16 v2h __attribute__((ext_vector_type(2)));
 
+// Measurement only (NULL in production): thread 0 of every workgroup writes the 100 MHz wall clock (s_memrealtime: one
+// time base across kernels and CUs) into slot `slot` of its 8-slot record (tools/small_m_timeline.py).
+__device__ __forceinline__ void dbg_stamp(void* buf, int slot)
+{
+    if (buf != nullptr && threadIdx.x == 0)
+        static_cast<unsigned long long*>(buf)[(size_t)blockIdx.x * 8 + slot] = wall_clock64();
+}
+
 #define MIXQ_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define MIXQ_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 

@@ -134,6 +134,7 @@ hipError_t launch_dequantization_silu(void* out, const int32_t* x, const void* s
 hipError_t launch_quant_extract(void* A, int8_t* qA, void* sA, void* fpA, const int32_t* ind, int M, int K, int O,
                                 bool zero, hipStream_t st,
                                 void* zero_words = nullptr); // (kSplitkWordsBytes to clear on the way, or null)
+void set_quant_stamp_buffer(void* device_u64_8_per_block); // measurement only (NULL in production)
 hipError_t launch_quant_with_scale(const void* src, const void* scale, int8_t* dst, int M, int K, hipStream_t st);
 hipError_t launch_extract(void* A, void* fpA, const int32_t* ind, int M, int K, int O, bool zero, hipStream_t st);
 hipError_t launch_rmsnorm_quant(const void* X, const void* gamma, void* out, void* outl, const int32_t* ind, int8_t* q,

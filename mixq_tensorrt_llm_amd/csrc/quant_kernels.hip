@@ -14,6 +14,7 @@
 //   * the outlier gather re-reads 2*O bytes of the row this block has just streamed (L2/L1 hits, no HBM traffic).
 #include "mixq_device.h"
 #include "mixq_launch.h"
+#include <atomic>
 
 namespace mixq {
 
@@ -23,8 +24,9 @@ template <int TPR, int MAXV, bool ZERO>
 __global__ __launch_bounds__(QBLOCK) void quant_extract_kernel(uint16_t* __restrict__ A, int8_t* __restrict__ qA,
                                                                uint16_t* __restrict__ sA, uint16_t* __restrict__ fpA,
                                                                const int32_t* __restrict__ ind, int M, int K, int O,
-                                                               unsigned* __restrict__ zero_words)
+                                                               unsigned* __restrict__ zero_words, void* dbg)
 {
+    dbg_stamp(dbg, 0); // (measurement only: NULL in production) entry
     // (enqueue: the hand-over words of the GEMM's K split over workgroups are cleared here, one launch earlier, instead
     //  of by a memset node of their own -- the plugin workspace is shared with whatever else the engine runs)
     if (zero_words != nullptr && blockIdx.x == 0)
@@ -58,9 +60,11 @@ __global__ __launch_bounds__(QBLOCK) void quant_extract_kernel(uint16_t* __restr
     }
 
     // outlier gather (before any zero write-back); strided over the row's TPR threads
+    dbg_stamp(dbg, 1); // row loads issued
     if (fpA != nullptr && row_ok) {
         for (int j = t; j < O; j += TPR) fpA[row * (int64_t)O + j] = A[row * (int64_t)K + ind[j]];
     }
+    dbg_stamp(dbg, 2); // outlier gather issued (two dependent loads + a store per element)
 
     if (ZERO) {
 #pragma unroll
@@ -116,6 +120,7 @@ __global__ __launch_bounds__(QBLOCK) void quant_extract_kernel(uint16_t* __restr
         }
         amax = row_max(amax);
     }
+    dbg_stamp(dbg, 3); // row data arrived, amax reduced
     const uint16_t amax_bits = amax < 0 ? (uint16_t)0x7fffu : (uint16_t)amax;
     const uint16_t s_bits = f2h_bits(h2f(amax_bits) / 127.0f); // __hdiv(max, 127.0)
     const float s = h2f(s_bits);
@@ -147,6 +152,11 @@ __global__ __launch_bounds__(QBLOCK) void quant_extract_kernel(uint16_t* __restr
         }
     }
 
+    if (dbg != nullptr) {
+        dbg_stamp(dbg, 4); // quantised row stored (issued)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        dbg_stamp(dbg, 5); // stores acknowledged
+    }
     if (ZERO) {
         // mixlib flavour mutates A (cult.cu:1426).  All loads of this row have been consumed (amax needed them);
         // the barrier orders other waves' loads of the same row before these stores when TPR > 64.
@@ -265,17 +275,21 @@ hipError_t launch_quant_with_scale(const void* src, const void* scale, int8_t* d
     return hipGetLastError();
 }
 
+static std::atomic<void*> g_quant_stamps{nullptr}; // measurement only (tools/small_m_timeline.py)
+void set_quant_stamp_buffer(void* p) { g_quant_stamps.store(p); }
+
 template <int TPR, int MAXV>
 static hipError_t launch_qe(uint16_t* A, int8_t* qA, uint16_t* sA, uint16_t* fpA, const int32_t* ind, int M, int K,
                             int O, bool zero, hipStream_t st, unsigned* zw)
 {
+    void* const dbg = g_quant_stamps.load(std::memory_order_relaxed);
     constexpr int RPB = QBLOCK / TPR;
     dim3 grid((unsigned)((M + RPB - 1) / RPB)), block(QBLOCK);
     if (zero) {
         size_t sm = (size_t)((K + 31) / 32) * 4;
-        hipLaunchKernelGGL((quant_extract_kernel<TPR, MAXV, true>), grid, block, sm, st, A, qA, sA, fpA, ind, M, K, O, zw);
+        hipLaunchKernelGGL((quant_extract_kernel<TPR, MAXV, true>), grid, block, sm, st, A, qA, sA, fpA, ind, M, K, O, zw, dbg);
     } else {
-        hipLaunchKernelGGL((quant_extract_kernel<TPR, MAXV, false>), grid, block, 0, st, A, qA, sA, fpA, ind, M, K, O, zw);
+        hipLaunchKernelGGL((quant_extract_kernel<TPR, MAXV, false>), grid, block, 0, st, A, qA, sA, fpA, ind, M, K, O, zw, dbg);
     }
     return hipGetLastError();
 }
