@@ -186,6 +186,15 @@ MIXQ_API size_t mixq_gemm_scratch_bound(void);
 MIXQ_API int mixq_gemm_mixed_scratch(const int8_t* qA, const int8_t* W, const void* sA, const void* sW, const void* fpA,
                                      const void* fpW, void* Out, int M, int N, int K, int O, void* scratch,
                                      size_t scratch_bytes, void* stream);
+/* MixLinear_GEMM.forward (MixQ/src/mixquant/modules/linear.py:163-286, bit = 8, static outlier set) as ONE call and TWO
+ * launches: the reference makes four mixlib calls per linear here (ExtractOutliersAndSetToZeros, FindRowScale, torch.mm on the
+ * outliers, int8FusedDequantize); a decode step is host-bound on those calls long before it is GPU-bound
+ * (profiles/r03_mixlib_overhead.txt).  x fp16 [M,K] (its `ind` columns are ZEROED, as the reference does), ind int32 [O],
+ * q_weight int8 [N,K], scale_col fp16 [N], weight_cache fp16 [N,O]; outputs: x_scale fp16 [M], q_x int8 [M,K], outliers fp16
+ * [M,O], out fp16 [M,N].  scratch: as mixq_gemm_mixed_scratch (may be NULL). */
+MIXQ_API int mixq_mixlinear_forward(int M, int N, int K, int O, void* x_f16, const int32_t* ind, const int8_t* q_weight,
+                                    const void* scale_col, const void* weight_cache, void* x_scale, int8_t* q_x,
+                                    void* outliers_f16, void* out_f16, void* scratch, size_t scratch_bytes, void* stream);
 /* gemm (TsinghuaMixQPlugin.cpp:36-77, cuBLAS s8 x s8 -> s32): raw int32 accumulators, for bit-exact checks. */
 MIXQ_API int mixq_gemm_s8s8s32(const int8_t* A, const int8_t* B, int32_t* C, int M, int N, int K, void* stream);
 /* gemmfp16 (TsinghuaMixQPlugin.cpp:122-161): Out = fpA . fpW^T, fp32 accumulate, fp16 out. */

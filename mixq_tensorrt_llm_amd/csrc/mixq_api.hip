@@ -556,6 +556,30 @@ int mixq_gemm_mixed_scratch(const int8_t* qA, const int8_t* W, const void* sA, c
     return hip_rc(mixq::launch_gemm(p, mixq::EPI_DEQUANT, st));
 }
 
+int mixq_mixlinear_forward(int M, int N, int K, int O, void* x, const int32_t* ind, const int8_t* q_weight,
+                           const void* scale_col, const void* weight_cache, void* x_scale, int8_t* q_x, void* outliers,
+                           void* out, void* scratch, size_t scratch_bytes, void* stream)
+{
+    if (M < 0 || N < 0 || K <= 0 || O < 0) return MIXQ_E_BADARG;
+    if (M == 0 || N == 0) return MIXQ_OK;
+    if (!x || !q_weight || !scale_col || !x_scale || !q_x || !out || (O > 0 && (!ind || !weight_cache || !outliers)))
+        return MIXQ_E_BADARG;
+    // two launches instead of the four of MixLinear_GEMM.forward (linear.py:163-286): ExtractOutliersAndSetToZeros +
+    // FindRowScale = the fused producer with zero_outliers = 1 (cult.cu:2616-2709 is the reference's own fused form), the
+    // outlier product + int8FusedDequantize = the fused GEMM with its fp16 side product (<= 128 outlier columns, a multiple
+    // of 8; anything else takes the reference's own two steps inside mixq_gemm_mixed_scratch)
+    int rc = mixq_quant_extract(M, K, x, q_x, x_scale, outliers, ind, O, 1, stream);
+    if (rc != MIXQ_OK) return rc;
+    if (O % 8 == 0)
+        return mixq_gemm_mixed_scratch(q_x, q_weight, x_scale, scale_col, outliers, weight_cache, out, M, N, K, O, scratch,
+                                       scratch_bytes, stream);
+    rc = mixq_gemm_fp16(outliers, weight_cache, out, M, N, O, stream);
+    if (rc != MIXQ_OK) return rc;
+    return mixq_int8_fused_dequantize(q_x, q_weight, x_scale, scale_col, out, out, M, N, K,
+                                      scratch_bytes >= mixq_gemm_scratch_size(M, N, K) ? static_cast<char*>(scratch) : nullptr,
+                                      stream);
+}
+
 int mixq_gemm_s8s8s32(const int8_t* A, const int8_t* B, int32_t* C, int M, int N, int K, void* stream)
 {
     if (M < 0 || N < 0 || K <= 0) return MIXQ_E_BADARG;

@@ -41,6 +41,19 @@ __global__ __launch_bounds__(NBLOCK) void rmsnorm_quant_kernel(const uint16_t* _
     unsigned* zmask = reinterpret_cast<unsigned*>(dyn);
     uint16_t* lrow = reinterpret_cast<uint16_t*>(dyn + mask_bytes) + (size_t)rslot * K;
 
+    // the row (and, for short rows, gamma) is requested FIRST: its round trip runs under the outlier-mask phase below (a
+    // decode batch is a chain of latencies: the mask phase alone is an `ind` round trip + two barriers)
+    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(X + (row_ok ? row : 0) * (int64_t)K);
+    const uint4* __restrict__ g4 = reinterpret_cast<const uint4*>(gamma);
+    uint4 x[MAXV];
+    constexpr bool GPRE = MAXV <= 4; // gamma prefetched into registers (16 more VGPRs at most)
+    uint4 gpre[GPRE ? MAXV : 1];
+#pragma unroll
+    for (int v = 0; v < MAXV; ++v) {
+        const int idx = v * TPR + t;
+        x[v] = (row_ok && idx < nvec) ? src[idx] : make_uint4(0u, 0u, 0u, 0u);
+        if (GPRE) gpre[v] = idx < nvec ? g4[idx] : make_uint4(0u, 0u, 0u, 0u);
+    }
     if (QUANT) {
         for (int i = tid; i < mask_bytes / 4; i += NBLOCK) zmask[i] = 0u;
         __syncthreads();
@@ -51,13 +64,9 @@ __global__ __launch_bounds__(NBLOCK) void rmsnorm_quant_kernel(const uint16_t* _
         __syncthreads();
     }
 
-    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(X + (row_ok ? row : 0) * (int64_t)K);
-    uint4 x[MAXV];
     float ss = 0.f;
 #pragma unroll
     for (int v = 0; v < MAXV; ++v) {
-        const int idx = v * TPR + t;
-        x[v] = (row_ok && idx < nvec) ? src[idx] : make_uint4(0u, 0u, 0u, 0u);
         const unsigned w[4] = {x[v].x, x[v].y, x[v].z, x[v].w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -76,13 +85,12 @@ __global__ __launch_bounds__(NBLOCK) void rmsnorm_quant_kernel(const uint16_t* _
     const float rstd = 1.0f / __builtin_sqrtf(ss / (float)K + eps);
 
     // normalise in place (registers now hold the fp16 result), stage the row in LDS for the gather
-    const uint4* __restrict__ g4 = reinterpret_cast<const uint4*>(gamma);
     unsigned m2 = 0u;
 #pragma unroll
     for (int v = 0; v < MAXV; ++v) {
         const int idx = v * TPR + t;
         if (idx < nvec) {
-            const uint4 gv = g4[idx];
+            const uint4 gv = GPRE ? gpre[v] : g4[idx];
             const unsigned w[4] = {x[v].x, x[v].y, x[v].z, x[v].w};
             const unsigned gw[4] = {gv.x, gv.y, gv.z, gv.w};
             unsigned o[4];
@@ -247,6 +255,13 @@ hipError_t launch_rmsnorm_quant(const void* X, const void* gamma, void* out, voi
     uint16_t* ol = static_cast<uint16_t*>(outl);
     uint16_t* sc = static_cast<uint16_t*>(scale);
     const int nvec = K / 8;
+    // Decode batches (few rows: the launch is a chain of latencies, not a stream): a whole 256-thread block per row, so that
+    // a row is ONE load round trip of 1-4 vectors per lane instead of 8-16 on a single wavefront -- the same rule as the
+    // quantiser's (quant_kernels.hip); 32 x 4096: 11.0 -> ~4.5 us for the fused producer (profiles/r03_small_m_timeline.txt)
+    if (M <= 64 && nvec > 64 * 2) {
+        if (nvec <= 256 * 2) return launch_norm<256, 2>(x, g, o, ol, ind, q, sc, eps, M, K, O, quant, st);
+        if (nvec <= 256 * 4) return launch_norm<256, 4>(x, g, o, ol, ind, q, sc, eps, M, K, O, quant, st);
+    }
     if (nvec <= 64 * 2) return launch_norm<64, 2>(x, g, o, ol, ind, q, sc, eps, M, K, O, quant, st);
     if (nvec <= 64 * 4) return launch_norm<64, 4>(x, g, o, ol, ind, q, sc, eps, M, K, O, quant, st);
     if (nvec <= 64 * 8) return launch_norm<64, 8>(x, g, o, ol, ind, q, sc, eps, M, K, O, quant, st);

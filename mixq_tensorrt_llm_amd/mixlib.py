@@ -16,25 +16,34 @@ __all__ = ["FindRowScale", "ExtractOutliersAndSetToZeros", "int8FusedDequantize"
            "layernorm_forward_cuda_extract_outliers", "int_to_half", "int_matrix_to_half",
            "int8_matrix_to_half", "w8_a16_gemm", "preprocess_weights", "mixq_linear", "int4FusedDequantize",
            "int4FusedDequantizeSilu", "unpack_int4_to_fp16", "int8FusedDequantizeSiluMul",
-           "layernorm_forward_cuda_extract_outliers_int4", "ExtractOutliers", "dequantizeInt8Silu"]
+           "layernorm_forward_cuda_extract_outliers_int4", "ExtractOutliers", "dequantizeInt8Silu", "mixlinear_forward"]
+
+
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)   # ~0.2 us; torch.cuda.current_stream() costs ~1.8 us
+_cur_device = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
 
 
 def _st(t):
-    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    """The current HIP stream of ``t``'s device as a raw pointer (profiles/r03_mixlib_overhead.txt: the Python-level
+    torch.cuda.current_stream(...).cuda_stream was 1.8 of the ~6.6 us a wrapper added to a direct C-ABI call)."""
+    if _raw_stream is not None:
+        return _raw_stream(t.device.index if t.device.index is not None else _cur_device())
+    return torch.cuda.current_stream(t.device).cuda_stream
 
 
 def _p(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    return t.data_ptr() if t is not None else None
 
 
 def _on_tensor_device(fn):
     """Run the op with the CUDA/HIP current device set to the device of its first tensor argument: the library caches
-    per-device state under hipGetDevice() and launches on that tensor's current stream."""
+    per-device state under hipGetDevice() and launches on that tensor's current stream.  (The common case -- the tensor
+    lives on the current device -- costs one attribute read and one C call.)"""
     @functools.wraps(fn)
     def wrapper(*args, **kwargs):
         for a in args:
-            if isinstance(a, torch.Tensor) and a.is_cuda:
-                if a.device.index != torch.cuda.current_device():
+            if isinstance(a, torch.Tensor):
+                if a.is_cuda and a.device.index != _cur_device():
                     with torch.cuda.device(a.device):
                         return fn(*args, **kwargs)
                 break
@@ -77,7 +86,7 @@ def ExtractOutliersAndSetToZeros(ind, input):
     assert ind.dtype == torch.int32 and input.dtype == torch.float16
     m, k = input.shape
     n = ind.shape[0]
-    out = torch.zeros((m, n), dtype=torch.float16, device=input.device)
+    out = torch.empty((m, n), dtype=torch.float16, device=input.device)  # (every element is written: no memset launch)
     _lib.check(_lib.load().mixq_extract_outliers_set_zero(m, k, _p(input), _p(out), _p(ind), n, _st(input)),
                "ExtractOutliersAndSetToZeros")
     return out
@@ -357,3 +366,27 @@ def mixq_linear(A, W_int8, sW, fp_weight, ind, out=None, workspace=None):
     _lib.check(lib.mixq_gemm_mixed_scratch(_p(qA), _p(W_int8), _p(sA), _p(sW), _p(fpA), _p(fp_weight), _p(out), M, N, K, O,
                                            _p(scr), scr.numel() if scr is not None else 0, _st(A)), "gemm_mixed")
     return out
+
+
+def mixlinear_forward(x, ind, q_weight, scale_col, weight_cache, x_scale):
+    """MixLinear_GEMM.forward (linear.py:163-286, bit = 8, static outlier set) in ONE library call and two launches (MI355X
+    extension, include/mixq.h ``mixq_mixlinear_forward``): returns (out fp16 [M,N], q_x int8 [M,K], outliers fp16 [M,O]); zeroes
+    the ``ind`` columns of ``x`` and fills ``x_scale`` like the reference's four-call sequence.  The wrapper does what one of
+    the four wrappers does -- the host cost per linear drops ~4x (profiles/r03_mixlib_overhead.txt)."""
+    M, K = x.shape
+    N = q_weight.shape[0]
+    O = int(ind.shape[0])
+    dev = x.device
+    out = torch.empty((M, N), dtype=torch.float16, device=dev)
+    q_x = torch.empty((M, K), dtype=torch.int8, device=dev)
+    outliers = torch.empty((M, O), dtype=torch.float16, device=dev)
+    lib = _lib.load()
+    scratch = gemm_scratch(x, M, N, K)
+    _lib.check(lib.mixq_mixlinear_forward(M, N, K, O, x.data_ptr(), ind.data_ptr() if O else None, q_weight.data_ptr(),
+                                          scale_col.data_ptr(), weight_cache.data_ptr() if (O and weight_cache is not None) else None,
+                                          x_scale.data_ptr(),
+                                          q_x.data_ptr(), outliers.data_ptr() if O else None, out.data_ptr(),
+                                          scratch.data_ptr() if scratch is not None else None,
+                                          scratch.numel() if scratch is not None else 0,
+                                          _st(x)), "mixlinear_forward")
+    return out, q_x, outliers

@@ -20,12 +20,7 @@ import torch
 from . import _lib, mixlib
 
 
-def _st(t):
-    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
-
-
-def _p(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+from .mixlib import _p, _st  # noqa: E402  (raw pointers / the raw current stream: cheap on the host)
 
 
 def find_outliers(activation: torch.Tensor, sigma: float, capacity: int = None) -> torch.Tensor:
@@ -183,6 +178,19 @@ class MixLinear_GEMM:
                 y += self.bias
             return y.reshape(cache.shape)
 
+        if unfused and self.bit == 8 and not self.add_outliers and inputs.is_contiguous():
+            # static outlier set: the reference's four mixlib calls (:186-189, :241-247) as ONE library call and two launches
+            # (mixq_mixlinear_forward); a decode step is host-bound on those calls long before it is GPU-bound
+            # (profiles/r03_mixlib_overhead.txt: 42.6 us of host time per linear through four wrappers, 16 us as four direct
+            # C-ABI calls, 7.8 us as this one)
+            assert cache.x_scale.numel() >= M
+            cache.ind = self.ind
+            wc = self.weight_cache if self.ind.shape[0] else None
+            y1, cache.q_xcache, cache.activation_outliers = mixlib.mixlinear_forward(
+                inputs, self.ind, self.q_weight, self.scale_col, wc, cache.x_scale)
+            if self.bias is not None:
+                y1 += self.bias
+            return y1.reshape(cache.shape)
         if unfused:
             if self.ind.shape[0]:
                 cache.activation_outliers = mixlib.ExtractOutliersAndSetToZeros(self.ind, inputs)

@@ -31,7 +31,12 @@ def _load_lianxiang_plugin_lib():
     return handle
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream_ptr(device) -> ctypes.c_void_p:
+    if _raw_stream is not None and device.index is not None:   # ~0.2 us instead of ~1.8 us per call
+        return ctypes.c_void_p(_raw_stream(device.index))
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
