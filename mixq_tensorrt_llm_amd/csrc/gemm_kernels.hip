@@ -773,7 +773,7 @@ hipError_t launch_dequantization(void* out, const int32_t* x, const void* sRow, 
 
 // dequantizationKernelSilu (quantkernel/mix_cuda/cult.cu:2305-2324, called by dequantizeInt8Silu :2341-2348 on the
 // P-flavour's sm90 route, MixQ/src/mixquant/modules/linear.py:321-324):
-//   out = fp16( silu( (float(x) * sRow[m]) * sCol[n] + float(y) ) )      -- fp32 throughout, ONE rounding to fp16
+//   out = fp16( silu( fma(fl32(float(x) * sRow[m]), sCol[n], float(y)) ) )   -- fp32 throughout, ONE rounding to fp16
 // (unlike dequantizationKernel above, which rounds the product to fp16 before an fp16 add).
 __global__ __launch_bounds__(256) void dequantization_silu_kernel(uint16_t* __restrict__ out,
                                                                    const int32_t* __restrict__ x,
@@ -784,9 +784,11 @@ __global__ __launch_bounds__(256) void dequantization_silu_kernel(uint16_t* __re
     const int64_t total = (int64_t)M * N;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int m = (int)(i / N), n = (int)(i % N);
-        float t = ((float)x[i] * h2f(sRow[m])) * h2f(sCol[n]); // two separate fp32 roundings (no FMA: nvcc contracts
-        asm("" : "+v"(t));                                        //  only mul+add pairs, and the add below is that pair)
-        out[i] = f2h_bits_of_f32_result(silu_f32(t + h2f(y[i])));
+        // nvcc (default -fmad=true) contracts the LAST multiply with the add: fma(fl32(x * sRow), sCol, y) -- the first
+        // product is rounded on its own (pinned: hipcc must not fold it into the fma), exactly as the oracle restates it
+        float t = (float)x[i] * h2f(sRow[m]);
+        asm("" : "+v"(t));
+        out[i] = f2h_bits_of_f32_result(silu_f32(__builtin_fmaf(t, h2f(sCol[n]), h2f(y[i]))));
     }
 }
 

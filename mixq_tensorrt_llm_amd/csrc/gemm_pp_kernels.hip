@@ -549,10 +549,14 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
     // (rows r and r+8 would otherwise hit the same banks in one ds_write_b64 pass).
     char* const wstg = smem + 2 * BUF + wave * 4096;
     const int obase = (lh ^ (lr & 15)) << 4; // 16-B slot of k-step ks = obase ^ (ks << 5)
-    float sa[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) // (clamped rows are never stored)
-        sa[j] = EPI == EPI_F16GEMM ? 1.f : 2 * j < nt ? h2f(p.sA[min(m0 + wm * 128 + jmap(j) * 32 + lr, p.M - 1)]) : 0.f;
+    // row scale of block j (this lane's row): fetched ONE BLOCK AHEAD instead of all four up front -- the four values + their
+    // addresses pushed the epilogue over the 256-register budget: 3 dwords per lane spilled to scratch, 6 KiB per tile, which
+    // is exactly the +4.7 % (67 / 64) by which WRITE_SIZE of this kernel exceeded 2 M N in round 2 (profiles/README.md)
+    auto load_sa = [&](int j) __attribute__((always_inline)) -> uint16_t { // (clamped rows are never stored)
+        return p.sA[min(m0 + wm * 128 + jmap(j) * 32 + lr, p.M - 1)];
+    };
+    uint16_t sa_next = EPI == EPI_F16GEMM ? (uint16_t)0 : load_sa(0);
+    float sa_cur = 1.f;
 
     // side GEMM of tile (i, j): 8 k-steps of 16 outlier columns
     auto side = [&](int i, int j) __attribute__((always_inline)) {
@@ -639,7 +643,7 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
             unsigned ow[2];
 #pragma unroll
             for (int e2 = 0; e2 < 4; e2 += 2) {
-                const v2f s2 = v2f{swf[e2], swf[e2 + 1]} * sa[j]; // exact: fp16 x fp16 products
+                const v2f s2 = v2f{swf[e2], swf[e2 + 1]} * sa_cur; // exact: fp16 x fp16 products
                 // addend pair: the fp16-rounded outlier products (cuBLAS writes fp16) or the caller's y
                 v2f c2;
                 if (HAS_O) {
@@ -680,14 +684,19 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
     // rows j*32 .. j*32+31 of the wave tile: window -> 4 x (8 rows x 128 B) stores
     // store address = wave-uniform base (SGPRs) + a per-lane 32-bit offset that never changes
     char* const dwave = static_cast<char*>(p.D) + ((int64_t)(m0 + wm * 128) * p.N + n0 + wn * 64) * 2;
-    const unsigned dlane = ((unsigned)(lane >> 3) * (unsigned)p.N + (lane & 7) * 8) * 2;
-    const int rd = (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4); // window read offset (rr & 7 == lane >> 3)
+    // (window read offset rd = (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4) and the store offset dlane: see flush)
     const bool n_ok = n0 + wn * 64 + (lane & 7) * 8 < p.N;
     const bool interior = m0 + BM <= p.M && n0 + BN <= p.N; // wave-uniform: no store predicates needed
     // TP: the same 128-byte row segments, once per destination, into [M, ldd] buffers (wave-uniform base per destination)
     const int64_t tp_wave = TP ? ((int64_t)(m0 + wm * 128) * p.tp.ldd + n0 + wn * 64) * 2 : 0;
     const unsigned tp_lane = TP ? ((unsigned)(lane >> 3) * (unsigned)p.tp.ldd + (lane & 7) * 8) * 2 : 0u;
     auto flush = [&](int j) __attribute__((always_inline)) {
+        // (the two per-lane offsets of the flush are re-derived from an opaque copy of the lane id instead of living in
+        //  registers across the side GEMM + dequant of the block: that was the last value the epilogue spilled)
+        unsigned ln = (unsigned)lane;
+        asm volatile("" : "+v"(ln));
+        const int rd = (int)((ln >> 3) * 128 + (((ln & 7) ^ (ln >> 3)) << 4));
+        const unsigned dlane = ((ln >> 3) * (unsigned)p.N + (ln & 7) * 8) * 2;
         uint4 v[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const uint4*>(wstg + q * 1024 + rd);
@@ -699,7 +708,7 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
             if (q & 1) v[q] = uint4{v[q].z, v[q].w, v[q].x, v[q].y}; // rows with bit 3 set hold their 8-B halves swapped
             const int row = jmap(j) * 32 + q * 8;     // wave-uniform
             if constexpr (TP) {
-                const bool ok = interior || (n_ok && m0 + wm * 128 + row + (lane >> 3) < p.M);
+                const bool ok = interior || (n_ok && m0 + wm * 128 + row + (int)(ln >> 3) < p.M);
                 const v4i val = {(int)v[q].x, (int)v[q].y, (int)v[q].z, (int)v[q].w};
                 for (int r = 0; r < p.tp.ndst; ++r) { // (uniform trip count; bases are scalars)
                     char* dst = static_cast<char*>(p.tp.base[r]) + tp_wave + (int64_t)row * p.tp.ldd * 2 + tp_lane;
@@ -711,7 +720,7 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
             }
             char* dst = dwave + (int64_t)row * p.N * 2 + dlane;
             if (interior) *reinterpret_cast<uint4*>(dst) = v[q];
-            else if (n_ok && m0 + wm * 128 + row + (lane >> 3) < p.M) *reinterpret_cast<uint4*>(dst) = v[q];
+            else if (n_ok && m0 + wm * 128 + row + (int)(ln >> 3) < p.M) *reinterpret_cast<uint4*>(dst) = v[q];
         }
     };
     // software pipeline over the 8 tiles (j-major): the MFMA chain of tile t+1 runs under the VALU work of tile t
@@ -722,6 +731,10 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
             if (SPLITK && t >= nt) break; // (uniform)
             v16f Pnext = Pcur;
             if (t + 1 < nt) Pnext = side((t + 1) & 1, (t + 1) >> 1);
+            if (EPI != EPI_F16GEMM && (t & 1) == 0) { // block j = t >> 1 starts: its row scale arrives, the next one is requested
+                sa_cur = h2f(sa_next);
+                if (t + 2 < nt) sa_next = load_sa((t >> 1) + 1);
+            }
             if ((HAS_Y || HAS_MUL) && (t & 1) == 0) { // block j = t >> 1 starts: operands of this block -> registers
                 if (HAS_Y) spread(ypre, yq);
                 if (HAS_MUL) spread(mpre, mq);

@@ -92,6 +92,7 @@ def ExtractOutliersAndSetToZeros(ind, input):
     return out
 
 
+_W8A16_PERSISTENT_SCRATCH_LIMIT = 64 << 20   # bytes of fpA_intB scratch kept per stream; larger = per call (two-pass form)
 _GEMM_SCRATCH = {}
 _GEMM_SCRATCH_RETIRED = []  # superseded buffers stay alive: a HIP graph captured earlier still holds their pointers
 
@@ -327,7 +328,15 @@ def w8_a16_gemm(input, weight, scale):
     out = torch.empty((m, n), dtype=torch.float16, device=input.device)
     lib = _lib.load()
     nws = int(lib.mixq_w8a16_gemm_workspace_size(m, n, k))
-    scr = _scratch_bytes(input, nws) if nws else None
+    # the two-pass form (m >= 1280) wants 16 KiB + N*K*2 bytes (the fp16 image of W: ~470 MB for 28672 x 8192); parking
+    # that in the never-released per-stream scratch would pin up to > 1 GB per stream.  Large requests come from the caching
+    # allocator per call instead (zeroed hand-over words; freed when the call's tensors die -- stream-ordered, so safe), unless a
+    # graph is being captured (then the small persistent scratch is offered and the library picks a form that fits it).
+    if nws > _W8A16_PERSISTENT_SCRATCH_LIMIT and not torch.cuda.is_current_stream_capturing():
+        scr = torch.empty(nws, dtype=torch.uint8, device=input.device)
+        scr[:16384].zero_()
+    else:
+        scr = _scratch_bytes(input, min(nws, _W8A16_PERSISTENT_SCRATCH_LIMIT)) if nws else None
     _lib.check(lib.mixq_w8a16_gemm_forward_ws(_p(input), _p(weight), _p(scale), _p(out), m, n, k, _p(scr),
                                               scr.numel() if scr is not None else 0, _st(input)), "w8_a16_gemm")
     return out

@@ -14,9 +14,15 @@ d = sys.argv[1]
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in glob.glob(f"{d}/{c}/**/*counter_collection.csv", recursive=True):
         agg = collections.defaultdict(list)
+        by_grid = collections.defaultdict(list)   # the three GEMM shapes differ in grid size: per-shape means
         for r in csv.DictReader(open(f)):
             if "mixq::" in r["Kernel_Name"] and r["Counter_Name"] == c:
-                agg[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+                k = r["Kernel_Name"].split("(")[0]
+                agg[k].append(float(r["Counter_Value"]))
+                if "gemm_w8a8o16_pp_kernel" in k:
+                    by_grid[(k, r.get("Grid_Size", r.get("Grid_Size_X", "?")))].append(float(r["Counter_Value"]))
         for k, v in sorted(agg.items()):
             print(f"{c} {k} mean_per_dispatch_KiB {sum(v)/len(v):.1f} n {len(v)}")
+        for (k, g), v in sorted(by_grid.items()):
+            print(f"{c} {k} grid {g} mean_per_dispatch_KiB {sum(v)/len(v):.1f} n {len(v)}")
 PY
