@@ -345,6 +345,13 @@ MIXQ_API int mixq_enqueue_tp(const mixq_handle* h, const mixq_tensor_desc* input
 MIXQ_API int mixq_preprocess_weights_int8(uint8_t* preprocessed, const int8_t* row_major, size_t rows, size_t cols);
 MIXQ_API int mixq_unprocess_weights_int8(int8_t* row_major, const uint8_t* preprocessed, size_t rows, size_t cols);
 
+/* ---- debug / measurement (NOT FOR PRODUCTION) ----------------------------------------------------------------------------
+ * Everything named mixq_debug_* is PROCESS-GLOBAL state (atomics: race-free, but a caller that flips a knob changes the
+ * kernel selection of every thread and stream of the process) and exists for the tests, the A/B tools under tools/ and the
+ * in-kernel timelines.  The operator boundary above holds no such state: with the knobs at their defaults --
+ * mixq_debug_reset() -- the selection is a pure function of (M, N, K, scratch).  No knob changes results beyond what the
+ * tests pin (every form is bit-identical or within the stated tolerance), except the ablation ranges marked "wrong results". */
+MIXQ_API void mixq_debug_reset(void);
 /* Test / measurement knob: main-loop schedule of the fused GEMM.  0 = auto (default), 1 = 2-barrier double-buffered
  * kernel only, 2 = 256x256 ping-pong kernel for every M > 4.  Results are identical bit for bit in all modes. */
 MIXQ_API void mixq_debug_set_gemm_variant(int variant);

@@ -133,6 +133,7 @@ SIGNATURES = {
     "mixq_preprocess_weights_int8": (_i, [_vp, _vp, _sz, _sz]),
     "mixq_unprocess_weights_int8": (_i, [_vp, _vp, _sz, _sz]),
     "mixq_debug_set_gemm_variant": (None, [_i]),
+    "mixq_debug_reset": (None, []),
     "mixq_debug_set_stamp_buffer": (None, [_vp]),
     "mixq_debug_set_quant_stamp_buffer": (None, [_vp]),
     "mixq_debug_last_gemm_kernel": (ctypes.c_char_p, []),

@@ -112,6 +112,16 @@ void mixq_debug_set_quant_stamp_buffer(void* device_u64_8_per_block) { mixq::set
 
 void mixq_debug_set_gemm_variant(int variant) { mixq::set_gemm_variant(variant < 0 ? 0 : variant); }
 
+void mixq_debug_reset(void)
+{
+    // every knob of the mixq_debug_* family back to the production default (see include/mixq.h "debug / measurement")
+    g_dbg_stamps.store(nullptr);
+    mixq::set_quant_stamp_buffer(nullptr);
+    for (int v : {0 /* schedule, tile configuration, skinny K width */, 79 /* K splits over workgroups automatic */, 69, 65, 91,
+                  80 /* fpA_intB forms automatic */, 85, 840, 843, 850, 858})
+        mixq::set_gemm_variant(v);
+}
+
 const char* mixq_debug_last_gemm_kernel(void) { return mixq::last_gemm_kernel(); }
 
 const char* mixq_version(void) { return "mixq-mi355x 0.2 (gfx950)"; }
