@@ -381,6 +381,15 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
         stamp(3);
     }
 
+    if constexpr ((ABL & 128) != 0) { // probe: ~4k idle cycles per tile (every wave sleeps) -- does the launch grow by the idle time
+        __builtin_amdgcn_s_sleep(63); // (time-bound) or by less (energy-bound at the power cap: the clock rises to compensate)?
+    }
+    if constexpr ((ABL & 256) != 0) {
+        __builtin_amdgcn_s_sleep(63);
+        __builtin_amdgcn_s_sleep(63);
+        __builtin_amdgcn_s_sleep(63);
+        __builtin_amdgcn_s_sleep(63);
+    }
     if ((ABL & 16) && p.M != -1) return; // (p.M is never -1: keeps the accumulators live)
     if (EPI == EPI_INT32 || (ABL & 16)) { // debug / unfused API: raw accumulators, 16-byte stores straight from the MFMA layout
 #pragma unroll
@@ -1027,6 +1036,8 @@ hipError_t launch_gemm_pp_ablate(const GemmParams& p, int abl, hipStream_t st)
     case 21: return launch_pp_cfg<EPI_DEQUANT, true, false, 21>(p, st);
     case 32: return launch_pp_cfg<EPI_DEQUANT, true, false, 32>(p, st); // MFMA operands swapped (transposed tiles: timing only)
     case 64: return launch_pp_cfg<EPI_DEQUANT, true, false, 64>(p, st); // 2 x 16x16x64 per 32x32x32 (timing only)
+    case 128: return launch_pp_cfg<EPI_DEQUANT, true, false, 128>(p, st); // + ~4k idle cycles per tile (correct results)
+    case 256: return launch_pp_cfg<EPI_DEQUANT, true, false, 256>(p, st); // + ~16k idle cycles per tile (correct results)
     default: return launch_pp_cfg<EPI_DEQUANT, true, false, 0>(p, st);
     }
 }
