@@ -100,7 +100,12 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
             if (!FULL) off = min(off + lq * 16, koff_last) - lq * 16;
             wf[u] = (ABL & 2) ? zero4 : *reinterpret_cast<const v4i*>(wrow + off);
 #pragma unroll
-            for (int t = 0; t < MT; ++t) af[u][t] = (ABL & 1) ? zero4 : *reinterpret_cast<const v4i*>(arow[t] + off);
+            for (int t = 0; t < MT; ++t) {
+                if constexpr ((ABL & 8) != 0) // timing probe (wrong results): the qA fragment as ONE contiguous 1-KiB block
+                    af[u][t] = *reinterpret_cast<const v4i*>(p.A + ((int64_t)(t * nsteps + min(s0 + u, nsteps - 1)) << 10) + lane * 16);
+                else
+                    af[u][t] = (ABL & 1) ? zero4 : *reinterpret_cast<const v4i*>(arow[t] + off);
+            }
         }
         __builtin_amdgcn_sched_barrier(0); // every load of the batch is issued before the first MFMA (the scheduler otherwise
                                            // sinks loads between the MFMAs to save registers: ~10 in flight instead of 48)
@@ -239,6 +244,7 @@ static hipError_t launch_skinny_epi(const GemmParams& p, hipStream_t st)
         case 2: return launch_skinny_kw<EPI, 4, 2>(p, st);
         case 3: return launch_skinny_kw<EPI, 4, 3>(p, st);
         case 4: return launch_skinny_kw<EPI, 4, 4>(p, st);
+        case 5: return launch_skinny_kw<EPI, 4, 8>(p, st);   // qA fragments as contiguous 1-KiB blocks (timing only)
         default: return launch_skinny_kw<EPI, 4, 7>(p, st);
         }
     }
