@@ -521,9 +521,15 @@ static hipError_t launch_epi(const GemmParams& p, hipStream_t st)
 // (The persistent ping-pong experiment of round 1 -- measured to lose -- lives in tools/experimental/, not in the library.)
 // Set through mixq_debug_set_gemm_variant() (tests, A/B measurements) or MIXQ_GEMM_VARIANT=v1|pp in the environment.
 static std::atomic<int> g_variant{-1};
+static std::atomic<int> g_qa_frag{1};
+bool qa_frag_enabled() { return g_qa_frag.load() != 0; }
 
 void set_gemm_variant(int v)
 {
+    if (v == 890 || v == 891) { // fragment-major qA for mixq_enqueue's decode batches: 890 off (row-major), 891 on (default)
+        g_qa_frag.store(v == 891 ? 1 : 0);
+        return;
+    }
     if (v >= 92 && v <= 99) { // skinny-kernel ablations (measurement only, wrong results): 92 + ABL - 1
         set_skinny_kw(21 + (v - 92));
         g_force_cfg.store(-1);
@@ -638,9 +644,16 @@ bool gemm_tp_fused_supported(int M, int N, int K, int O)
     return tiles256 >= 96 && wg64 > 768;
 }
 
+bool gemm_takes_skinny(const GemmParams& p, int epi)
+{
+    const bool xsplit_wins = epi != EPI_INT32 && p.splitk_ws != nullptr && p.K >= 8192 && gemm_xsplit_factor(p.M, p.N, p.K) != 0;
+    return gemm_variant() != 1 && !xsplit_wins && gemm_skinny_supported(p) && (p.M <= 16 || (p.M <= 32 && p.N < 8192));
+}
+
 hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st)
 {
     if (p.M <= 0 || p.N <= 0) return hipSuccess;
+    if (p.a_frag && !gemm_takes_skinny(p, epi)) return hipErrorInvalidValue; // (only the skinny kernel reads that image)
     const int variant = gemm_variant();
     auto chose = [](const char* name) { g_last_kernel.store(name, std::memory_order_relaxed); };
     // M <= 16, and M <= 32 on narrow outputs: the weight-streaming GEMV-like kernel (measured against the split-K tiles)

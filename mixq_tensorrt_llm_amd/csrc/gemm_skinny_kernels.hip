@@ -20,7 +20,7 @@
 namespace mixq {
 
 // ABL: measurement-only ablations (wrong results): 1 = no qA loads, 2 = no weight loads, 4 = no epilogue operand loads.
-template <int MT, int EPI, int KW, int ABL = 0>
+template <int MT, int EPI, int KW, int ABL = 0, bool AFRAG = false>
 __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p)
 {
     __shared__ v4i part[KW][MT][64]; // [K part][m tile][lane]
@@ -101,8 +101,9 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
             wf[u] = (ABL & 2) ? zero4 : *reinterpret_cast<const v4i*>(wrow + off);
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
-                if constexpr ((ABL & 8) != 0) // timing probe (wrong results): the qA fragment as ONE contiguous 1-KiB block
-                    af[u][t] = *reinterpret_cast<const v4i*>(p.A + ((int64_t)(t * nsteps + min(s0 + u, nsteps - 1)) << 10) + lane * 16);
+                if (AFRAG) // fragment-major qA (quant_kernels.hip FRAG): block (m tile, k-step), lane l at l * 16 -- ONE
+                           // contiguous 1-KiB read; the row-major form touches 16 rows x 64 B, 4 KiB apart (7.9 vs 5.4 us)
+                    af[u][t] = (ABL & 1) ? zero4 : *reinterpret_cast<const v4i*>(p.A + ((int64_t)(t * nsteps + su) << 10) + lane * 16);
                 else
                     af[u][t] = (ABL & 1) ? zero4 : *reinterpret_cast<const v4i*>(arow[t] + off);
             }
@@ -218,6 +219,15 @@ static hipError_t launch_skinny_kw(const GemmParams& p, hipStream_t st)
 {
     const dim3 grid((unsigned)((p.N + 15) / 16)), block(KW * 64);
     const int mt = (p.M + 15) / 16;
+    if constexpr (KW == 4 && ABL == 0 && EPI == EPI_DEQUANT) {
+        if (p.a_frag) { // (mixq_enqueue's decode batches: M <= 32)
+            if (mt == 1) hipLaunchKernelGGL((gemm_skinny_kernel<1, EPI, KW, 0, true>), grid, block, 0, st, p);
+            else if (mt == 2) hipLaunchKernelGGL((gemm_skinny_kernel<2, EPI, KW, 0, true>), grid, block, 0, st, p);
+            else return hipErrorInvalidValue;
+            return hipGetLastError();
+        }
+    }
+    if (p.a_frag) return hipErrorInvalidValue;
     switch (mt) {
     case 1: hipLaunchKernelGGL((gemm_skinny_kernel<1, EPI, KW, ABL>), grid, block, 0, st, p); break;
     case 2: hipLaunchKernelGGL((gemm_skinny_kernel<2, EPI, KW, ABL>), grid, block, 0, st, p); break;
@@ -237,6 +247,10 @@ static hipError_t launch_skinny_epi(const GemmParams& p, hipStream_t st)
     //  four times the weight registers in flight per wave; the int8 fragments are half the bytes of the fp16 ones to begin with.
     //  Rotating the K-step order per workgroup, so that the workgroups do not all ask for the same qA lines at the same moment:
     //  no change either -- 7.9-8.2 vs 8.3-8.7 us at M = 32 on 4096 x 4096 -- the L2 serves the broadcast.)
+    if (p.a_frag) { // fragment-major qA (mixq_enqueue's decode batches): the one configuration that reads that image
+        if constexpr (EPI == EPI_DEQUANT) return launch_skinny_kw<EPI, 4>(p, st);
+        return hipErrorInvalidValue;
+    }
     int kw = g_skinny_kw.load();
     if (EPI == EPI_DEQUANT && kw >= 21 && kw <= 28) { // measurement-only ablations (variant 40 + 20 + ABL): wrong results
         switch (kw - 20) {
@@ -244,7 +258,6 @@ static hipError_t launch_skinny_epi(const GemmParams& p, hipStream_t st)
         case 2: return launch_skinny_kw<EPI, 4, 2>(p, st);
         case 3: return launch_skinny_kw<EPI, 4, 3>(p, st);
         case 4: return launch_skinny_kw<EPI, 4, 4>(p, st);
-        case 5: return launch_skinny_kw<EPI, 4, 8>(p, st);   // qA fragments as contiguous 1-KiB blocks (timing only)
         default: return launch_skinny_kw<EPI, 4, 7>(p, st);
         }
     }

@@ -118,7 +118,7 @@ void mixq_debug_reset(void)
     g_dbg_stamps.store(nullptr);
     mixq::set_quant_stamp_buffer(nullptr);
     for (int v : {0 /* schedule, tile configuration, skinny K width */, 79 /* K splits over workgroups automatic */, 69, 65, 91,
-                  80 /* fpA_intB forms automatic */, 85, 840, 843, 850, 858})
+                  80 /* fpA_intB forms automatic */, 85, 840, 843, 850, 858, 891 /* fragment-major qA on */})
         mixq::set_gemm_variant(v);
 }
 
@@ -250,6 +250,18 @@ int mixq_supports_format_combination(const mixq_handle*, int pos, const mixq_ten
 int mixq_get_output_data_type(const mixq_handle*, int) { return MIXQ_TYPE_HALF; }
 
 // ------------------------------------------------------------------------------------------ workspace ---
+// Bytes of the qA region of the workspace carve for a call with M rows: M x K row-major -- or, for decode batches, room for the
+// skinny GEMM's fragment-major image (whole 16-row tiles x whole 64-byte k-steps: quant_kernels.hip FRAG), whichever is larger.
+static size_t qa_region_bytes(int64_t M, int64_t K)
+{
+    size_t b = (size_t)M * (size_t)K;
+    if (M > kSmallMFastPath && M <= 64) {
+        const size_t f = (size_t)((M + 15) / 16 * 16) * (size_t)((K + 63) / 64 * 64);
+        if (f > b) b = f;
+    }
+    return b;
+}
+
 // Exchange scratch ONE mixq_enqueue call with exactly M rows carves behind fpA (the K splits over workgroups of
 // gemm_pp_kernels.hip / gemm_kernels.hip): the 256x256 form's from 256 rows on, the small-tile form's below that.
 // enqueue_impl and the workspace bound below both go through this function, so they cannot disagree.
@@ -293,7 +305,11 @@ size_t mixq_workspace_size(const mixq_handle*, int64_t maxM, int64_t N, int64_t 
 {
     if (maxM <= 0 || K <= 0) return kWorkspaceAlign;
     size_t s = kWorkspaceAlign; // slack for aligning the base like nextWorkspacePtr(ptr, 0)
-    s += align_up((size_t)maxM * (size_t)K, kWorkspaceAlign);                                 // qA
+    {   // qA: the largest region any M <= maxM carves (decode batches may hold the padded fragment-major image)
+        size_t q = qa_region_bytes(maxM, K);
+        const size_t q64 = qa_region_bytes(maxM < 64 ? maxM : 64, K);
+        s += align_up(q > q64 ? q : q64, kWorkspaceAlign);
+    }
     s += align_up((size_t)maxM * sizeof(uint16_t), kWorkspaceAlign);                          // sA
     s += align_up((size_t)maxM * (size_t)kNumOutliers * sizeof(uint16_t), kWorkspaceAlign);   // fpA
     // exchange scratch of the K splits over workgroups (csrc/gemm_pp_kernels.hip, gemm_kernels.hip): only what a call
@@ -535,9 +551,21 @@ int mixq_gemm_mixed(const int8_t* qA, const int8_t* W, const void* sA, const voi
     return mixq_gemm_mixed_scratch(qA, W, sA, sW, fpA, fpW, Out, M, N, K, O, nullptr, 0, stream);
 }
 
+static int gemm_mixed_impl(const int8_t* qA, const int8_t* W, const void* sA, const void* sW, const void* fpA, const void* fpW,
+                           void* Out, int M, int N, int K, int O, void* scratch, size_t scratch_bytes, void* stream,
+                           bool a_frag);
+
 int mixq_gemm_mixed_scratch(const int8_t* qA, const int8_t* W, const void* sA, const void* sW, const void* fpA,
                             const void* fpW, void* Out, int M, int N, int K, int O, void* scratch, size_t scratch_bytes,
                             void* stream)
+{
+    return gemm_mixed_impl(qA, W, sA, sW, fpA, fpW, Out, M, N, K, O, scratch, scratch_bytes, stream, false);
+}
+
+// a_frag: qA is the skinny GEMM's fragment-major image (enqueue's decode batches only; the public entry is row-major)
+static int gemm_mixed_impl(const int8_t* qA, const int8_t* W, const void* sA, const void* sW, const void* fpA, const void* fpW,
+                           void* Out, int M, int N, int K, int O, void* scratch, size_t scratch_bytes, void* stream,
+                           bool a_frag)
 {
     if (M < 0 || N < 0 || K <= 0 || O < 0) return MIXQ_E_BADARG;
     if (M == 0 || N == 0) return MIXQ_OK;
@@ -554,6 +582,7 @@ int mixq_gemm_mixed_scratch(const int8_t* qA, const int8_t* W, const void* sA, c
     if (!p.zeros) return MIXQ_E_HIP;
     p.M = M, p.N = N, p.K = K;
     p.dbg = g_dbg_stamps.load(std::memory_order_relaxed);
+    p.a_frag = a_frag ? 1 : 0;
     if (scratch && aligned16(scratch) && scratch_bytes >= gemm_scratch_bytes(M, N, K)) p.splitk_ws = scratch;
     if (O <= kNumOutliers) {
         p.fpA = static_cast<const uint16_t*>(fpA), p.fpW = static_cast<const uint16_t*>(fpW), p.O = O;
@@ -697,7 +726,7 @@ static int enqueue_impl(const mixq_handle* h, const mixq_tensor_desc* inputDesc,
         // workspace carve, same order and 128-B alignment as TsinghuaMixQPlugin.cpp:404-421
         uintptr_t base = align_up(reinterpret_cast<uintptr_t>(workspace), kWorkspaceAlign);
         int8_t* qA = reinterpret_cast<int8_t*>(base);
-        base = align_up(base + (size_t)M * (size_t)K, kWorkspaceAlign);
+        base = align_up(base + qa_region_bytes(M, K), kWorkspaceAlign);
         void* sA = reinterpret_cast<void*>(base);
         base = align_up(base + (size_t)M * sizeof(uint16_t), kWorkspaceAlign);
         void* fpA = reinterpret_cast<void*>(base);
@@ -716,12 +745,21 @@ static int enqueue_impl(const mixq_handle* h, const mixq_tensor_desc* inputDesc,
         }
         if (K % 8) return MIXQ_E_SHAPE;
         if (!aligned16(A)) return MIXQ_E_ALIGN;
+        // decode batches that the weight-streaming skinny GEMM serves: the quantiser writes qA in that kernel's MFMA fragment
+        // order, so that each of its qA loads is one contiguous 1-KiB read (profiles/r03_small_m_timeline.txt)
+        bool frag = false;
+        if (M <= 32 && K % 16 == 0 && N % 16 == 0 && mixq::qa_frag_enabled() && mixq::quant_frag_layout_supported((int)M, (int)K)) {
+            mixq::GemmParams probe{};
+            probe.M = (int)M, probe.N = (int)N, probe.K = (int)K, probe.O = kNumOutliers;
+            probe.splitk_ws = scratch;
+            frag = mixq::gemm_takes_skinny(probe, mixq::EPI_DEQUANT);
+        }
         int rc = hip_rc(mixq::launch_quant_extract(const_cast<void*>(A), qA, sA, fpA, ind, (int)M, (int)K, kNumOutliers,
-                                                   false, st, scratch));
+                                                   false, st, scratch, frag));
         if (rc != MIXQ_OK) return rc;
         if (ev_gemm_start && hipEventRecord(static_cast<hipEvent_t>(ev_gemm_start), st) != hipSuccess) return MIXQ_E_HIP;
-        rc = mixq_gemm_mixed_scratch(qA, W, sA, scale_b, fpA, fp_weight, Out, (int)M, (int)N, (int)K, kNumOutliers,
-                                     scratch, scratch_bytes, stream);
+        rc = gemm_mixed_impl(qA, W, sA, scale_b, fpA, fp_weight, Out, (int)M, (int)N, (int)K, kNumOutliers, scratch,
+                             scratch_bytes, stream, frag);
         if (ev_gemm_stop && hipEventRecord(static_cast<hipEvent_t>(ev_gemm_stop), st) != hipSuccess) return MIXQ_E_HIP;
         return rc;
     }

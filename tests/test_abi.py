@@ -132,10 +132,13 @@ def test_workspace_sized_once_covers_every_smaller_m(lib, N, K, maxM):
     def up(v, a=128):
         return (v + a - 1) // a * a
 
+    def qa(m):   # qA region: row-major, or (decode batches) whole 16-row tiles x whole 64-byte k-steps of the fragment-major image
+        return max(m * K, up(m, 16) * up(K, 64)) if 4 < m <= 64 else m * K
+
     worst = 0
     for m in range(5, maxM + 1):
         scratch = lib.mixq_enqueue_scratch_size(m, N, K)
-        carve = 127 + up(m * K) + up(2 * m) + up(2 * 128 * m) + scratch   # unaligned base, 128-B carve of each region
+        carve = 127 + up(qa(m)) + up(2 * m) + up(2 * 128 * m) + scratch   # unaligned base, 128-B carve of each region
         assert carve <= ws, (m, scratch, ws)
         worst = max(worst, scratch)
     # and the bound is tight: it is the largest per-M scratch, not the shape-independent 64 MiB

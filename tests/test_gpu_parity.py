@@ -580,3 +580,33 @@ def test_enqueue_is_capturable_in_a_hip_graph(oracle, M):
         torch.cuda.synchronize()
         eager = run_enqueue(A2, p)
         assert np.array_equal(bits(out.cpu().numpy().reshape(M, N)), bits(eager)), "graph replay == eager launch"
+
+
+@pytest.mark.parametrize("M,N,K", [(5, 4096, 4096), (16, 4096, 4096), (17, 4096, 4096), (32, 4096, 4096), (31, 3584, 3584),
+                                   (32, 512, 2064), (9, 12288, 4096), (24, 1024, 8192), (32, 4096, 1088)])
+def test_enqueue_decode_batches_fragment_major_qa(oracle, variant, M, N, K):
+    """Round 3: for decode batches that the weight-streaming skinny GEMM serves, mixq_enqueue's quantiser writes qA in that
+    kernel's MFMA fragment order (one contiguous 1-KiB read per fragment load instead of 16 rows x 64 B).  The operator must
+    give the SAME BITS as with the row-major image (knob 890) and match the oracle element by element -- whole and ragged 16-row
+    tiles, K % 64 != 0 (2064: the last k-step is partial), shapes outside the layout's domain (K <= 1024, K = 8192 with scratch:
+    row-major either way)."""
+    A, W, act = make_layer(M, N, K, seed=3 * M + N + K)
+    if K % 64 == 0:
+        p = oracle.pack_linear_weights(W, act)
+    else:   # (the decode-path `qweight` image needs whole 64-row tiles; the prefill path does not read it)
+        sW = oracle.weight_scales(W)
+        ind = oracle.select_outliers(act, 128)
+        p = dict(weight=oracle.quantize_weight(W, sW, ind), weights_scaling_factor=sW,
+                 fp_weight=np.ascontiguousarray(W[:, ind]), fp_ind=ind, qweight=np.zeros((K, N), np.uint8))
+    want, parts = oracle.linear_prefill(A, p["weight"], p["weights_scaling_factor"], p["fp_weight"], p["fp_ind"],
+                                        return_parts=True)
+    variant(891)
+    got = run_enqueue(A, p)
+    variant(890)
+    try:
+        ref = run_enqueue(A, p)
+    finally:
+        variant(891)
+    assert_bits_equal(got, ref, f"fragment-major vs row-major qA {M}x{N}x{K}")
+    assert rel_err(got, want) < REL_TOL
+    assert_elementwise(got, want, prefill_slack(parts), f"decode batch {M}x{N}x{K}")
