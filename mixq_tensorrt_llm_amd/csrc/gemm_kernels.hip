@@ -521,11 +521,16 @@ static hipError_t launch_epi(const GemmParams& p, hipStream_t st)
 // (The persistent ping-pong experiment of round 1 -- measured to lose -- lives in tools/experimental/, not in the library.)
 // Set through mixq_debug_set_gemm_variant() (tests, A/B measurements) or MIXQ_GEMM_VARIANT=v1|pp in the environment.
 static std::atomic<int> g_variant{-1};
+static std::atomic<int> g_skinny_wide{0};
 static std::atomic<int> g_qa_frag{1};
 bool qa_frag_enabled() { return g_qa_frag.load() != 0; }
 
 void set_gemm_variant(int v)
 {
+    if (v == 892 || v == 893) { // probe: the skinny kernel for every N up to 32 rows (892) / the measured rule (893, default)
+        g_skinny_wide.store(v == 892 ? 1 : 0);
+        return;
+    }
     if (v == 890 || v == 891) { // fragment-major qA for mixq_enqueue's decode batches: 890 off (row-major), 891 on (default)
         g_qa_frag.store(v == 891 ? 1 : 0);
         return;
@@ -647,21 +652,23 @@ bool gemm_tp_fused_supported(int M, int N, int K, int O)
 bool gemm_takes_skinny(const GemmParams& p, int epi)
 {
     const bool xsplit_wins = epi != EPI_INT32 && p.splitk_ws != nullptr && p.K >= 8192 && gemm_xsplit_factor(p.M, p.N, p.K) != 0;
-    return gemm_variant() != 1 && !xsplit_wins && gemm_skinny_supported(p) && (p.M <= 16 || (p.M <= 32 && p.N < 8192));
+    return gemm_variant() != 1 && !xsplit_wins && gemm_skinny_supported(p) &&
+           (p.M <= 16 || (p.M <= 32 && (p.N < 10240 || g_skinny_wide.load() != 0))); // (round 3, fragment-major qA: N = 8192 15.9 -> 13.8 us;
+                                                                                   //  from 11008 the two-barrier tiles are equal or ahead)
 }
 
 hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st)
 {
     if (p.M <= 0 || p.N <= 0) return hipSuccess;
-    if (p.a_frag && !gemm_takes_skinny(p, epi)) return hipErrorInvalidValue; // (only the skinny kernel reads that image)
+    if (p.a_frag == 1 && !gemm_takes_skinny(p, epi)) return hipErrorInvalidValue; // (only the skinny kernel reads that image)
+    if (p.a_frag == 2 && !(epi == EPI_DEQUANT && gemm_tp_fused_supported(p.M, p.N, p.K, p.O))) return hipErrorInvalidValue;
+    if (p.a_frag < 0 || p.a_frag > 2) return hipErrorInvalidValue;
     const int variant = gemm_variant();
     auto chose = [](const char* name) { g_last_kernel.store(name, std::memory_order_relaxed); };
     // M <= 16, and M <= 32 on narrow outputs: the weight-streaming GEMV-like kernel (measured against the split-K tiles)
     // ... unless K is long and the tiles are few: then the small tiles with K split over workgroups win (M = 24 / 32 on
     // 4096 x 11008: 14 vs 18 us; on 1024 x 28672: 17 vs 39 us)
-    const bool xsplit_wins = epi != EPI_INT32 && p.splitk_ws != nullptr && p.K >= 8192 &&
-                             gemm_xsplit_factor(p.M, p.N, p.K) != 0;
-    if (variant != 1 && !xsplit_wins && gemm_skinny_supported(p) && (p.M <= 16 || (p.M <= 32 && p.N < 8192))) {
+    if (gemm_takes_skinny(p, epi)) {
         chose("gemm_skinny_kernel");
         return launch_gemm_skinny(p, epi, st);
     }

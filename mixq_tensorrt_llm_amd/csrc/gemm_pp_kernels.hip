@@ -171,7 +171,13 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
     // Address = wave-uniform 64-bit base (tile origin + slice offset, SGPRs) + constant per-thread 32-bit offset.
     const int64_t K = p.K;
     const char* const baseB = reinterpret_cast<const char*>(p.B) + ((ABL & 8) ? 0 : (int64_t)n0 * K);
-    const char* const baseA = reinterpret_cast<const char*>(p.A) + ((ABL & 8) ? 0 : (int64_t)m0 * K);
+    // A (qA) layout: row-major [M][K], or -- p.a_frag == 2, written by the quantiser for this kernel -- K-SLICE-MAJOR
+    // [K / 128][M][128 B]: the 8 consecutive rows one LDS-DMA instruction copies are then 1 KiB contiguous instead of 8
+    // segments K bytes apart (the same lever as the skinny kernel's fragment-major image)
+    const bool a_slices = (ABL & 512) != 0 || p.a_frag == 2;
+    const char* const baseA = reinterpret_cast<const char*>(p.A) +
+                              ((ABL & 8) ? 0 : a_slices ? (int64_t)m0 * KS : (int64_t)m0 * K);
+    const int64_t a_slice_stride = a_slices ? (int64_t)p.M * KS : (int64_t)KS; // bytes from one K slice of A to the next
     unsigned off[4][2];
     int koff_src;
     {
@@ -187,7 +193,7 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
                                       : (q >> 6) * 128 + h * 64 + (q & 63);
                 const int rn = min(n0 + nl, p.N - 1) - n0, rm = min(m0 + ml, p.M - 1) - m0; // clamped rows, >= 0
                 off[h][i] = (unsigned)rn * (unsigned)p.K + ((slot ^ sw) << 4);
-                off[2 + h][i] = (unsigned)rm * (unsigned)p.K + ((slot ^ sw) << 4);
+                off[2 + h][i] = (unsigned)rm * (a_slices ? (unsigned)KS : (unsigned)p.K) + ((slot ^ sw) << 4);
             }
         koff_src = (slot ^ (((tid >> 3) >> 1) & 7)) << 4; // same for i = 0,1 (64 rows apart)
     }
@@ -202,7 +208,7 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
     auto issue = [&](int region, int kt, bool tailchk) __attribute__((always_inline)) {
         if (ABL & 1) return;
         const unsigned dst = lds0 + (kt & 1) * BUF + region * REGION;
-        const char* base = (region < 2 ? baseB : baseA) + (int64_t)kt * KS; // scalar
+        const char* base = region < 2 ? baseB + (int64_t)kt * KS : baseA + (int64_t)kt * a_slice_stride; // scalar
         if (tailchk && ktail) {
             const bool oob = (int64_t)kt * KS + koff_src >= K;
 #pragma unroll
@@ -1036,6 +1042,7 @@ hipError_t launch_gemm_pp_ablate(const GemmParams& p, int abl, hipStream_t st)
     case 21: return launch_pp_cfg<EPI_DEQUANT, true, false, 21>(p, st);
     case 32: return launch_pp_cfg<EPI_DEQUANT, true, false, 32>(p, st); // MFMA operands swapped (transposed tiles: timing only)
     case 64: return launch_pp_cfg<EPI_DEQUANT, true, false, 64>(p, st); // 2 x 16x16x64 per 32x32x32 (timing only)
+    case 512: return launch_pp_cfg<EPI_DEQUANT, true, false, 512>(p, st); // probe: A read as K-slice-major (timing only)
     case 128: return launch_pp_cfg<EPI_DEQUANT, true, false, 128>(p, st); // + ~4k idle cycles per tile (correct results)
     case 256: return launch_pp_cfg<EPI_DEQUANT, true, false, 256>(p, st); // + ~16k idle cycles per tile (correct results)
     default: return launch_pp_cfg<EPI_DEQUANT, true, false, 0>(p, st);

@@ -553,19 +553,20 @@ int mixq_gemm_mixed(const int8_t* qA, const int8_t* W, const void* sA, const voi
 
 static int gemm_mixed_impl(const int8_t* qA, const int8_t* W, const void* sA, const void* sW, const void* fpA, const void* fpW,
                            void* Out, int M, int N, int K, int O, void* scratch, size_t scratch_bytes, void* stream,
-                           bool a_frag);
+                           int a_frag);
 
 int mixq_gemm_mixed_scratch(const int8_t* qA, const int8_t* W, const void* sA, const void* sW, const void* fpA,
                             const void* fpW, void* Out, int M, int N, int K, int O, void* scratch, size_t scratch_bytes,
                             void* stream)
 {
-    return gemm_mixed_impl(qA, W, sA, sW, fpA, fpW, Out, M, N, K, O, scratch, scratch_bytes, stream, false);
+    return gemm_mixed_impl(qA, W, sA, sW, fpA, fpW, Out, M, N, K, O, scratch, scratch_bytes, stream, 0);
 }
 
-// a_frag: qA is the skinny GEMM's fragment-major image (enqueue's decode batches only; the public entry is row-major)
+// a_frag: layout of qA (GemmParams::a_frag): enqueue's own quantiser may write the consuming kernel's preferred image; the
+// public entries take row-major qA
 static int gemm_mixed_impl(const int8_t* qA, const int8_t* W, const void* sA, const void* sW, const void* fpA, const void* fpW,
                            void* Out, int M, int N, int K, int O, void* scratch, size_t scratch_bytes, void* stream,
-                           bool a_frag)
+                           int a_frag)
 {
     if (M < 0 || N < 0 || K <= 0 || O < 0) return MIXQ_E_BADARG;
     if (M == 0 || N == 0) return MIXQ_OK;
@@ -582,7 +583,7 @@ static int gemm_mixed_impl(const int8_t* qA, const int8_t* W, const void* sA, co
     if (!p.zeros) return MIXQ_E_HIP;
     p.M = M, p.N = N, p.K = K;
     p.dbg = g_dbg_stamps.load(std::memory_order_relaxed);
-    p.a_frag = a_frag ? 1 : 0;
+    p.a_frag = a_frag;
     if (scratch && aligned16(scratch) && scratch_bytes >= gemm_scratch_bytes(M, N, K)) p.splitk_ws = scratch;
     if (O <= kNumOutliers) {
         p.fpA = static_cast<const uint16_t*>(fpA), p.fpW = static_cast<const uint16_t*>(fpW), p.O = O;
@@ -747,12 +748,15 @@ static int enqueue_impl(const mixq_handle* h, const mixq_tensor_desc* inputDesc,
         if (!aligned16(A)) return MIXQ_E_ALIGN;
         // decode batches that the weight-streaming skinny GEMM serves: the quantiser writes qA in that kernel's MFMA fragment
         // order, so that each of its qA loads is one contiguous 1-KiB read (profiles/r03_small_m_timeline.txt)
-        bool frag = false;
+        // (Large calls keep the row-major image: a K-slice-major one -- 8 consecutive rows of a 128-byte slice contiguous, one LDS-DMA
+        //  instruction = one 1-KiB read -- was built and measured on one box: GEMM -0.3 %, quantiser +7.6 % (its row becomes 32
+        //  scattered 128-byte stores), prefill tokens/s -0.35 %: docs/LAB_NOTEBOOK.md R3.10.)
+        int frag = 0;
         if (M <= 32 && K % 16 == 0 && N % 16 == 0 && mixq::qa_frag_enabled() && mixq::quant_frag_layout_supported((int)M, (int)K)) {
             mixq::GemmParams probe{};
             probe.M = (int)M, probe.N = (int)N, probe.K = (int)K, probe.O = kNumOutliers;
             probe.splitk_ws = scratch;
-            frag = mixq::gemm_takes_skinny(probe, mixq::EPI_DEQUANT);
+            frag = mixq::gemm_takes_skinny(probe, mixq::EPI_DEQUANT) ? 1 : 0;
         }
         int rc = hip_rc(mixq::launch_quant_extract(const_cast<void*>(A), qA, sA, fpA, ind, (int)M, (int)K, kNumOutliers,
                                                    false, st, scratch, frag));

@@ -72,8 +72,9 @@ struct GemmParams {
     void* D;              // fp16 [M,N] (EPI_DEQUANT*) or int32 [M,N] (EPI_INT32)
     const void* zeros;    // >= 16 B of device zeros (K / O tails)
     int M, N, K, O;
-    int a_frag;           // 1: A is NOT row-major but the skinny GEMM's fragment-major image (quant_kernels.hip, FRAG); only valid
-                          // when gemm_takes_skinny(p, epi) -- mixq_enqueue's decode-batch route
+    int a_frag;           // layout of A: 0 row-major | 1 the skinny GEMM's fragment-major image (only valid when gemm_takes_skinny) |
+                          // 2 K-slice-major [K/128][M][128 B] (read by the plain 256 x 256 ping-pong kernel only; no producer ships:
+                          // measured a net loss, docs/LAB_NOTEBOOK.md R3.10); 1 is written by mixq_enqueue's quantiser (FRAG)
     void* dbg;            // measurement only: 8 x uint64 s_memtime stamps per block (ping-pong kernel), else null
     int xsplit;           // (set by launch_epi) workgroups per tile of the small-tile kernels' K split, else 0
     int splitk_solo;      // (set by launch_gemm_pp_splitk) leading tiles that are not split
@@ -136,7 +137,7 @@ hipError_t launch_dequantization_silu(void* out, const int32_t* x, const void* s
 hipError_t launch_quant_extract(void* A, int8_t* qA, void* sA, void* fpA, const int32_t* ind, int M, int K, int O,
                                 bool zero, hipStream_t st,
                                 void* zero_words = nullptr, // (kSplitkWordsBytes to clear on the way, or null)
-                                bool frag = false); // qA in the skinny GEMM's fragment order (quant_frag_layout_supported only)
+                                int frag = 0); // qA layout: 0 row-major | 1 the skinny GEMM's fragment order (quant_frag_layout_supported)
 bool quant_frag_layout_supported(int M, int K);   // the quantiser can write the fragment-major image for this shape
 bool gemm_takes_skinny(const GemmParams& p, int epi);
 bool qa_frag_enabled(); // test knob 890 / 891 (default on) // launch_gemm would run gemm_skinny_kernel on this problem

@@ -24,7 +24,9 @@ constexpr int QBLOCK = 256;
 // and 64-byte k-step s, the 1-KiB block t * ceil(K / 64) + s holds lane l's 16 bytes (row t * 16 + l % 16, k = s * 64 + (l / 16)
 // * 16 ...) at l * 16 -- so that a fragment load of gemm_skinny_kernel is ONE contiguous 1-KiB read instead of 16 rows x 64
 // bytes 4 KiB apart (gemm_skinny_kernels.hip; 32 x 4096 x 4096: GEMM 7.9 -> 5.4 us).
-template <int TPR, int MAXV, bool ZERO, bool FRAG = false>
+// (A K-slice-major image [K / 128][M][128 B] for the 256 x 256 ping-pong GEMM was FRAG == 2 for one build: GEMM -0.3 %, this kernel
+//  +7.6 %, end to end -0.35 %: removed; the GEMM keeps its reader, ablation 512.)
+template <int TPR, int MAXV, bool ZERO, int FRAG = 0>
 __global__ __launch_bounds__(QBLOCK) void quant_extract_kernel(uint16_t* __restrict__ A, int8_t* __restrict__ qA,
                                                                uint16_t* __restrict__ sA, uint16_t* __restrict__ fpA,
                                                                const int32_t* __restrict__ ind, int M, int K, int O,
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(QBLOCK) void quant_extract_kernel(uint16_t* __restr
     uint2* __restrict__ dst = reinterpret_cast<uint2*>(qA + (row_ok ? row : 0) * (int64_t)K);
     // 8-byte group idx (k = 8 idx .. 8 idx + 7) of this row -> its place in the image
     auto slot = [&](int idx) __attribute__((always_inline)) -> uint2* {
-        if (!FRAG) return dst + idx;
+        if (FRAG == 0) return dst + idx;
         const int64_t r = row_ok ? row : 0;
         const int nsteps = (K + 63) >> 6;
         const int64_t blk = (r >> 4) * nsteps + (idx >> 3);                               // (tile, k-step)
@@ -292,16 +294,17 @@ void set_quant_stamp_buffer(void* p) { g_quant_stamps.store(p); }
 
 template <int TPR, int MAXV>
 static hipError_t launch_qe(uint16_t* A, int8_t* qA, uint16_t* sA, uint16_t* fpA, const int32_t* ind, int M, int K,
-                            int O, bool zero, hipStream_t st, unsigned* zw, bool frag = false)
+                            int O, bool zero, hipStream_t st, unsigned* zw, int frag = 0)
 {
     void* const dbg = g_quant_stamps.load(std::memory_order_relaxed);
     if constexpr (TPR == 256 && MAXV <= 4) {
-        if (frag && !zero) { // decode batches of mixq_enqueue: qA in the skinny GEMM's fragment order
+        if (frag == 1 && !zero) { // decode batches of mixq_enqueue: qA in the skinny GEMM's fragment order
             dim3 grid((unsigned)M), block(QBLOCK);
-            hipLaunchKernelGGL((quant_extract_kernel<TPR, MAXV, false, true>), grid, block, 0, st, A, qA, sA, fpA, ind, M, K, O, zw, dbg);
+            hipLaunchKernelGGL((quant_extract_kernel<TPR, MAXV, false, 1>), grid, block, 0, st, A, qA, sA, fpA, ind, M, K, O, zw, dbg);
             return hipGetLastError();
         }
     }
+    if (frag != 0) return hipErrorInvalidValue;
     constexpr int RPB = QBLOCK / TPR;
     dim3 grid((unsigned)((M + RPB - 1) / RPB)), block(QBLOCK);
     if (zero) {
@@ -316,9 +319,10 @@ static hipError_t launch_qe(uint16_t* A, int8_t* qA, uint16_t* sA, uint16_t* fpA
 bool quant_frag_layout_supported(int M, int K) { return M > 0 && M <= 64 && K % 8 == 0 && K / 8 > 64 * 2 && K / 8 <= 256 * 4; }
 
 hipError_t launch_quant_extract(void* A, int8_t* qA, void* sA, void* fpA, const int32_t* ind, int M, int K, int O,
-                                bool zero, hipStream_t st, void* zero_words, bool frag)
+                                bool zero, hipStream_t st, void* zero_words, int frag)
 {
-    if (frag && (zero || !quant_frag_layout_supported(M, K))) return hipErrorInvalidValue;
+    if (frag == 1 && (zero || !quant_frag_layout_supported(M, K))) return hipErrorInvalidValue;
+    if (frag < 0 || frag > 1) return hipErrorInvalidValue;
     if (M <= 0) return hipSuccess;
     unsigned* const zw = static_cast<unsigned*>(zero_words);
     uint16_t* a = static_cast<uint16_t*>(A);
@@ -331,12 +335,12 @@ hipError_t launch_quant_extract(void* A, int8_t* qA, void* sA, void* fpA, const 
         if (nvec <= 256 * 2) return launch_qe<256, 2>(a, qA, s, f, ind, M, K, O, zero, st, zw, frag);
         if (nvec <= 256 * 4) return launch_qe<256, 4>(a, qA, s, f, ind, M, K, O, zero, st, zw, frag);
     }
-    if (nvec <= 64 * 2) return launch_qe<64, 2>(a, qA, s, f, ind, M, K, O, zero, st, zw);
-    if (nvec <= 64 * 4) return launch_qe<64, 4>(a, qA, s, f, ind, M, K, O, zero, st, zw);
-    if (nvec <= 64 * 8) return launch_qe<64, 8>(a, qA, s, f, ind, M, K, O, zero, st, zw);
-    if (nvec <= 64 * 16) return launch_qe<64, 16>(a, qA, s, f, ind, M, K, O, zero, st, zw);
-    if (nvec <= 256 * 8) return launch_qe<256, 8>(a, qA, s, f, ind, M, K, O, zero, st, zw);
-    if (nvec <= 256 * 16) return launch_qe<256, 16>(a, qA, s, f, ind, M, K, O, zero, st, zw);
+    if (nvec <= 64 * 2) return launch_qe<64, 2>(a, qA, s, f, ind, M, K, O, zero, st, zw, frag);
+    if (nvec <= 64 * 4) return launch_qe<64, 4>(a, qA, s, f, ind, M, K, O, zero, st, zw, frag);
+    if (nvec <= 64 * 8) return launch_qe<64, 8>(a, qA, s, f, ind, M, K, O, zero, st, zw, frag);
+    if (nvec <= 64 * 16) return launch_qe<64, 16>(a, qA, s, f, ind, M, K, O, zero, st, zw, frag);
+    if (nvec <= 256 * 8) return launch_qe<256, 8>(a, qA, s, f, ind, M, K, O, zero, st, zw, frag);
+    if (nvec <= 256 * 16) return launch_qe<256, 16>(a, qA, s, f, ind, M, K, O, zero, st, zw, frag);
     dim3 grid((unsigned)M), block(QBLOCK);
     if (zero) {
         size_t sm = (size_t)((K + 31) / 32) * 4;

@@ -80,9 +80,20 @@ def ulp_histogram(got, want):
 W8A16_GAMMA = 4e-6   # fp32 accumulation of <= 28672 fp16 x fp16 products in two different orders, relative to sum |a w|
 
 
-def prefill_slack(parts):
-    """Order slack of the W8A8O16 operator: one ulp of the fp16-rounded outlier product (oracle.linear_prefill parts)."""
-    return ulp16(parts["P"])
+SIDE_GAMMA = 2.0 ** -22   # fp32 accumulation of the 128 outlier products in two different orders, relative to sum |a w|
+
+
+def prefill_slack(parts, A=None, p=None):
+    """Order slack of the W8A8O16 operator (oracle.linear_prefill parts): one ulp of the fp16-rounded outlier product P16 -- the
+    only order-dependent quantity, the int8 part being exact -- plus, when the operands are given, the fp32 accumulation error
+    of that product itself (SIDE_GAMMA x sum_j |fpA fpW|): where the 128 terms cancel to a tiny P, two summation orders can
+    differ by several ulps OF THAT TINY P (seen at 2048 x 12288 x 512: 2 of 25 M outputs, 3 ulps of a 1.6e-4 result)."""
+    slack = ulp16(parts["P"])
+    if A is not None and p is not None:
+        fa = np.abs(A[:, p["fp_ind"]].astype(np.float32))
+        fw = np.abs(p["fp_weight"].astype(np.float32))
+        slack = slack + SIDE_GAMMA * (fa @ fw.T).astype(np.float64)
+    return slack
 
 
 def w8a16_slack(A, q_rm, scale):

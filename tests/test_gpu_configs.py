@@ -47,7 +47,7 @@ def test_config0_single_4096_linear_bs32_real_act_scales(oracle):
                                         return_parts=True)
     got = run_layer(A, p)
     assert rel_err(got, want) < REL_TOL
-    assert_elementwise(got, want, prefill_slack(parts), "config 0")
+    assert_elementwise(got, want, prefill_slack(parts, A, p), "config 0")
     assert ulp_histogram(got, want)["<=1"] > 0.999
     ref = A.astype(np.float64) @ W.astype(np.float64).T
     assert rel_err(got, ref) < 0.05
@@ -66,7 +66,7 @@ def test_config1_llama2_7b_shapes(oracle, name, N, K):
     want, parts = oracle.linear_prefill(A, p["weight"], p["weights_scaling_factor"], p["fp_weight"], p["fp_ind"],
                                         return_parts=True)
     assert rel_err(got, want) < REL_TOL
-    assert_elementwise(got, want, prefill_slack(parts), f"config 1 {name}")
+    assert_elementwise(got, want, prefill_slack(parts, A, p), f"config 1 {name}")
     assert ulp_histogram(got, want)["<=1"] > 0.999
 
 
@@ -89,7 +89,7 @@ def test_config3_qwen2_7b_fpA_intB_outliers(oracle, name, N, K, bias):
     got = run_layer(A, p, b)
     want, parts = oracle.linear_prefill(A, p["weight"], p["weights_scaling_factor"], p["fp_weight"], p["fp_ind"],
                                         return_parts=True)
-    slack = prefill_slack(parts)
+    slack = prefill_slack(parts, A, p)
     if bias:   # one more fp16 addition per element after the operator: a 1-ulp difference before it can move its result by
         slack = slack + ulp16_of(want)  # one ulp of the un-biased value
         want = (want.astype(np.float16) + b[None, :]).astype(np.float16)
@@ -108,7 +108,7 @@ def test_config4_llama2_70b_tp8_shard_shapes(oracle, name, N, K):
     want, parts = oracle.linear_prefill(A, p["weight"], p["weights_scaling_factor"], p["fp_weight"], p["fp_ind"],
                                         return_parts=True)
     assert rel_err(got, want) < REL_TOL
-    assert_elementwise(got, want, prefill_slack(parts), f"config 4 {name}")
+    assert_elementwise(got, want, prefill_slack(parts, A, p), f"config 4 {name}")
     # decode on the same shard (M = 2) through the interleaved qweight
     got2 = run_layer(A[:2], p)
     q_un = oracle.eetq_symmetric_quantize(W.T.copy())[0]
@@ -147,7 +147,9 @@ def test_bench_configuration_at_full_size_on_sampled_rows(oracle, name, N, K):
     want, parts = oracle.linear_prefill(A_s, W8.cpu().numpy(), t["weights_scaling_factor"].cpu().numpy(),
                                         t["fp_weight"].cpu().numpy(), t["ind_i32"].cpu().numpy(), return_parts=True)
     assert rel_err(got, want) < REL_TOL
-    assert_elementwise(got, want, prefill_slack(parts), f"bench configuration {name}")
+    assert_elementwise(got, want, prefill_slack(parts, A_s, dict(fp_ind=t["ind_i32"].cpu().numpy().astype(np.int64),
+                                                                 fp_weight=t["fp_weight"].cpu().numpy())),
+                       f"bench configuration {name}")
     h = ulp_histogram(got, want)
     assert h["<=1"] > 0.995, h
     # integer half of the path at full size: quantiser rows and the int32 accumulators of the 65536-row GEMM, bit for bit
