@@ -158,11 +158,14 @@ def small_m_points(lib, TensorDesc, dev, gen, st_ptr, iters=300):
         W8 = t["weight"].view(torch.int8)
         eps = ctypes.c_float(1e-6)
 
+        lay = int(lib.mixq_qa_layout(M, N, K))     # the producer writes the image the GEMM reads fastest (fragment-major here)
+        q = torch.empty(int(lib.mixq_qa_bytes(M, K, lay)), dtype=torch.int8, device=dev)
+
         def pair(st):
-            assert lib.mixq_rmsnorm_extract_quant(M, K, p(X), p(gamma), p(xn), eps, p(t["ind_i32"]), NUM_OUTLIERS, p(outl),
-                                                  p(q), p(sA), st) == 0
-            assert lib.mixq_gemm_mixed(p(q), p(W8), p(sA), p(t["weights_scaling_factor"]), p(outl), p(t["fp_weight"]),
-                                       p(o), M, N, K, NUM_OUTLIERS, st) == 0
+            assert lib.mixq_rmsnorm_extract_quant_layout(M, K, p(X), p(gamma), p(xn), eps, p(t["ind_i32"]), NUM_OUTLIERS,
+                                                         p(outl), p(q), p(sA), lay, st) == 0
+            assert lib.mixq_gemm_mixed_layout(p(q), p(W8), p(sA), p(t["weights_scaling_factor"]), p(outl), p(t["fp_weight"]),
+                                              p(o), M, N, K, NUM_OUTLIERS, lay, None, 0, st) == 0
 
         def norm_only(st):
             assert lib.mixq_rmsnorm(M, K, p(X), p(gamma), p(xn), eps, st) == 0
@@ -171,6 +174,7 @@ def small_m_points(lib, TensorDesc, dev, gen, st_ptr, iters=300):
         out["config0_norm_fused"] = {"us_per_call": t_pair - t_norm, "pair_us": t_pair, "plain_rmsnorm_us": t_norm,
                                      "weight_GBps": N * K / ((t_pair - t_norm) * 1e-6) / 1e9,
                                      "hbm_frac": N * K / ((t_pair - t_norm) * 1e-6) / 8e12, "launches_per_call": 1,
+                                     "qa_layout": "fragment-major" if lay else "row-major",
                                      "what": "fused RMSNorm -> extract -> quant producer + fused GEMM, minus the plain "
                                              "RMSNorm the model runs anyway (the linear's marginal cost on the P-flavour "
                                              "decode route)"}

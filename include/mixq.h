@@ -186,15 +186,42 @@ MIXQ_API size_t mixq_gemm_scratch_bound(void);
 MIXQ_API int mixq_gemm_mixed_scratch(const int8_t* qA, const int8_t* W, const void* sA, const void* sW, const void* fpA,
                                      const void* fpW, void* Out, int M, int N, int K, int O, void* scratch,
                                      size_t scratch_bytes, void* stream);
+/* ---- qA layouts (MI355X extension; decode batches) --------------------------------------------------------------------------
+ * The int8 activation image between a producer (quantiser, fused norm) and the fused GEMM is the library's own intermediate,
+ * so the producer may write the layout the consuming kernel reads fastest.  ROW_MAJOR [M,K] is what every reference-named
+ * entry above produces and consumes.  FRAGMENT_MAJOR (5..32 rows, K in (1024, 8192], shapes the weight-streaming skinny GEMM
+ * serves -- mixq_qa_layout(M, N, K) decides): for 16-row tile t and 64-byte k-step s, the 1-KiB block t * ceil(K / 64) + s holds,
+ * at lane * 16, the 16 bytes (row t * 16 + lane % 16, k = s * 64 + (lane / 16) * 16 ...) -- each qA load of that kernel becomes one
+ * contiguous 1-KiB read instead of 16 rows x 64 bytes 4 KiB apart: 32 x 4096 x 4096 GEMM 7.9 -> 5.4 us (BASELINE configs[0]
+ * 11.8 -> 9.2 us through mixq_enqueue, which uses it internally).  The image is opaque (mixq_qa_bytes bytes, 16-byte aligned)
+ * and has ONE reader: passing it for a shape the skinny kernel does not serve returns MIXQ_E_SHAPE.  Same bits as row-major. */
+#define MIXQ_QA_ROW_MAJOR 0
+#define MIXQ_QA_FRAGMENT_MAJOR 1
+MIXQ_API int mixq_qa_layout(int M, int N, int K);               /* the layout to produce for a [M,K] x [N,K]^T consumer without scratch */
+MIXQ_API size_t mixq_qa_bytes(int M, int K, int layout);        /* bytes of the image */
+MIXQ_API int mixq_quant_extract_layout(int M, int K, void* A_f16, int8_t* qA, void* sA_f16, void* fpA_f16, const int32_t* ind,
+                                       int len, int zero_outliers, int q_layout, void* stream);
+MIXQ_API int mixq_rmsnorm_extract_quant_layout(int M, int K, const void* x_f16, const void* gamma_f16, void* out_f16, float eps,
+                                               const int32_t* ind, int len, void* outliers_f16, int8_t* q, void* scale_f16,
+                                               int q_layout, void* stream);
+/* int8FusedDequantize / ...Silu / ...SiluMul (epilogue 0 / 1 / 3) on a qA image of the given layout; mul NULL unless epilogue 3 */
+MIXQ_API int mixq_int8_fused_dequantize_layout(const int8_t* A, const int8_t* B, const void* scale_row, const void* scale_col,
+                                               const void* y, const void* mul, void* D, int M, int N, int K, int epilogue,
+                                               int qa_layout, char* workspace, void* stream);
+MIXQ_API int mixq_gemm_mixed_layout(const int8_t* qA, const int8_t* W, const void* sA, const void* sW, const void* fpA,
+                                    const void* fpW, void* Out, int M, int N, int K, int O, int qa_layout, void* scratch,
+                                    size_t scratch_bytes, void* stream);
 /* MixLinear_GEMM.forward (MixQ/src/mixquant/modules/linear.py:163-286, bit = 8, static outlier set) as ONE call and TWO
  * launches: the reference makes four mixlib calls per linear here (ExtractOutliersAndSetToZeros, FindRowScale, torch.mm on the
  * outliers, int8FusedDequantize); a decode step is host-bound on those calls long before it is GPU-bound
  * (profiles/r03_mixlib_overhead.txt).  x fp16 [M,K] (its `ind` columns are ZEROED, as the reference does), ind int32 [O],
  * q_weight int8 [N,K], scale_col fp16 [N], weight_cache fp16 [N,O]; outputs: x_scale fp16 [M], q_x int8 [M,K], outliers fp16
- * [M,O], out fp16 [M,N].  scratch: as mixq_gemm_mixed_scratch (may be NULL). */
+ * [M,O], out fp16 [M,N].  q_layout: MIXQ_QA_ROW_MAJOR, or -- only where mixq_qa_layout(M, N, K) says so -- FRAGMENT_MAJOR (q_x then
+ * is the opaque image of mixq_qa_bytes(M, K, 1) bytes).  scratch: as mixq_gemm_mixed_scratch (may be NULL). */
 MIXQ_API int mixq_mixlinear_forward(int M, int N, int K, int O, void* x_f16, const int32_t* ind, const int8_t* q_weight,
                                     const void* scale_col, const void* weight_cache, void* x_scale, int8_t* q_x,
-                                    void* outliers_f16, void* out_f16, void* scratch, size_t scratch_bytes, void* stream);
+                                    void* outliers_f16, void* out_f16, int q_layout, void* scratch, size_t scratch_bytes,
+                                    void* stream);
 /* gemm (TsinghuaMixQPlugin.cpp:36-77, cuBLAS s8 x s8 -> s32): raw int32 accumulators, for bit-exact checks. */
 MIXQ_API int mixq_gemm_s8s8s32(const int8_t* A, const int8_t* B, int32_t* C, int M, int N, int K, void* stream);
 /* gemmfp16 (TsinghuaMixQPlugin.cpp:122-161): Out = fpA . fpW^T, fp32 accumulate, fp16 out. */

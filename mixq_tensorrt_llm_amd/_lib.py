@@ -110,7 +110,13 @@ SIGNATURES = {
     "mixq_gemm_mixed_scratch": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, ctypes.c_size_t, _vp]),
     "mixq_int8_fused_dequantize_silu_mul": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "mixq_gemm_mixed": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "mixq_mixlinear_forward": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    "mixq_mixlinear_forward": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, ctypes.c_size_t, _vp]),
+    "mixq_qa_layout": (_i, [_i, _i, _i]),
+    "mixq_qa_bytes": (ctypes.c_size_t, [_i, _i, _i]),
+    "mixq_quant_extract_layout": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "mixq_rmsnorm_extract_quant_layout": (_i, [_i, _i, _vp, _vp, _vp, ctypes.c_float, _vp, _i, _vp, _vp, _vp, _i, _vp]),
+    "mixq_int8_fused_dequantize_layout": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "mixq_gemm_mixed_layout": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, ctypes.c_size_t, _vp]),
     "mixq_gemm_s8s8s32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "mixq_gemm_fp16": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "mixq_dequantization": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),

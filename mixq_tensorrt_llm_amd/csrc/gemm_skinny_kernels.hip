@@ -219,8 +219,8 @@ static hipError_t launch_skinny_kw(const GemmParams& p, hipStream_t st)
 {
     const dim3 grid((unsigned)((p.N + 15) / 16)), block(KW * 64);
     const int mt = (p.M + 15) / 16;
-    if constexpr (KW == 4 && ABL == 0 && EPI == EPI_DEQUANT) {
-        if (p.a_frag == 1) { // (mixq_enqueue's decode batches: M <= 32)
+    if constexpr (KW == 4 && ABL == 0 && EPI != EPI_INT32) {
+        if (p.a_frag == 1) { // (decode batches: M <= 32)
             if (mt == 1) hipLaunchKernelGGL((gemm_skinny_kernel<1, EPI, KW, 0, true>), grid, block, 0, st, p);
             else if (mt == 2) hipLaunchKernelGGL((gemm_skinny_kernel<2, EPI, KW, 0, true>), grid, block, 0, st, p);
             else return hipErrorInvalidValue;
@@ -247,8 +247,8 @@ static hipError_t launch_skinny_epi(const GemmParams& p, hipStream_t st)
     //  four times the weight registers in flight per wave; the int8 fragments are half the bytes of the fp16 ones to begin with.
     //  Rotating the K-step order per workgroup, so that the workgroups do not all ask for the same qA lines at the same moment:
     //  no change either -- 7.9-8.2 vs 8.3-8.7 us at M = 32 on 4096 x 4096 -- the L2 serves the broadcast.)
-    if (p.a_frag == 1) { // fragment-major qA (mixq_enqueue's decode batches): the one configuration that reads that image
-        if constexpr (EPI == EPI_DEQUANT) return launch_skinny_kw<EPI, 4>(p, st);
+    if (p.a_frag == 1) { // fragment-major qA (decode batches): the one configuration that reads that image
+        if constexpr (EPI != EPI_INT32) return launch_skinny_kw<EPI, 4>(p, st);
         return hipErrorInvalidValue;
     }
     int kw = g_skinny_kw.load();

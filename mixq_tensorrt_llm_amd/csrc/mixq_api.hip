@@ -426,7 +426,7 @@ int mixq_rmsnorm_extract_quant4(int M, int K, const void* x, const void* gamma, 
 
 static int fused_dequant_impl(const int8_t* A, const int8_t* B, const void* scale_row, const void* scale_col,
                               const void* y, void* D, int M, int N, int K, int epi, void* stream,
-                              const void* mul = nullptr, void* scratch = nullptr)
+                              const void* mul = nullptr, void* scratch = nullptr, int a_frag = 0)
 {
     if (M < 0 || N < 0 || K <= 0) return MIXQ_E_BADARG;
     if (M == 0 || N == 0) return MIXQ_OK;
@@ -444,6 +444,8 @@ static int fused_dequant_impl(const int8_t* A, const int8_t* B, const void* scal
     p.M = M, p.N = N, p.K = K, p.O = 0;
     if (!p.zeros) return MIXQ_E_HIP;
     if (scratch && aligned16(scratch)) p.splitk_ws = scratch; // K split over workgroups where the shape calls for it
+    p.a_frag = a_frag;
+    if (a_frag != 0 && !(a_frag == 1 && mixq::gemm_takes_skinny(p, epi))) return MIXQ_E_SHAPE; // (the image has ONE reader)
     return hip_rc(mixq::launch_gemm(p, epi, static_cast<hipStream_t>(stream)));
 }
 
@@ -596,9 +598,77 @@ static int gemm_mixed_impl(const int8_t* qA, const int8_t* W, const void* sA, co
     return hip_rc(mixq::launch_gemm(p, mixq::EPI_DEQUANT, st));
 }
 
+// ---- qA layouts (MI355X extension): the producer may write the image its consumer reads fastest ---------------------------
+int mixq_qa_layout(int M, int N, int K)
+{
+    if (M <= kSmallMFastPath || M > 32 || N <= 0 || K <= 0 || K % 16 || N % 16) return MIXQ_QA_ROW_MAJOR;
+    if (!mixq::qa_frag_enabled() || !mixq::quant_frag_layout_supported(M, K)) return MIXQ_QA_ROW_MAJOR;
+    if (gemm_scratch_bytes(M, N, K) != 0) return MIXQ_QA_ROW_MAJOR; // (a caller with scratch gets a K split there, not the skinny kernel)
+    mixq::GemmParams probe{};
+    probe.M = M, probe.N = N, probe.K = K, probe.O = kNumOutliers;
+    return mixq::gemm_takes_skinny(probe, mixq::EPI_DEQUANT) ? MIXQ_QA_FRAGMENT_MAJOR : MIXQ_QA_ROW_MAJOR;
+}
+
+size_t mixq_qa_bytes(int M, int K, int layout)
+{
+    if (M <= 0 || K <= 0) return 0;
+    if (layout == MIXQ_QA_FRAGMENT_MAJOR) return (size_t)((M + 15) / 16 * 16) * (size_t)((K + 63) / 64 * 64);
+    return (size_t)M * (size_t)K;
+}
+
+int mixq_quant_extract_layout(int M, int K, void* A, int8_t* qA, void* sA, void* fpA, const int32_t* ind, int len,
+                              int zero_outliers, int q_layout, void* stream)
+{
+    if (q_layout == MIXQ_QA_ROW_MAJOR) return mixq_quant_extract(M, K, A, qA, sA, fpA, ind, len, zero_outliers, stream);
+    if (q_layout != MIXQ_QA_FRAGMENT_MAJOR) return MIXQ_E_BADARG;
+    if (M < 0 || K <= 0 || len < 0 || (M > 0 && (!A || !qA || !sA))) return MIXQ_E_BADARG;
+    if (len > 0 && (!fpA || !ind)) return MIXQ_E_BADARG;
+    if (K % 8 || !mixq::quant_frag_layout_supported(M, K)) return MIXQ_E_SHAPE;
+    if (!aligned16(A) || !aligned16(qA)) return MIXQ_E_ALIGN;
+    return hip_rc(mixq::launch_quant_extract(A, qA, sA, len > 0 ? fpA : nullptr, ind, M, K, len, zero_outliers != 0,
+                                             static_cast<hipStream_t>(stream), nullptr, 1));
+}
+
+int mixq_rmsnorm_extract_quant_layout(int M, int K, const void* x, const void* gamma, void* out, float eps, const int32_t* ind,
+                                      int len, void* outliers, int8_t* q, void* scale, int q_layout, void* stream)
+{
+    if (q_layout == MIXQ_QA_ROW_MAJOR) return mixq_rmsnorm_extract_quant(M, K, x, gamma, out, eps, ind, len, outliers, q, scale, stream);
+    if (q_layout != MIXQ_QA_FRAGMENT_MAJOR) return MIXQ_E_BADARG;
+    if (M < 0 || K <= 0 || len < 0 || (M > 0 && (!x || !gamma || !out || !q || !scale))) return MIXQ_E_BADARG;
+    if (len > 0 && (!ind || !outliers)) return MIXQ_E_BADARG;
+    if (K % 8 || K > 32768 || !mixq::quant_frag_layout_supported(M, K)) return MIXQ_E_SHAPE;
+    if (!aligned16(x) || !aligned16(gamma) || !aligned16(out) || !aligned16(q)) return MIXQ_E_ALIGN;
+    return hip_rc(mixq::launch_rmsnorm_quant(x, gamma, out, outliers, ind, q, scale, eps, M, K, len, 8,
+                                             static_cast<hipStream_t>(stream), 1));
+}
+
+int mixq_int8_fused_dequantize_layout(const int8_t* A, const int8_t* B, const void* scale_row, const void* scale_col,
+                                      const void* y, const void* mul, void* D, int M, int N, int K, int epilogue, int qa_layout,
+                                      char* workspace, void* stream)
+{
+    if (epilogue != mixq::EPI_DEQUANT && epilogue != mixq::EPI_DEQUANT_SILU && epilogue != mixq::EPI_DEQUANT_SILU_MUL)
+        return MIXQ_E_BADARG;
+    if (qa_layout != MIXQ_QA_ROW_MAJOR && qa_layout != MIXQ_QA_FRAGMENT_MAJOR) return MIXQ_E_BADARG;
+    return fused_dequant_impl(A, B, scale_row, scale_col, y, D, M, N, K, epilogue, stream, mul, workspace, qa_layout);
+}
+
+int mixq_gemm_mixed_layout(const int8_t* qA, const int8_t* W, const void* sA, const void* sW, const void* fpA, const void* fpW,
+                           void* Out, int M, int N, int K, int O, int qa_layout, void* scratch, size_t scratch_bytes, void* stream)
+{
+    if (qa_layout != MIXQ_QA_ROW_MAJOR && qa_layout != MIXQ_QA_FRAGMENT_MAJOR) return MIXQ_E_BADARG;
+    if (qa_layout == MIXQ_QA_FRAGMENT_MAJOR) {
+        if (O > kNumOutliers || M <= 0 || N <= 0 || K <= 0) return MIXQ_E_SHAPE;
+        mixq::GemmParams probe{};
+        probe.M = M, probe.N = N, probe.K = K, probe.O = O;
+        probe.splitk_ws = (scratch && scratch_bytes >= gemm_scratch_bytes(M, N, K) && gemm_scratch_bytes(M, N, K)) ? scratch : nullptr;
+        if (!mixq::gemm_takes_skinny(probe, mixq::EPI_DEQUANT)) return MIXQ_E_SHAPE; // (the image has ONE reader)
+    }
+    return gemm_mixed_impl(qA, W, sA, sW, fpA, fpW, Out, M, N, K, O, scratch, scratch_bytes, stream, qa_layout);
+}
+
 int mixq_mixlinear_forward(int M, int N, int K, int O, void* x, const int32_t* ind, const int8_t* q_weight,
                            const void* scale_col, const void* weight_cache, void* x_scale, int8_t* q_x, void* outliers,
-                           void* out, void* scratch, size_t scratch_bytes, void* stream)
+                           void* out, int q_layout, void* scratch, size_t scratch_bytes, void* stream)
 {
     if (M < 0 || N < 0 || K <= 0 || O < 0) return MIXQ_E_BADARG;
     if (M == 0 || N == 0) return MIXQ_OK;
@@ -608,11 +678,15 @@ int mixq_mixlinear_forward(int M, int N, int K, int O, void* x, const int32_t* i
     // FindRowScale = the fused producer with zero_outliers = 1 (cult.cu:2616-2709 is the reference's own fused form), the
     // outlier product + int8FusedDequantize = the fused GEMM with its fp16 side product (<= 128 outlier columns, a multiple
     // of 8; anything else takes the reference's own two steps inside mixq_gemm_mixed_scratch)
-    int rc = mixq_quant_extract(M, K, x, q_x, x_scale, outliers, ind, O, 1, stream);
+    // q_layout: MIXQ_QA_FRAGMENT_MAJOR only where mixq_qa_layout(M, N, K) says so (q_x then holds mixq_qa_bytes(M, K, 1) bytes and
+    // is opaque to the caller; later consumers of it -- the gate projection -- must pass the same layout)
+    if (q_layout == MIXQ_QA_FRAGMENT_MAJOR && (O % 8 != 0 || O > kNumOutliers || mixq_qa_layout(M, N, K) != MIXQ_QA_FRAGMENT_MAJOR))
+        return MIXQ_E_SHAPE;
+    int rc = mixq_quant_extract_layout(M, K, x, q_x, x_scale, outliers, ind, O, 1, q_layout, stream);
     if (rc != MIXQ_OK) return rc;
     if (O % 8 == 0)
-        return mixq_gemm_mixed_scratch(q_x, q_weight, x_scale, scale_col, outliers, weight_cache, out, M, N, K, O, scratch,
-                                       scratch_bytes, stream);
+        return mixq_gemm_mixed_layout(q_x, q_weight, x_scale, scale_col, outliers, weight_cache, out, M, N, K, O, q_layout,
+                                      q_layout ? nullptr : scratch, q_layout ? 0 : scratch_bytes, stream);
     rc = mixq_gemm_fp16(outliers, weight_cache, out, M, N, O, stream);
     if (rc != MIXQ_OK) return rc;
     return mixq_int8_fused_dequantize(q_x, q_weight, x_scale, scale_col, out, out, M, N, K,

@@ -145,7 +145,8 @@ void set_quant_stamp_buffer(void* device_u64_8_per_block); // measurement only (
 hipError_t launch_quant_with_scale(const void* src, const void* scale, int8_t* dst, int M, int K, hipStream_t st);
 hipError_t launch_extract(void* A, void* fpA, const int32_t* ind, int M, int K, int O, bool zero, hipStream_t st);
 hipError_t launch_rmsnorm_quant(const void* X, const void* gamma, void* out, void* outl, const int32_t* ind, int8_t* q,
-                                void* scale, float eps, int M, int K, int O, int quant /* 0, 8, 4 */, hipStream_t st);
+                                void* scale, float eps, int M, int K, int O, int quant /* 0, 8, 4 */, hipStream_t st,
+                                int q_layout = 0 /* 1: fragment-major int8 rows (quant == 8, quant_frag_layout_supported) */);
 hipError_t launch_find_outliers(const void* A, int M, int K, float sigma, unsigned* mask, int32_t* ind, int32_t* count,
                                 int capacity, hipStream_t st);
 hipError_t launch_dequant_columns(const int8_t* W, const void* sW, const int32_t* ind, int len, void* out, int N, int K,

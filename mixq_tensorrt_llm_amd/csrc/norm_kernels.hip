@@ -19,7 +19,8 @@ namespace mixq {
 constexpr int NBLOCK = 256;
 
 // QUANT: 0 = plain RMSNorm, 8 = int8 rows (scale amax/127), 4 = packed int4 rows (scale amax/7, layernorm.cu:201-290)
-template <int TPR, int MAXV, int QUANT>
+// FRAG (QUANT == 8, decode batches): the int8 rows go out in the skinny GEMM's fragment-major order (quant_kernels.hip FRAG).
+template <int TPR, int MAXV, int QUANT, bool FRAG = false>
 __global__ __launch_bounds__(NBLOCK) void rmsnorm_quant_kernel(const uint16_t* __restrict__ X,
                                                                const uint16_t* __restrict__ gamma,
                                                                uint16_t* __restrict__ out, uint16_t* __restrict__ outl,
@@ -192,11 +193,17 @@ __global__ __launch_bounds__(NBLOCK) void rmsnorm_quant_kernel(const uint16_t* _
         return;
     }
     uint2* __restrict__ dstq = reinterpret_cast<uint2*>(q + (row_ok ? row : 0) * (int64_t)K);
+    auto slot = [&](int idx) __attribute__((always_inline)) -> uint2* { // 8-byte group idx of this row -> its place in the image
+        if (!FRAG) return dstq + idx;
+        const int64_t r = row_ok ? row : 0;
+        const int64_t blk = (r >> 4) * ((K + 63) >> 6) + (idx >> 3);
+        return reinterpret_cast<uint2*>(q + (blk << 10) + (((idx >> 1) & 3) << 8) + ((r & 15) << 4) + ((idx & 1) << 3));
+    };
     if (amax_all < 0x7c00 && s_bits != 0) { // every element finite, scale finite and non-zero (row-uniform)
 #pragma unroll
         for (int v = 0; v < MAXV; ++v) {
             const int idx = v * TPR + t;
-            if (row_ok && idx < nvec) dstq[idx] = quant_vec8_finite(x[v], s, rs);
+            if (row_ok && idx < nvec) *slot(idx) = quant_vec8_finite(x[v], s, rs);
         }
     } else {
         for (int v = 0; v < MAXV; ++v) {
@@ -210,7 +217,7 @@ __global__ __launch_bounds__(NBLOCK) void rmsnorm_quant_kernel(const uint16_t* _
                     const int q1 = quant_one(h2f((uint16_t)(w[e] >> 16)), s);
                     o[e >> 1] |= (unsigned)(q0 | (q1 << 8)) << ((e & 1) * 16);
                 }
-                dstq[idx] = make_uint2(o[0], o[1]);
+                *slot(idx) = make_uint2(o[0], o[1]);
             }
         }
     }
@@ -219,8 +226,20 @@ __global__ __launch_bounds__(NBLOCK) void rmsnorm_quant_kernel(const uint16_t* _
 template <int TPR, int MAXV>
 static hipError_t launch_norm(const uint16_t* X, const uint16_t* gamma, uint16_t* out, uint16_t* outl,
                               const int32_t* ind, int8_t* q, uint16_t* scale, float eps, int M, int K, int O,
-                              int quant, hipStream_t st)
+                              int quant, hipStream_t st, int q_layout = 0)
 {
+    if constexpr (TPR == 256 && MAXV <= 4) {
+        if (q_layout == 1 && quant == 8) {
+            const size_t lds = (size_t)((K + 127) / 128) * 16 + (size_t)K * 2;
+            static DeviceOnce oncef;
+            if (hipError_t e = ensure_dynamic_lds(rmsnorm_quant_kernel<TPR, MAXV, 8, true>, 160 * 1024 - 64, oncef); e != hipSuccess)
+                return e;
+            hipLaunchKernelGGL((rmsnorm_quant_kernel<TPR, MAXV, 8, true>), dim3((unsigned)M), dim3(NBLOCK), lds, st, X, gamma, out,
+                               outl, ind, q, scale, eps, M, K, O);
+            return hipGetLastError();
+        }
+    }
+    if (q_layout != 0) return hipErrorInvalidValue;
     constexpr int RPB = NBLOCK / TPR;
     const dim3 grid((unsigned)((M + RPB - 1) / RPB)), block(NBLOCK);
     if (quant) {
@@ -246,8 +265,9 @@ static hipError_t launch_norm(const uint16_t* X, const uint16_t* gamma, uint16_t
 
 // quant = 0: plain RMSNorm (only `out`), 8 / 4: fused producer.  hipErrorInvalidValue for rows longer than 32768.
 hipError_t launch_rmsnorm_quant(const void* X, const void* gamma, void* out, void* outl, const int32_t* ind, int8_t* q,
-                                void* scale, float eps, int M, int K, int O, int quant, hipStream_t st)
+                                void* scale, float eps, int M, int K, int O, int quant, hipStream_t st, int q_layout)
 {
+    if (q_layout != 0 && !(q_layout == 1 && quant == 8 && quant_frag_layout_supported(M, K))) return hipErrorInvalidValue;
     if (M <= 0) return hipSuccess;
     const uint16_t* x = static_cast<const uint16_t*>(X);
     const uint16_t* g = static_cast<const uint16_t*>(gamma);
@@ -259,8 +279,8 @@ hipError_t launch_rmsnorm_quant(const void* X, const void* gamma, void* out, voi
     // a row is ONE load round trip of 1-4 vectors per lane instead of 8-16 on a single wavefront -- the same rule as the
     // quantiser's (quant_kernels.hip); 32 x 4096: 11.0 -> ~4.5 us for the fused producer (profiles/r03_small_m_timeline.txt)
     if (M <= 64 && nvec > 64 * 2) {
-        if (nvec <= 256 * 2) return launch_norm<256, 2>(x, g, o, ol, ind, q, sc, eps, M, K, O, quant, st);
-        if (nvec <= 256 * 4) return launch_norm<256, 4>(x, g, o, ol, ind, q, sc, eps, M, K, O, quant, st);
+        if (nvec <= 256 * 2) return launch_norm<256, 2>(x, g, o, ol, ind, q, sc, eps, M, K, O, quant, st, q_layout);
+        if (nvec <= 256 * 4) return launch_norm<256, 4>(x, g, o, ol, ind, q, sc, eps, M, K, O, quant, st, q_layout);
     }
     if (nvec <= 64 * 2) return launch_norm<64, 2>(x, g, o, ol, ind, q, sc, eps, M, K, O, quant, st);
     if (nvec <= 64 * 4) return launch_norm<64, 4>(x, g, o, ol, ind, q, sc, eps, M, K, O, quant, st);

@@ -298,9 +298,13 @@ static hipError_t launch_qe(uint16_t* A, int8_t* qA, uint16_t* sA, uint16_t* fpA
 {
     void* const dbg = g_quant_stamps.load(std::memory_order_relaxed);
     if constexpr (TPR == 256 && MAXV <= 4) {
-        if (frag == 1 && !zero) { // decode batches of mixq_enqueue: qA in the skinny GEMM's fragment order
+        if (frag == 1) { // decode batches: qA in the skinny GEMM's fragment order (both flavours)
             dim3 grid((unsigned)M), block(QBLOCK);
-            hipLaunchKernelGGL((quant_extract_kernel<TPR, MAXV, false, 1>), grid, block, 0, st, A, qA, sA, fpA, ind, M, K, O, zw, dbg);
+            if (zero)
+                hipLaunchKernelGGL((quant_extract_kernel<TPR, MAXV, true, 1>), grid, block, (size_t)((K + 31) / 32) * 4, st, A, qA, sA,
+                                   fpA, ind, M, K, O, zw, dbg);
+            else
+                hipLaunchKernelGGL((quant_extract_kernel<TPR, MAXV, false, 1>), grid, block, 0, st, A, qA, sA, fpA, ind, M, K, O, zw, dbg);
             return hipGetLastError();
         }
     }
@@ -321,7 +325,7 @@ bool quant_frag_layout_supported(int M, int K) { return M > 0 && M <= 64 && K % 
 hipError_t launch_quant_extract(void* A, int8_t* qA, void* sA, void* fpA, const int32_t* ind, int M, int K, int O,
                                 bool zero, hipStream_t st, void* zero_words, int frag)
 {
-    if (frag == 1 && (zero || !quant_frag_layout_supported(M, K))) return hipErrorInvalidValue;
+    if (frag == 1 && !quant_frag_layout_supported(M, K)) return hipErrorInvalidValue;
     if (frag < 0 || frag > 1) return hipErrorInvalidValue;
     if (M <= 0) return hipSuccess;
     unsigned* const zw = static_cast<unsigned*>(zero_words);

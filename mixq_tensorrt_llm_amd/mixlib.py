@@ -16,7 +16,25 @@ __all__ = ["FindRowScale", "ExtractOutliersAndSetToZeros", "int8FusedDequantize"
            "layernorm_forward_cuda_extract_outliers", "int_to_half", "int_matrix_to_half",
            "int8_matrix_to_half", "w8_a16_gemm", "preprocess_weights", "mixq_linear", "int4FusedDequantize",
            "int4FusedDequantizeSilu", "unpack_int4_to_fp16", "int8FusedDequantizeSiluMul",
-           "layernorm_forward_cuda_extract_outliers_int4", "ExtractOutliers", "dequantizeInt8Silu", "mixlinear_forward"]
+           "layernorm_forward_cuda_extract_outliers_int4", "ExtractOutliers", "dequantizeInt8Silu", "mixlinear_forward",
+           "qa_layout", "QA_ROW_MAJOR", "QA_FRAGMENT_MAJOR"]
+
+QA_ROW_MAJOR, QA_FRAGMENT_MAJOR = 0, 1   # include/mixq.h MIXQ_QA_*
+
+
+def qa_layout(M, N, K):
+    """The int8 activation image a producer should write for a [M,K] x [N,K]^T consumer (include/mixq.h ``mixq_qa_layout``):
+    QA_FRAGMENT_MAJOR for decode batches the weight-streaming skinny GEMM serves (its qA loads become contiguous 1-KiB reads),
+    else QA_ROW_MAJOR.  The reference-named ops below default to row-major; our own producers / consumers
+    (``mixlinear.FasterTransformerRMSNorm``, ``MixLinear_GEMM``) pass the layout along in the cache."""
+    return int(_lib.load().mixq_qa_layout(int(M), int(N), int(K)))
+
+
+def _alloc_q(m, k, layout, device):
+    if layout == QA_FRAGMENT_MAJOR:   # opaque image: whole 16-row tiles x whole 64-byte k-steps
+        return torch.empty(int(_lib.load().mixq_qa_bytes(m, k, layout)), dtype=torch.int8, device=device)
+    return torch.empty((m, k), dtype=torch.int8, device=device)
+
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)   # ~0.2 us; torch.cuda.current_stream() costs ~1.8 us
@@ -124,25 +142,31 @@ def gemm_scratch(t, M, N, K):
     return _scratch_bytes(t, n)
 
 
-def _fused(name, A, B, scale_row, scale_col, y, M, N, K):
-    _dev(*(t for t in (A, B, scale_row, scale_col, y) if t is not None))  # y = None: no addend (zeros in the reference)
+def _fused(name, A, B, scale_row, scale_col, y, M, N, K, qa_layout=0, epilogue=0, mul=None):
+    _dev(*(t for t in (A, B, scale_row, scale_col, y, mul) if t is not None))  # y = None: no addend (zeros in the reference)
     D = torch.empty((M, N), dtype=torch.float16, device=A.device)
-    fn = getattr(_lib.load(), name)
+    lib = _lib.load()
+    if qa_layout:   # the fragment-major image (decode batches): one entry for the three epilogues
+        _lib.check(lib.mixq_int8_fused_dequantize_layout(_p(A), _p(B), _p(scale_row), _p(scale_col), _p(y), _p(mul), _p(D), M, N,
+                                                         K, epilogue, qa_layout, None, _st(A)), name)
+        return D
+    fn = getattr(lib, name)
     _lib.check(fn(_p(A), _p(B), _p(scale_row), _p(scale_col), _p(y), _p(D), M, N, K, _p(gemm_scratch(A, M, N, K)),
                   _st(A)), name)
     return D
 
 
 @_on_tensor_device
-def int8FusedDequantize(A, B, scale_row, scale_col, y, M, N, K):
-    """cult.cu:1937-2000: D = fp16(float(A.B^T) * (scale_col[n]*scale_row[m]) + y), new tensor D."""
-    return _fused("mixq_int8_fused_dequantize", A, B, scale_row, scale_col, y, M, N, K)
+def int8FusedDequantize(A, B, scale_row, scale_col, y, M, N, K, qa_layout=0):
+    """cult.cu:1937-2000: D = fp16(float(A.B^T) * (scale_col[n]*scale_row[m]) + y), new tensor D.
+    ``qa_layout`` (MI355X extension): the layout of ``A`` as its producer wrote it (``qa_layout()``); default row-major."""
+    return _fused("mixq_int8_fused_dequantize", A, B, scale_row, scale_col, y, M, N, K, qa_layout, 0)
 
 
 @_on_tensor_device
-def int8FusedDequantizeSilu(A, B, scale_row, scale_col, y, M, N, K):
+def int8FusedDequantizeSilu(A, B, scale_row, scale_col, y, M, N, K, qa_layout=0):
     """cult.cu:2067-2117: same with SiLU applied before the fp16 rounding."""
-    return _fused("mixq_int8_fused_dequantize_silu", A, B, scale_row, scale_col, y, M, N, K)
+    return _fused("mixq_int8_fused_dequantize_silu", A, B, scale_row, scale_col, y, M, N, K, qa_layout, 1)
 
 
 def _fused4(name, A, B, scale_row, scale_col, y, M, N, K):
@@ -182,9 +206,11 @@ def unpack_int4_to_fp16(weight, ind):
 
 
 @_on_tensor_device
-def int8FusedDequantizeSiluMul(A, B, scale_row, scale_col, y, mul, M, N, K):
+def int8FusedDequantizeSiluMul(A, B, scale_row, scale_col, y, mul, M, N, K, qa_layout=0):
     """MI355X extension (no reference op): int8FusedDequantizeSilu followed by ``*= mul`` (fused/mlp.py:61-63) in ONE
     kernel: D = fp16(fp16(silu(...)) * mul), the same bits as the two-step sequence."""
+    if qa_layout:
+        return _fused("int8FusedDequantizeSiluMul", A, B, scale_row, scale_col, y, M, N, K, qa_layout, 3, mul)
     _dev(*(t for t in (A, B, scale_row, scale_col, y, mul) if t is not None))
     D = torch.empty((M, N), dtype=torch.float16, device=A.device)
     _lib.check(_lib.load().mixq_int8_fused_dequantize_silu_mul(_p(A), _p(B), _p(scale_row), _p(scale_col), _p(y), _p(mul),
@@ -235,14 +261,15 @@ def Int8quantize(src, scale):
 
 
 @_on_tensor_device
-def FindRowScaleFusedExtracOutliers(x, scaleRow, ind, len_ind, rows, cols):
-    """cult.cu:2671-2709: returns [int8 rows, outliers fp16 [rows,len_ind]]; zeroes the outlier columns of x."""
+def FindRowScaleFusedExtracOutliers(x, scaleRow, ind, len_ind, rows, cols, q_layout=0):
+    """cult.cu:2671-2709: returns [int8 rows, outliers fp16 [rows,len_ind]]; zeroes the outlier columns of x.
+    ``q_layout`` (MI355X extension): write the rows in the consumer's preferred image (``qa_layout()``)."""
     _dev(x, scaleRow)
     _rows_fit(scaleRow, rows, "FindRowScaleFusedExtracOutliers")
-    q = torch.empty((rows, cols), dtype=torch.int8, device=x.device)
-    outl = torch.zeros((rows, len_ind), dtype=torch.float16, device=x.device)
-    _lib.check(_lib.load().mixq_quant_extract(rows, cols, _p(x), _p(q), _p(scaleRow), _p(outl),
-                                              _p(ind) if len_ind else None, len_ind, 1, _st(x)),
+    q = _alloc_q(rows, cols, q_layout, x.device)
+    outl = torch.empty((rows, len_ind), dtype=torch.float16, device=x.device)
+    _lib.check(_lib.load().mixq_quant_extract_layout(rows, cols, _p(x), _p(q), _p(scaleRow), _p(outl),
+                                                     _p(ind) if len_ind else None, len_ind, 1, q_layout, _st(x)),
                "FindRowScaleFusedExtracOutliers")
     return [q, outl]
 
@@ -258,18 +285,20 @@ def layernorm_forward_cuda(_input, _gamma, _out, eps):
 
 
 @_on_tensor_device
-def layernorm_forward_cuda_extract_outliers(_input, _gamma, _out, eps, _ind, scaleRow):
+def layernorm_forward_cuda_extract_outliers(_input, _gamma, _out, eps, _ind, scaleRow, q_layout=0):
     """layernorm.cu:316-346: fused RMSNorm -> extract(+zero) outliers -> per-row int8 quantisation.
-    Fills _out (normalised, outlier columns zeroed) and scaleRow; returns [outliers fp16 [m,len], quant int8 [m,c]]."""
+    Fills _out (normalised, outlier columns zeroed) and scaleRow; returns [outliers fp16 [m,len], quant int8 [m,c]].
+    ``q_layout`` (MI355X extension): write the int8 rows in the consumer's preferred image (``qa_layout()``)."""
     _dev(_input, _gamma, _out, _ind, scaleRow)
     c = _input.shape[-1]
     m = _input.numel() // c
     _rows_fit(scaleRow, m, "layernorm_forward_cuda_extract_outliers")
     n = _ind.shape[0]
     outl = torch.zeros((m, n), dtype=torch.float16, device=_input.device)
-    q = torch.empty((m, c), dtype=torch.int8, device=_input.device)
-    _lib.check(_lib.load().mixq_rmsnorm_extract_quant(m, c, _p(_input), _p(_gamma), _p(_out), ctypes.c_float(eps),
-                                                      _p(_ind), n, _p(outl), _p(q), _p(scaleRow), _st(_input)),
+    q = _alloc_q(m, c, q_layout, _input.device)
+    _lib.check(_lib.load().mixq_rmsnorm_extract_quant_layout(m, c, _p(_input), _p(_gamma), _p(_out), ctypes.c_float(eps),
+                                                             _p(_ind), n, _p(outl), _p(q), _p(scaleRow), q_layout,
+                                                             _st(_input)),
                "layernorm_forward_cuda_extract_outliers")
     return [outl, q]
 
@@ -377,7 +406,7 @@ def mixq_linear(A, W_int8, sW, fp_weight, ind, out=None, workspace=None):
     return out
 
 
-def mixlinear_forward(x, ind, q_weight, scale_col, weight_cache, x_scale):
+def mixlinear_forward(x, ind, q_weight, scale_col, weight_cache, x_scale, q_layout=0):
     """MixLinear_GEMM.forward (linear.py:163-286, bit = 8, static outlier set) in ONE library call and two launches (MI355X
     extension, include/mixq.h ``mixq_mixlinear_forward``): returns (out fp16 [M,N], q_x int8 [M,K], outliers fp16 [M,O]); zeroes
     the ``ind`` columns of ``x`` and fills ``x_scale`` like the reference's four-call sequence.  The wrapper does what one of
@@ -387,14 +416,14 @@ def mixlinear_forward(x, ind, q_weight, scale_col, weight_cache, x_scale):
     O = int(ind.shape[0])
     dev = x.device
     out = torch.empty((M, N), dtype=torch.float16, device=dev)
-    q_x = torch.empty((M, K), dtype=torch.int8, device=dev)
+    q_x = _alloc_q(M, K, q_layout, dev)   # (q_layout = qa_layout(M, N, K): the opaque fragment-major image for decode batches)
     outliers = torch.empty((M, O), dtype=torch.float16, device=dev)
     lib = _lib.load()
-    scratch = gemm_scratch(x, M, N, K)
+    scratch = None if q_layout else gemm_scratch(x, M, N, K)
     _lib.check(lib.mixq_mixlinear_forward(M, N, K, O, x.data_ptr(), ind.data_ptr() if O else None, q_weight.data_ptr(),
                                           scale_col.data_ptr(), weight_cache.data_ptr() if (O and weight_cache is not None) else None,
                                           x_scale.data_ptr(),
-                                          q_x.data_ptr(), outliers.data_ptr() if O else None, out.data_ptr(),
+                                          q_x.data_ptr(), outliers.data_ptr() if O else None, out.data_ptr(), q_layout,
                                           scratch.data_ptr() if scratch is not None else None,
                                           scratch.numel() if scratch is not None else 0,
                                           _st(x)), "mixlinear_forward")

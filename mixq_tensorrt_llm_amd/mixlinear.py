@@ -85,6 +85,7 @@ class MixLibCache:
         self.shape = None
         self.activation_outliers = None
         self.q_xcache = None
+        self.q_layout = 0      # layout of q_xcache (mixlib.QA_ROW_MAJOR / QA_FRAGMENT_MAJOR: MI355X extension, decode batches)
         self.is_prefill = False
         self.bit = bit
         self.max_outliers = 256
@@ -186,8 +187,10 @@ class MixLinear_GEMM:
             assert cache.x_scale.numel() >= M
             cache.ind = self.ind
             wc = self.weight_cache if self.ind.shape[0] else None
+            n_out = int(self.ind.shape[0])
+            cache.q_layout = mixlib.qa_layout(M, self.out_features, self.in_features) if (n_out % 8 == 0 and n_out <= 128) else 0
             y1, cache.q_xcache, cache.activation_outliers = mixlib.mixlinear_forward(
-                inputs, self.ind, self.q_weight, self.scale_col, wc, cache.x_scale)
+                inputs, self.ind, self.q_weight, self.scale_col, wc, cache.x_scale, cache.q_layout)
             if self.bias is not None:
                 y1 += self.bias
             return y1.reshape(cache.shape)
@@ -195,6 +198,7 @@ class MixLinear_GEMM:
             if self.ind.shape[0]:
                 cache.activation_outliers = mixlib.ExtractOutliersAndSetToZeros(self.ind, inputs)
             cache.q_xcache = mixlib.FindRowScale(inputs, cache.x_scale, M, self.in_features, self.bit)
+            cache.q_layout = 0
         cache.ind = self.ind
 
         if self.add_outliers:
@@ -216,6 +220,7 @@ class MixLinear_GEMM:
                 self.ind = torch.hstack((self.ind, ind))
                 cache.ind = self.ind
                 cache.q_xcache = mixlib.FindRowScale(inputs, cache.x_scale, M, self.in_features, self.bit)
+                cache.q_layout = 0
             self.cnt += 1
             if self.cnt >= cache.stop or self.ind.shape[0] > 256:
                 self.add_outliers = False
@@ -223,7 +228,7 @@ class MixLinear_GEMM:
         y = outlier_product(cache.activation_outliers, self.weight_cache) if self.ind.shape[0] else None
         if self.bit == 8:
             y1 = mixlib.int8FusedDequantize(cache.q_xcache, self.q_weight, cache.x_scale, self.scale_col, y, M,
-                                            self.out_features, self.in_features)
+                                            self.out_features, self.in_features, getattr(cache, "q_layout", 0))
         else:
             y1 = mixlib.int4FusedDequantize(cache.q_xcache, self.q_weight, cache.x_scale, self.scale_col, y, M,
                                             self.out_features, self.in_features // 2)
@@ -260,10 +265,10 @@ class MixLinear_GEMM:
         if fused_mul:
             y1 = mixlib.int8FusedDequantizeSiluMul(cache.q_xcache, self.q_weight, cache.x_scale, self.scale_col, y,
                                                    mul.reshape(M, self.out_features), M, self.out_features,
-                                                   self.in_features)
+                                                   self.in_features, getattr(cache, "q_layout", 0))
         elif self.bit == 8:
             y1 = mixlib.int8FusedDequantizeSilu(cache.q_xcache, self.q_weight, cache.x_scale, self.scale_col, y, M,
-                                                self.out_features, self.in_features)
+                                                self.out_features, self.in_features, getattr(cache, "q_layout", 0))
         else:
             if y is None:
                 raise RuntimeError("int4 mod should have outliers !")  # :364
@@ -294,8 +299,16 @@ class FasterTransformerRMSNorm:
         if self.next_layer is None:
             mixlib.layernorm_forward_cuda(x, self.weight, output, self.variance_epsilon)
         elif self.next_layer.bit == 8:
+            # decode batches: the int8 rows in the image the next layer's GEMM reads fastest (mixlib.qa_layout; the gate
+            # projection that re-uses the cache has the same N).  A dynamic outlier set re-quantises row-major later.
+            c = x.shape[-1]
+            m = x.numel() // c
+            n_out = int(self.next_layer.ind.shape[0])
+            lay = mixlib.qa_layout(m, self.next_layer.out_features, c) if (n_out % 8 == 0 and n_out <= 128 and
+                                                                            not self.next_layer.add_outliers) else 0
+            self.cache.q_layout = lay
             self.cache.activation_outliers, self.cache.q_xcache = mixlib.layernorm_forward_cuda_extract_outliers(
-                x, self.weight, output, self.variance_epsilon, self.next_layer.ind, self.cache.x_scale)
+                x, self.weight, output, self.variance_epsilon, self.next_layer.ind, self.cache.x_scale, lay)
         elif self.next_layer.bit == 4:
             self.cache.activation_outliers, self.cache.q_xcache = mixlib.layernorm_forward_cuda_extract_outliers_int4(
                 x, self.weight, output, self.variance_epsilon, self.next_layer.ind, self.cache.x_scale)

@@ -243,3 +243,59 @@ def test_product_reproduces_the_reference_generated_fixture():
     assert np.array_equal(l4.scale_col.cpu().numpy().reshape(-1).view(np.uint16), g["w4_scale_col"].view(np.uint16))
     assert np.array_equal(l4.weight_cache.cpu().numpy().view(np.uint16), g["w4_weight_cache"].view(np.uint16))
     assert np.array_equal(mixlinear.find_outliers(dev(g["fo_A"]), 6.0).cpu().numpy(), g["fo_ind"])
+
+
+@pytest.mark.parametrize("M,N,K", [(32, 4096, 4096), (16, 1024, 2048), (24, 512, 3584)])
+def test_p_flavour_decode_batches_use_the_fragment_major_image_and_keep_their_bits(M, N, K):
+    """Round 3: producers inside the library (fused norm, one-call linear) hand the int8 activation to the skinny GEMM in its
+    fragment-major order for decode batches (mixlib.qa_layout).  Norm -> up projection -> gate projection (SiLU * up in the
+    epilogue) must give the same bits with the layout on and off (knob 890), and the one-call unfused forward too."""
+    from mixq_tensorrt_llm_amd import _lib, mixlib, mixlinear
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(M + N + K)
+    W_up = (torch.randn((N, K), device=dev, generator=g) * 0.02).to(torch.float16)
+    W_gate = (torch.randn((N, K), device=dev, generator=g) * 0.02).to(torch.float16)
+    scales = torch.rand(K, device=dev, generator=g)
+    gamma = (torch.rand(K, device=dev, generator=g) + 0.5).to(torch.float16)
+    X = torch.randn((M, K), device=dev, generator=g).to(torch.float16)
+    outs = {}
+    for knob in (891, 890):
+        lib.mixq_debug_set_gemm_variant(knob)
+        try:
+            cache = mixlinear.MixLibCache(inputdim=64, device=dev)
+            up = mixlinear.MixLinear_GEMM.from_linear(W_up, None, bit=8, cache=cache, layer_scales=scales, fp_features_num=128)
+            gate = mixlinear.MixLinear_GEMM.from_linear(W_gate, None, bit=8, cache=cache, layer_scales=scales,
+                                                        fp_features_num=128)
+            up.add_outliers = gate.add_outliers = False
+            norm = mixlinear.FasterTransformerRMSNorm(gamma, 1e-6, cache)
+            norm.next_layer = up
+            xn = norm(X.clone())
+            assert cache.q_layout == (mixlib.qa_layout(M, N, K) if knob == 891 else 0)
+            if knob == 891:
+                assert cache.q_layout == mixlib.QA_FRAGMENT_MAJOR, "these shapes are in the layout's domain"
+            y_up = up(xn, cache)
+            y_gate = gate.forward_without_preconditionFusedSilu(xn, cache, mul=y_up)
+            y_unfused = up(X.clone(), cache, unfused=True)       # one call, two launches; its own producer
+            torch.cuda.synchronize()
+            outs[knob] = [t.cpu() for t in (y_up, y_gate, y_unfused)]
+        finally:
+            lib.mixq_debug_set_gemm_variant(891)
+    for a, b, name in zip(outs[891], outs[890], ("up", "gate (SiLU * up)", "unfused one-call")):
+        assert torch.equal(a, b), f"{name}: fragment-major and row-major images give different bits"
+    assert torch.isfinite(outs[891][0].float()).all()
+    # the one-call entry with a static outlier set of 128 columns, both layouts, same bits (and the same x_scale / outliers)
+    ind = torch.randperm(K, device=dev, generator=g)[:128].to(torch.int32)
+    up2 = mixlinear.MixLinear_GEMM.from_linear(W_up, None, bit=8, cache=mixlinear.MixLibCache(inputdim=64, device=dev),
+                                               layer_scales=scales)
+    wc = mixlinear.dequant_weight_columns(up2.q_weight, up2.scale_col, ind)
+    res = []
+    for lay in (0, mixlib.qa_layout(M, N, K)):
+        xs = torch.zeros((64, 1), dtype=torch.float16, device=dev)
+        x = X.clone()
+        out, q_x, outl = mixlib.mixlinear_forward(x, ind, up2.q_weight, up2.scale_col, wc, xs, lay)
+        torch.cuda.synchronize()
+        res.append((out.cpu(), xs.cpu(), outl.cpu(), x.cpu()))
+    assert mixlib.qa_layout(M, N, K) == 1
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)

@@ -73,7 +73,7 @@ def main():
     res["torch.cuda.current_stream().cuda_stream"] = bench(lambda: torch.cuda.current_stream(dev).cuda_stream)
     if hasattr(lib, "mixq_mixlinear_forward"):
         res["one-call entry mixq_mixlinear_forward (2 launches), direct"] = bench(
-            lambda: lib.mixq_mixlinear_forward(M, N, K, O, px, pind, pqw, psc, pwc, pxs, pq, poutl, pD, None, 0, st))
+            lambda: lib.mixq_mixlinear_forward(M, N, K, O, px, pind, pqw, psc, pwc, pxs, pq, poutl, pD, 0, None, 0, st))
         if hasattr(mixlib, "mixlinear_forward"):
             res["one-call entry through mixlib.mixlinear_forward"] = bench(
                 lambda: mixlib.mixlinear_forward(x, ind, qw, sc, wc, xs))
