@@ -527,6 +527,10 @@ bool qa_frag_enabled() { return g_qa_frag.load() != 0; }
 
 void set_gemm_variant(int v)
 {
+    if (v >= 894 && v <= 896) { // fragment-major skinny form: feature tiles per workgroup automatic / 1 / 2
+        set_skinny_nt(v - 894);
+        return;
+    }
     if (v == 892 || v == 893) { // probe: the skinny kernel for every N up to 32 rows (892) / the measured rule (893, default)
         g_skinny_wide.store(v == 892 ? 1 : 0);
         return;
@@ -653,8 +657,10 @@ bool gemm_takes_skinny(const GemmParams& p, int epi)
 {
     const bool xsplit_wins = epi != EPI_INT32 && p.splitk_ws != nullptr && p.K >= 8192 && gemm_xsplit_factor(p.M, p.N, p.K) != 0;
     return gemm_variant() != 1 && !xsplit_wins && gemm_skinny_supported(p) &&
-           (p.M <= 16 || (p.M <= 32 && (p.N < 10240 || g_skinny_wide.load() != 0))); // (round 3, fragment-major qA: N = 8192 15.9 -> 13.8 us;
-                                                                                   //  from 11008 the two-barrier tiles are equal or ahead)
+           (p.M <= 16 || (p.M <= 32 && (p.N <= 12288 || g_skinny_wide.load() != 0)));
+    // (17..32 rows, round 3 with the fragment-major qA image, operator us, tiles vs skinny: N = 8192 15.9 / 12.8, 11008 17.6 / 16.0,
+    //  12288 18.8 / 16.0, 18944 x 3584 19.8 / 22.4, 28672 x 8192 41.5 / 49.6: the two-barrier tiles from more than 768 workgroups on.
+    //  Callers that pass a row-major image take the same rule: 12288 x 4096 at 32 rows 14.8 skinny vs 15.3 tiles in round 2.)
 }
 
 hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st)

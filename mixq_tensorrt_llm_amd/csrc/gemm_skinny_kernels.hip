@@ -20,14 +20,18 @@
 namespace mixq {
 
 // ABL: measurement-only ablations (wrong results): 1 = no qA loads, 2 = no weight loads, 4 = no epilogue operand loads.
-template <int MT, int EPI, int KW, int ABL = 0, bool AFRAG = false>
+// NT (round 3): 16-column feature tiles per workgroup.  NT = 1 is the form above; NT = 2 makes every qA fragment feed two MFMAs
+// (32 output features per workgroup): the workgroups of a WIDE output then pull half as many qA bytes in total (N / 32 x M x K
+// instead of N / 16 x M x K) while the chip is still full (N = 12288: 384 workgroups).  Output tile tt = nt * MT + t of the
+// workgroup is finished by wave tt % KW.
+template <int MT, int EPI, int KW, int ABL = 0, bool AFRAG = false, int NT = 1>
 __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p)
 {
-    __shared__ v4i part[KW][MT][64]; // [K part][m tile][lane]
+    __shared__ v4i part[KW][MT * NT][64]; // [K part][output tile][lane]
     dbg_stamp(p.dbg, 0); // (measurement only: p.dbg is NULL in production) entry
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n0 = blockIdx.x * 16;
+    const int n0 = blockIdx.x * 16 * NT;
     const int lr = lane & 15, lq = lane >> 4;
     const int64_t K = p.K;
 
@@ -36,28 +40,33 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
     const int per = (nsteps + KW - 1) / KW;
     const int s_begin = min(wave * per, nsteps), s_end = min(s_begin + per, nsteps);
 
-    const int8_t* wrow = p.B + (int64_t)min(n0 + lr, p.N - 1) * K + lq * 16;
+    const int8_t* wrow[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) wrow[c] = p.B + (int64_t)min(n0 + c * 16 + lr, p.N - 1) * K + lq * 16;
     const int8_t* arow[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t)
         arow[t] = p.A + (int64_t)min(t * 16 + lr, p.M - 1) * K + lq * 16;
 
-    v4i acc[MT];
+    v4i acc[NT][MT];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) acc[t] = v4i{0, 0, 0, 0};
+    for (int c = 0; c < NT; ++c)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[c][t] = v4i{0, 0, 0, 0};
 
-    // Epilogue operands of the m-tile this wave will finish (tile `wave`; KW >= MT, so at most one per wave) are requested
+    // Epilogue operands of the FIRST output tile this wave will finish (tile `wave` = (m tile wave % MT, feature tile wave / MT)) are requested
     // NOW -- the first 128 outlier columns of the side GEMM, the row scale, the weight scales -- so that their L2 round
     // trip runs under the weight stream instead of after it (the kernel is a chain of latencies at this size).
     constexpr int PRE = 4; // pre-loaded side-GEMM steps (32 outlier columns each)
     v8h pxf[PRE], pyf[PRE];
     uint16_t psa = 0;
     uint2 psw = {0u, 0u};
-    const bool fin = EPI != EPI_INT32 && wave < MT && !(ABL & 4); // this wave runs an fp16 epilogue
-    const int fm = wave * 16 + lr, fnb = n0 + 4 * lq;
+    const bool fin = EPI != EPI_INT32 && wave < MT * NT && !(ABL & 4); // this wave runs an fp16 epilogue
+    const int ft = wave % MT, fc = wave / MT;                              // its first tile: m tile ft, feature tile fc
+    const int fm = ft * 16 + lr, fnb = n0 + fc * 16 + 4 * lq;
     if (fin) {
         const int obytes = p.O * 2;
-        const char* xw = reinterpret_cast<const char*>(p.fpW) + (int64_t)min(n0 + lr, p.N - 1) * obytes;
+        const char* xw = reinterpret_cast<const char*>(p.fpW) + (int64_t)min(n0 + fc * 16 + lr, p.N - 1) * obytes;
         const char* ya = reinterpret_cast<const char*>(p.fpA) + (int64_t)min(fm, p.M - 1) * obytes;
 #pragma unroll
         for (int u = 0; u < PRE; ++u) {
@@ -87,18 +96,19 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
     //     first MFMA, so the compiler's counted `vmcnt(n)` lets step u multiply while steps u+1.. are still on their way.
     // (Round 2's ablations of the old form, 4096 x 4096, GEMM only, us: M = 32 full 7.8 | no qA loads 4.7 | no weight loads
     //  5.9 | no loads at all 4.6.)
-    constexpr int STEPS = MT <= 2 ? 16 : 8; // k-steps per batch: (1 + MT) x STEPS x 4 fragment registers
+    constexpr int STEPS = (MT <= 2 && NT == 1) ? 16 : 8; // k-steps per batch: (NT + MT) x STEPS x 4 fragment registers
     const bool ktail = (p.K & 63) != 0;     // the row's last step is partial (K % 16 == 0 is checked on the host)
     const int koff_last = p.K - 16;
     auto do_steps = [&](int s0, int cnt, auto full_tag) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_tag)::value; // cnt == STEPS and no partial step: no clamps, no selects
-        v4i wf[STEPS], af[STEPS][MT];
+        v4i wf[STEPS][NT], af[STEPS][MT];
 #pragma unroll
         for (int u = 0; u < STEPS; ++u) {
             const int su = FULL ? s0 + u : min(s0 + u, s0 + cnt - 1); // (wave-uniform)
             int off = su * 64;                                        // byte offset inside the row, + lq * 16 per lane
             if (!FULL) off = min(off + lq * 16, koff_last) - lq * 16;
-            wf[u] = (ABL & 2) ? zero4 : *reinterpret_cast<const v4i*>(wrow + off);
+#pragma unroll
+            for (int c = 0; c < NT; ++c) wf[u][c] = (ABL & 2) ? zero4 : *reinterpret_cast<const v4i*>(wrow[c] + off);
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
                 if (AFRAG) // fragment-major qA (quant_kernels.hip FRAG): block (m tile, k-step), lane l at l * 16 -- ONE
@@ -112,13 +122,17 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
                                            // sinks loads between the MFMAs to save registers: ~10 in flight instead of 48)
 #pragma unroll
         for (int u = 0; u < STEPS; ++u) {
-            v4i w = wf[u];
-            if (!FULL) {
-                const bool dead = u >= cnt || (ktail && (s0 + u) * 64 + lq * 16 >= p.K);
-                if (dead) w = zero4;
-            }
 #pragma unroll
-            for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w, af[u][t], acc[t], 0, 0, 0);
+            for (int c = 0; c < NT; ++c) {
+                v4i w = wf[u][c];
+                if (!FULL) {
+                    const bool dead = u >= cnt || (ktail && (s0 + u) * 64 + lq * 16 >= p.K);
+                    if (dead) w = zero4;
+                }
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+                    acc[c][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w, af[u][t], acc[c][t], 0, 0, 0);
+            }
         }
     };
     dbg_stamp(p.dbg, 1); // epilogue operands requested
@@ -131,20 +145,24 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
     dbg_stamp(p.dbg, 3); // last MFMA issued
 
 #pragma unroll
-    for (int t = 0; t < MT; ++t) part[wave][t][lane] = acc[t];
+    for (int c = 0; c < NT; ++c)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) part[wave][c * MT + t][lane] = acc[c][t];
     __syncthreads();
     dbg_stamp(p.dbg, 4); // LDS hand-over
 
-    // wave t finishes m-tile t : C/D layout of the 16x16 MFMA: m = lane & 15, n = 4 * (lane >> 4) + r
-    for (int t = wave; t < MT; t += KW) {
-        v4i a = part[0][t][lane];
+    // wave w finishes output tiles w, w + KW, ...: tile tt = (m tile tt % MT, feature tile tt / MT); C/D layout of the 16x16
+    // MFMA: m = lane & 15, n = 4 * (lane >> 4) + r
+    for (int tt = wave; tt < MT * NT; tt += KW) {
+        const int t = tt % MT, c0 = (tt / MT) * 16; // (c0: column offset of the feature tile inside the workgroup)
+        v4i a = part[0][tt][lane];
 #pragma unroll
         for (int w2 = 1; w2 < KW; ++w2) {
-            const v4i b = part[w2][t][lane];
+            const v4i b = part[w2][tt][lane];
             a = v4i{a[0] + b[0], a[1] + b[1], a[2] + b[2], a[3] + b[3]};
         }
         const int m = t * 16 + lr;
-        const int nb = n0 + 4 * lq;
+        const int nb = n0 + c0 + 4 * lq;
         if (EPI == EPI_INT32) {
             if (m < p.M && nb < p.N) *reinterpret_cast<v4i*>(static_cast<int32_t*>(p.D) + (int64_t)m * p.N + nb) = a;
             continue;
@@ -152,14 +170,14 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
         v4f P = {0.f, 0.f, 0.f, 0.f};
         if (p.O > 0) {
             const int obytes = p.O * 2;
-            const char* xw = reinterpret_cast<const char*>(p.fpW) + (int64_t)min(n0 + lr, p.N - 1) * obytes;
+            const char* xw = reinterpret_cast<const char*>(p.fpW) + (int64_t)min(n0 + c0 + lr, p.N - 1) * obytes;
             const char* ya = reinterpret_cast<const char*>(p.fpA) + (int64_t)min(m, p.M - 1) * obytes;
-            if (t == wave) { // (always true for KW >= MT) the first PRE steps were requested before the main loop
+            if (tt == wave) { // (the wave's first tile) the first PRE steps were requested before the main loop
 #pragma unroll
                 for (int u = 0; u < PRE; ++u)
                     if (u * 64 < obytes) P = __builtin_amdgcn_mfma_f32_16x16x32_f16(pxf[u], pyf[u], P, 0, 0, 0);
             }
-            for (int k0 = (t == wave ? PRE * 64 : 0); k0 < obytes; k0 += 64) { // 32 outlier columns per step, 8 per lane
+            for (int k0 = (tt == wave ? PRE * 64 : 0); k0 < obytes; k0 += 64) { // 32 outlier columns per step, 8 per lane
                 const int kb = k0 + lq * 16;
                 v8h xf, yf;
                 if (kb < obytes) {
@@ -173,8 +191,8 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
             }
         }
         if (m < p.M && nb < p.N) {
-            const float sa = h2f(t == wave ? psa : p.sA[m]);
-            const uint2 swb = t == wave ? psw : *reinterpret_cast<const uint2*>(p.sW + nb);
+            const float sa = h2f(tt == wave ? psa : p.sA[m]);
+            const uint2 swb = tt == wave ? psw : *reinterpret_cast<const uint2*>(p.sW + nb);
             const uint16_t swh[4] = {(uint16_t)(swb.x & 0xffffu), (uint16_t)(swb.x >> 16), (uint16_t)(swb.y & 0xffffu),
                                      (uint16_t)(swb.y >> 16)};
             uint16_t yh[4] = {0, 0, 0, 0};
@@ -213,6 +231,19 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
 
 static std::atomic<int> g_skinny_kw{0}; // measurement knob: force the K-split width (0 = auto)
 void set_skinny_kw(int kw) { g_skinny_kw.store(kw); }
+static std::atomic<int> g_skinny_nt{0}; // measurement knob: feature tiles per workgroup of the fragment-major form (0 = auto)
+void set_skinny_nt(int nt) { g_skinny_nt.store(nt); }
+// 16-column feature tiles per workgroup (fragment-major form).  Measured (tools/experimental/skinny_wide_probe.sh, 32 rows, us per
+// operator call, 1 vs 2 tiles): 4096 x 4096 9.1 / 12.4, 6144 12.2 / 12.3, 8192 12.8 / 12.8, 11008 16.0 / 17.8, 12288 16.0 / 17.8 --
+// halving the qA bytes does not pay for halving the workgroups -- except where N / 16 workgroups are a little more than one
+// round of the chip (5120 x 5120: 320 workgroups, 18.0 -> 15.0 with 160): 2 tiles only there.
+int skinny_feature_tiles(int M, int N, int K)
+{
+    const int f = g_skinny_nt.load();
+    if (f == 1 || f == 2) return f;
+    const int wgs = (N + 15) / 16, cus = num_cus();
+    return (wgs > cus && 8 * wgs < 11 * cus) ? 2 : 1; // (256, 352) workgroups on 256 CUs
+}
 
 template <int EPI, int KW, int ABL = 0>
 static hipError_t launch_skinny_kw(const GemmParams& p, hipStream_t st)
@@ -221,9 +252,15 @@ static hipError_t launch_skinny_kw(const GemmParams& p, hipStream_t st)
     const int mt = (p.M + 15) / 16;
     if constexpr (KW == 4 && ABL == 0 && EPI != EPI_INT32) {
         if (p.a_frag == 1) { // (decode batches: M <= 32)
+            if (mt > 2) return hipErrorInvalidValue;
+            if (skinny_feature_tiles(p.M, p.N, p.K) == 2) { // wide outputs: 32 features per workgroup
+                const dim3 grid2((unsigned)((p.N + 31) / 32));
+                if (mt == 1) hipLaunchKernelGGL((gemm_skinny_kernel<1, EPI, KW, 0, true, 2>), grid2, block, 0, st, p);
+                else hipLaunchKernelGGL((gemm_skinny_kernel<2, EPI, KW, 0, true, 2>), grid2, block, 0, st, p);
+                return hipGetLastError();
+            }
             if (mt == 1) hipLaunchKernelGGL((gemm_skinny_kernel<1, EPI, KW, 0, true>), grid, block, 0, st, p);
-            else if (mt == 2) hipLaunchKernelGGL((gemm_skinny_kernel<2, EPI, KW, 0, true>), grid, block, 0, st, p);
-            else return hipErrorInvalidValue;
+            else hipLaunchKernelGGL((gemm_skinny_kernel<2, EPI, KW, 0, true>), grid, block, 0, st, p);
             return hipGetLastError();
         }
     }

@@ -129,6 +129,8 @@ bool w8a16_skinny_takes(int M, int N, int K); // the fpA_intB skinny form serves
 void set_wo_force(int form, int ks);
 const char* last_gemm_kernel(); // kernel family launch_gemm chose last (reporting only)
 void set_skinny_kw(int kw); // measurement knob: K-split width of the skinny kernel (0 = auto)
+void set_skinny_nt(int nt); // measurement knob 894 / 895 / 896: feature tiles per workgroup of the fragment-major form auto / 1 / 2
+int skinny_feature_tiles(int M, int N, int K);
 hipError_t launch_gemm_fp16(const void* fpA, const void* fpW, void* Out, int M, int N, int O, hipStream_t st);
 hipError_t launch_dequantization(void* out, const int32_t* x, const void* sRow, const void* sCol, int M, int N,
                                  hipStream_t st);

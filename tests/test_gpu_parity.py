@@ -583,12 +583,15 @@ def test_enqueue_is_capturable_in_a_hip_graph(oracle, M):
 
 
 @pytest.mark.parametrize("M,N,K", [(5, 4096, 4096), (16, 4096, 4096), (17, 4096, 4096), (32, 4096, 4096), (31, 3584, 3584),
-                                   (32, 512, 2064), (9, 12288, 4096), (24, 1024, 8192), (32, 4096, 1088)])
+                                   (32, 512, 2064), (9, 12288, 4096), (24, 1024, 8192), (32, 4096, 1088), (32, 5120, 5120),
+                                   (20, 5136, 2048), (32, 12288, 4096), (32, 18944, 3584)])
 def test_enqueue_decode_batches_fragment_major_qa(oracle, variant, M, N, K):
     """Round 3: for decode batches that the weight-streaming skinny GEMM serves, mixq_enqueue's quantiser writes qA in that
     kernel's MFMA fragment order (one contiguous 1-KiB read per fragment load instead of 16 rows x 64 B).  The operator must
     give the SAME BITS as with the row-major image (knob 890) and match the oracle element by element -- whole and ragged 16-row
-    tiles, K % 64 != 0 (2064: the last k-step is partial), shapes outside the layout's domain (K <= 1024, K = 8192 with scratch:
+    tiles, K % 64 != 0 (2064: the last k-step is partial), 32 features per workgroup (N = 5120 / 5136: a little more than one
+    round of 16-column workgroups; 5136 leaves the last workgroup half empty), the widest output the skinny kernel takes at 32 rows
+    (12288) and one beyond it (18944: two-barrier tiles), shapes outside the layout's domain (K <= 1024, K = 8192 with scratch:
     row-major either way)."""
     A, W, act = make_layer(M, N, K, seed=3 * M + N + K)
     if K % 64 == 0:

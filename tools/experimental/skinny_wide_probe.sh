@@ -1,19 +1,21 @@
-# decode batches of 17..32 rows on WIDE outputs: two-barrier tiles (rule of round 1) vs the skinny kernel with fragment-major qA
+# decode batches on WIDE outputs: two-barrier tiles (893) vs the fragment-major skinny kernel with 1 (892+895) / 2 (892+896)
+# feature tiles per workgroup; operator time through mixq_enqueue (HIP graph of 100 calls)
 cd "$(dirname "$0")/../.."
 python - <<'PY'
-import ctypes, sys, os
+import ctypes, sys, os, io, contextlib
 sys.path.insert(0, os.getcwd())
 import torch
-sys.argv = ["x"]
 import importlib.util
 spec = importlib.util.spec_from_file_location("tl", "tools/small_m_timeline.py"); tl = importlib.util.module_from_spec(spec); spec.loader.exec_module(tl)
 from mixq_tensorrt_llm_amd import _lib
 lib = _lib.load()
-for (M, N, K) in ((32, 12288, 4096), (24, 12288, 4096), (17, 12288, 4096), (32, 11008, 4096), (32, 8192, 4096), (32, 18944, 3584), (32, 28672, 8192), (20, 10240, 8192)):
-    for v in (893, 892):
-        lib.mixq_debug_set_gemm_variant(v)
+shapes = [(32, 12288, 4096), (16, 12288, 4096), (8, 12288, 4096), (32, 11008, 4096), (32, 8192, 4096), (32, 4096, 4096), (16, 4096, 4096), (32, 18944, 3584), (32, 28672, 8192), (20, 10240, 8192), (32, 6144, 4096), (32, 5120, 5120)]
+for (M, N, K) in shapes:
+    row = []
+    for name, knobs in (("rule", (893, 894)), ("skinny NT1", (892, 895)), ("skinny NT2", (892, 896))):
+        for v in knobs:
+            lib.mixq_debug_set_gemm_variant(v)
         sys.argv = ["x", "--M", str(M), "--N", str(N), "--K", str(K)]
-        import io, contextlib
         buf = io.StringIO()
         try:
             with contextlib.redirect_stdout(buf):
@@ -21,6 +23,8 @@ for (M, N, K) in ((32, 12288, 4096), (24, 12288, 4096), (17, 12288, 4096), (32, 
         except Exception:
             pass
         line = [l for l in buf.getvalue().splitlines() if "no stamps" in l][0]
-        kern = [l for l in buf.getvalue().splitlines() if l.startswith("# M=")][0]
-        print(v, kern, "|", line.split(":")[1].strip())
+        kern = [l for l in buf.getvalue().splitlines() if l.startswith("# M=")][0].split("kernel:")[1].strip()[:22]
+        row.append(f"{name} {line.split(':')[1].strip().split()[0]} ({kern})")
+    print(f"{M}x{N}x{K}: " + " | ".join(row), flush=True)
+lib.mixq_debug_set_gemm_variant(893); lib.mixq_debug_set_gemm_variant(894)
 PY
