@@ -189,7 +189,7 @@ MIXQ_API int mixq_gemm_mixed_scratch(const int8_t* qA, const int8_t* W, const vo
 /* ---- qA layouts (MI355X extension; decode batches) --------------------------------------------------------------------------
  * The int8 activation image between a producer (quantiser, fused norm) and the fused GEMM is the library's own intermediate,
  * so the producer may write the layout the consuming kernel reads fastest.  ROW_MAJOR [M,K] is what every reference-named
- * entry above produces and consumes.  FRAGMENT_MAJOR (5..32 rows, K in (1024, 8192], shapes the weight-streaming skinny GEMM
+ * entry above produces and consumes.  FRAGMENT_MAJOR (5..64 rows, K in (1024, 16384], shapes the weight-streaming skinny GEMM
  * serves -- mixq_qa_layout(M, N, K) decides): for 16-row tile t and 64-byte k-step s, the 1-KiB block t * ceil(K / 64) + s holds,
  * at lane * 16, the 16 bytes (row t * 16 + lane % 16, k = s * 64 + (lane / 16) * 16 ...) -- each qA load of that kernel becomes one
  * contiguous 1-KiB read instead of 16 rows x 64 bytes 4 KiB apart: 32 x 4096 x 4096 GEMM 7.9 -> 5.4 us (BASELINE configs[0]

@@ -531,8 +531,8 @@ void set_gemm_variant(int v)
         set_skinny_nt(v - 894);
         return;
     }
-    if (v == 892 || v == 893) { // probe: the skinny kernel for every N up to 32 rows (892) / the measured rule (893, default)
-        g_skinny_wide.store(v == 892 ? 1 : 0);
+    if (v == 892 || v == 893 || v == 897) { // probe: the skinny kernel for every N up to 32 rows (892) / up to 64 rows (897) / the
+        g_skinny_wide.store(v == 892 ? 1 : v == 897 ? 2 : 0); // measured rule (893, default)
         return;
     }
     if (v == 890 || v == 891) { // fragment-major qA for mixq_enqueue's decode batches: 890 off (row-major), 891 on (default)
@@ -655,9 +655,17 @@ bool gemm_tp_fused_supported(int M, int N, int K, int O)
 
 bool gemm_takes_skinny(const GemmParams& p, int epi)
 {
-    const bool xsplit_wins = epi != EPI_INT32 && p.splitk_ws != nullptr && p.K >= 8192 && gemm_xsplit_factor(p.M, p.N, p.K) != 0;
+    const bool frag = p.a_frag == 1; // the caller holds (or, probing, could produce) the fragment-major qA image
+    // long K: the small tiles with K split over workgroups -- unless the image is there, N / 16 workgroups fill the chip and K is
+    // not longer than 12288 (operator us, K split vs skinny on the image: 4096 x 11008 at 32 / 48 rows 20.9 / 21.4 vs 17.6 / 20.0,
+    // 8192 x 8192 at 32 22.4 vs 19.9; 3584 x 18944 25.6 vs 36.9 and 1024 x 28672 24.2 vs 50.0 stay with the K split)
+    const bool xsplit_wins = epi != EPI_INT32 && p.splitk_ws != nullptr && p.K >= 8192 && gemm_xsplit_factor(p.M, p.N, p.K) != 0 &&
+                             !(frag && p.N >= 16 * num_cus() && p.K <= 12288);
     return gemm_variant() != 1 && !xsplit_wins && gemm_skinny_supported(p) &&
-           (p.M <= 16 || (p.M <= 32 && (p.N <= 12288 || g_skinny_wide.load() != 0)));
+           (p.M <= 16 || (p.M <= 32 && (p.N <= 12288 || g_skinny_wide.load() != 0)) ||
+            (frag && ((p.M <= 48 && p.N <= 12288) || (p.M <= 64 && p.N <= 6144))) || (p.M <= 64 && g_skinny_wide.load() == 2));
+    // (33..64 rows, fragment-major image only, operator us, tiles vs skinny: 4096 x 4096 at 40 / 48 / 64 rows 13.4 / 13.5 / 13.5 vs
+    //  10.3 / 10.3 / 11.9; 3584 x 3584 at 64 12.7 / 11.1; 8192 x 4096 at 48 15.9 / 14.5; 12288 x 4096 at 48 19.2 / 18.7, at 64 19.9 / 22.4)
     // (17..32 rows, round 3 with the fragment-major qA image, operator us, tiles vs skinny: N = 8192 15.9 / 12.8, 11008 17.6 / 16.0,
     //  12288 18.8 / 16.0, 18944 x 3584 19.8 / 22.4, 28672 x 8192 41.5 / 49.6: the two-barrier tiles from more than 768 workgroups on.
     //  Callers that pass a row-major image take the same rule: 12288 x 4096 at 32 rows 14.8 skinny vs 15.3 tiles in round 2.)

@@ -252,8 +252,10 @@ static hipError_t launch_skinny_kw(const GemmParams& p, hipStream_t st)
     const int mt = (p.M + 15) / 16;
     if constexpr (KW == 4 && ABL == 0 && EPI != EPI_INT32) {
         if (p.a_frag == 1) { // (decode batches: M <= 32)
-            if (mt > 2) return hipErrorInvalidValue;
-            if (skinny_feature_tiles(p.M, p.N, p.K) == 2) { // wide outputs: 32 features per workgroup
+            if (mt > 4) return hipErrorInvalidValue;
+            if (mt == 3) { hipLaunchKernelGGL((gemm_skinny_kernel<3, EPI, KW, 0, true>), grid, block, 0, st, p); return hipGetLastError(); }
+            if (mt == 4) { hipLaunchKernelGGL((gemm_skinny_kernel<4, EPI, KW, 0, true>), grid, block, 0, st, p); return hipGetLastError(); }
+            if (skinny_feature_tiles(p.M, p.N, p.K) == 2) { // 32 features per workgroup
                 const dim3 grid2((unsigned)((p.N + 31) / 32));
                 if (mt == 1) hipLaunchKernelGGL((gemm_skinny_kernel<1, EPI, KW, 0, true, 2>), grid2, block, 0, st, p);
                 else hipLaunchKernelGGL((gemm_skinny_kernel<2, EPI, KW, 0, true, 2>), grid2, block, 0, st, p);

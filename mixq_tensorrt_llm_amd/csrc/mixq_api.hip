@@ -601,11 +601,13 @@ static int gemm_mixed_impl(const int8_t* qA, const int8_t* W, const void* sA, co
 // ---- qA layouts (MI355X extension): the producer may write the image its consumer reads fastest ---------------------------
 int mixq_qa_layout(int M, int N, int K)
 {
-    if (M <= kSmallMFastPath || M > 32 || N <= 0 || K <= 0 || K % 16 || N % 16) return MIXQ_QA_ROW_MAJOR;
+    if (M <= kSmallMFastPath || M > 64 || N <= 0 || K <= 0 || K % 16 || N % 16) return MIXQ_QA_ROW_MAJOR;
     if (!mixq::qa_frag_enabled() || !mixq::quant_frag_layout_supported(M, K)) return MIXQ_QA_ROW_MAJOR;
-    if (gemm_scratch_bytes(M, N, K) != 0) return MIXQ_QA_ROW_MAJOR; // (a caller with scratch gets a K split there, not the skinny kernel)
     mixq::GemmParams probe{};
-    probe.M = M, probe.N = N, probe.K = K, probe.O = kNumOutliers;
+    probe.M = M, probe.N = N, probe.K = K, probe.O = kNumOutliers, probe.a_frag = 1;
+    static int dummy;
+    if (gemm_scratch_bytes(M, N, K) != 0) probe.splitk_ws = &dummy; // (where a caller WITH scratch would get a K split over workgroups
+                                                                    //  instead of the skinny kernel, the answer must be row-major)
     return mixq::gemm_takes_skinny(probe, mixq::EPI_DEQUANT) ? MIXQ_QA_FRAGMENT_MAJOR : MIXQ_QA_ROW_MAJOR;
 }
 
@@ -659,7 +661,7 @@ int mixq_gemm_mixed_layout(const int8_t* qA, const int8_t* W, const void* sA, co
     if (qa_layout == MIXQ_QA_FRAGMENT_MAJOR) {
         if (O > kNumOutliers || M <= 0 || N <= 0 || K <= 0) return MIXQ_E_SHAPE;
         mixq::GemmParams probe{};
-        probe.M = M, probe.N = N, probe.K = K, probe.O = O;
+        probe.M = M, probe.N = N, probe.K = K, probe.O = O, probe.a_frag = 1;
         probe.splitk_ws = (scratch && scratch_bytes >= gemm_scratch_bytes(M, N, K) && gemm_scratch_bytes(M, N, K)) ? scratch : nullptr;
         if (!mixq::gemm_takes_skinny(probe, mixq::EPI_DEQUANT)) return MIXQ_E_SHAPE; // (the image has ONE reader)
     }
@@ -826,10 +828,11 @@ static int enqueue_impl(const mixq_handle* h, const mixq_tensor_desc* inputDesc,
         //  instruction = one 1-KiB read -- was built and measured on one box: GEMM -0.3 %, quantiser +7.6 % (its row becomes 32
         //  scattered 128-byte stores), prefill tokens/s -0.35 %: docs/LAB_NOTEBOOK.md R3.10.)
         int frag = 0;
-        if (M <= 32 && K % 16 == 0 && N % 16 == 0 && mixq::qa_frag_enabled() && mixq::quant_frag_layout_supported((int)M, (int)K)) {
+        if (M <= 64 && K % 16 == 0 && N % 16 == 0 && mixq::qa_frag_enabled() && mixq::quant_frag_layout_supported((int)M, (int)K)) {
             mixq::GemmParams probe{};
             probe.M = (int)M, probe.N = (int)N, probe.K = (int)K, probe.O = kNumOutliers;
             probe.splitk_ws = scratch;
+            probe.a_frag = 1; // ("if the quantiser writes the fragment-major image, does the skinny kernel take the problem?")
             frag = mixq::gemm_takes_skinny(probe, mixq::EPI_DEQUANT) ? 1 : 0;
         }
         int rc = hip_rc(mixq::launch_quant_extract(const_cast<void*>(A), qA, sA, fpA, ind, (int)M, (int)K, kNumOutliers,

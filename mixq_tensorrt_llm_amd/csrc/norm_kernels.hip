@@ -228,7 +228,7 @@ static hipError_t launch_norm(const uint16_t* X, const uint16_t* gamma, uint16_t
                               const int32_t* ind, int8_t* q, uint16_t* scale, float eps, int M, int K, int O,
                               int quant, hipStream_t st, int q_layout = 0)
 {
-    if constexpr (TPR == 256 && MAXV <= 4) {
+    if constexpr (TPR == 256 && MAXV <= 8) {
         if (q_layout == 1 && quant == 8) {
             const size_t lds = (size_t)((K + 127) / 128) * 16 + (size_t)K * 2;
             static DeviceOnce oncef;
@@ -286,7 +286,7 @@ hipError_t launch_rmsnorm_quant(const void* X, const void* gamma, void* out, voi
     if (nvec <= 64 * 4) return launch_norm<64, 4>(x, g, o, ol, ind, q, sc, eps, M, K, O, quant, st);
     if (nvec <= 64 * 8) return launch_norm<64, 8>(x, g, o, ol, ind, q, sc, eps, M, K, O, quant, st);
     if (nvec <= 64 * 16) return launch_norm<64, 16>(x, g, o, ol, ind, q, sc, eps, M, K, O, quant, st);
-    if (nvec <= 256 * 8) return launch_norm<256, 8>(x, g, o, ol, ind, q, sc, eps, M, K, O, quant, st);
+    if (nvec <= 256 * 8) return launch_norm<256, 8>(x, g, o, ol, ind, q, sc, eps, M, K, O, quant, st, q_layout);
     if (nvec <= 256 * 16) return launch_norm<256, 16>(x, g, o, ol, ind, q, sc, eps, M, K, O, quant, st);
     return hipErrorInvalidValue;
 }

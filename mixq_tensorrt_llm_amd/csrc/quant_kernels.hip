@@ -297,7 +297,7 @@ static hipError_t launch_qe(uint16_t* A, int8_t* qA, uint16_t* sA, uint16_t* fpA
                             int O, bool zero, hipStream_t st, unsigned* zw, int frag = 0)
 {
     void* const dbg = g_quant_stamps.load(std::memory_order_relaxed);
-    if constexpr (TPR == 256 && MAXV <= 4) {
+    if constexpr (TPR == 256 && MAXV <= 8) {
         if (frag == 1) { // decode batches: qA in the skinny GEMM's fragment order (both flavours)
             dim3 grid((unsigned)M), block(QBLOCK);
             if (zero)
@@ -320,7 +320,7 @@ static hipError_t launch_qe(uint16_t* A, int8_t* qA, uint16_t* sA, uint16_t* fpA
     return hipGetLastError();
 }
 
-bool quant_frag_layout_supported(int M, int K) { return M > 0 && M <= 64 && K % 8 == 0 && K / 8 > 64 * 2 && K / 8 <= 256 * 4; }
+bool quant_frag_layout_supported(int M, int K) { return M > 0 && M <= 64 && K % 8 == 0 && K / 8 > 64 * 2 && K / 8 <= 256 * 8; }
 
 hipError_t launch_quant_extract(void* A, int8_t* qA, void* sA, void* fpA, const int32_t* ind, int M, int K, int O,
                                 bool zero, hipStream_t st, void* zero_words, int frag)

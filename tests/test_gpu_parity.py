@@ -584,7 +584,9 @@ def test_enqueue_is_capturable_in_a_hip_graph(oracle, M):
 
 @pytest.mark.parametrize("M,N,K", [(5, 4096, 4096), (16, 4096, 4096), (17, 4096, 4096), (32, 4096, 4096), (31, 3584, 3584),
                                    (32, 512, 2064), (9, 12288, 4096), (24, 1024, 8192), (32, 4096, 1088), (32, 5120, 5120),
-                                   (20, 5136, 2048), (32, 12288, 4096), (32, 18944, 3584)])
+                                   (20, 5136, 2048), (32, 12288, 4096), (32, 18944, 3584), (33, 4096, 4096), (48, 8192, 4096),
+                                   (64, 4096, 4096), (57, 3584, 3584), (64, 12288, 4096), (32, 4096, 11008), (48, 4096, 11008),
+                                   (32, 3584, 18944)])
 def test_enqueue_decode_batches_fragment_major_qa(oracle, variant, M, N, K):
     """Round 3: for decode batches that the weight-streaming skinny GEMM serves, mixq_enqueue's quantiser writes qA in that
     kernel's MFMA fragment order (one contiguous 1-KiB read per fragment load instead of 16 rows x 64 B).  The operator must
