@@ -142,7 +142,8 @@ hipError_t launch_quant_extract(void* A, int8_t* qA, void* sA, void* fpA, const 
                                 int frag = 0); // qA layout: 0 row-major | 1 the skinny GEMM's fragment order (quant_frag_layout_supported)
 bool quant_frag_layout_supported(int M, int K);   // the quantiser can write the fragment-major image for this shape
 bool gemm_takes_skinny(const GemmParams& p, int epi);
-bool qa_frag_enabled(); // test knob 890 / 891 (default on) // launch_gemm would run gemm_skinny_kernel on this problem
+bool qa_frag_enabled(); // test knob 890 / 891 (default on)
+bool probe_a2();        // timing probe 898 / 899 // launch_gemm would run gemm_skinny_kernel on this problem
 void set_quant_stamp_buffer(void* device_u64_8_per_block); // measurement only (NULL in production)
 hipError_t launch_quant_with_scale(const void* src, const void* scale, int8_t* dst, int M, int K, hipStream_t st);
 hipError_t launch_extract(void* A, void* fpA, const int32_t* ind, int M, int K, int O, bool zero, hipStream_t st);
