@@ -8,6 +8,9 @@ alternative the table chose between (forced through mixq_debug_set_gemm_variant)
   gemm_pp128_wins    (csrc/gemm_kernels.hip)        128 x 256 tiles (5) | 256 x 256 tiles (2) | automatic (0)
   wo_skinny_pick     (csrc/w8a16_gemm_kernels.hip)  fpA_intB skinny form automatic (850) | off (851); decode 856 | 857 | 858
   wo_wide_plan       (csrc/w8a16_gemm_kernels.hip)  wide-form tile heights 831..834, K split 86..89 | automatic (80, 85)
+  gemm_takes_skinny  (csrc/gemm_kernels.hip)        decode-batch OPERATOR through mixq_enqueue (quantiser + GEMM; the fragment-major qA
+                                                    image): two-barrier tiles (1) | skinny for any N up to 32 rows (892) / up to 64
+                                                    rows (897) | small-tile K split off (60) | 1 / 2 feature tiles (895 / 896)
 
 A probe is flagged when the automatic choice is more than --tolerance (default 10 %) slower than the best alternative: the
 constants were fitted on one 256-CU / 1400 W box class with +-4 % box-to-box spread; a flag means "re-fit this row", not a bug
@@ -181,7 +184,40 @@ def main():
         auto, _ = pr.time()
         report("wo_wide_plan", f"{M}x{N}x{K}", auto, alts)
         del pr
-    knobs(0, 79, 69, 80, 85, 840, 850, 858)
+    # ---- 5. gemm_takes_skinny: the decode-batch operator through mixq_enqueue ---------------------------------------------------
+    from mixq_tensorrt_llm_amd._lib import TensorDesc
+    decode = [(32, 12288, 4096), (32, 18944, 3584), (48, 4096, 4096), (64, 12288, 4096), (64, 4096, 4096), (32, 4096, 11008),
+              (32, 3584, 18944), (32, 5120, 5120), (24, 8192, 4096), (48, 12288, 4096)]
+    for M, N, K in (decode[::2] if a.quick else decode):
+        g = torch.Generator(device=DEV).manual_seed(M + N + K)
+        W = torch.randint(-127, 128, (N, K), device=DEV, generator=g, dtype=torch.int32).to(torch.int8)
+        ind = torch.randperm(K, device=DEV, generator=g)[:128].to(torch.int32)
+        A = torch.randn((M, K), device=DEV, generator=g).to(torch.float16)
+        sW = (torch.rand(N, device=DEV, generator=g) * 4e-4 + 4e-4).to(torch.float16)
+        fpW = (torch.randn((N, 128), device=DEV, generator=g) * 0.02).to(torch.float16)
+        qw = torch.zeros((K, N), dtype=torch.uint8, device=DEV)
+        ins = [A, W.view(torch.float16), sW, fpW, ind.view(torch.float16), qw.view(torch.float16), sW]
+        out = torch.empty((M, N), dtype=torch.float16, device=DEV)
+        in_desc = (TensorDesc * 7)(*[TensorDesc.make(t.shape) for t in ins])
+        out_desc = TensorDesc.make(out.shape)
+        in_ptrs = (ctypes.c_void_p * 7)(*[t.data_ptr() for t in ins])
+        out_ptrs = (ctypes.c_void_p * 1)(out.data_ptr())
+        h = ctypes.c_void_p(LIB.mixq_create(M, N, K))
+        ws = torch.empty(max(LIB.mixq_workspace_size(h, M, N, K), 16), dtype=torch.uint8, device=DEV)
+
+        def op(st):
+            assert LIB.mixq_enqueue(h, in_desc, ctypes.byref(out_desc), in_ptrs, out_ptrs, ctypes.c_void_p(ws.data_ptr()), st) == 0
+
+        def timed(*ks):
+            LIB.mixq_debug_reset()
+            knobs(*ks)
+            return graph_us(op)
+        alts = {"tiles": timed(1), "skinny<=32": timed(892), "skinny<=64": timed(897), "no-K-split": timed(60),
+                "1-tile": timed(892, 895), "2-tiles": timed(892, 896)}
+        auto = timed()
+        report("gemm_takes_skinny", f"{M}x{N}x{K}", auto, alts)
+        LIB.mixq_destroy(h)
+    LIB.mixq_debug_reset()
     print(f"\n{len(flagged)} probe(s) more than {a.tolerance * 100:.0f} % behind their best alternative")
     for t, s, d in flagged:
         print(f"   {t} {s}: {d * 100:+.1f} %")
