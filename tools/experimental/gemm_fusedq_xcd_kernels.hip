@@ -21,6 +21,10 @@
 //      L2 HITS written microseconds earlier by a neighbour CU -- 8x redundant quantisation (8 KiB read + 4 KiB written per
 //      row and XCD) buys a fragment phase at L2-hit latency instead of Infinity-Cache latency, and one kernel boundary.
 //
+// Second build (same round): the per-XCD copy is written and read FRAGMENT-MAJOR (quant_kernels.hip FRAG, gemm_skinny_kernels.hip
+// AFRAG: block (16-row tile, 64-byte k-step), lane l's 16 bytes at l x 16), which is what made the two-launch operator's
+// fragment phase fast; the first build read a row-major copy and its fragment phase was as slow as before (5.3 us).
+//
 // Visibility argument (gfx950-specific, and deliberately so): producer and consumers of a copy are on the SAME XCD by
 // construction (both index it with the XCC id they read), a CU's vector L1 is write-through and starts every kernel
 // invalidated, no consumer touches the copy before the flags are up, so its loads miss L1 and are served by the one L2
@@ -102,12 +106,16 @@ __device__ __forceinline__ void quant_row(const uint4 (&x)[MAXV], const uint16_t
     const float s = h2f(s_bits);
     const float rs = 1.0f / s;
     if (tid == 0) sA[row] = s_bits;
-    uint2* const dst = reinterpret_cast<uint2*>(qA + row * (int64_t)K);
+    const int nsteps = (K + 63) >> 6;
+    auto slot = [&](int idx) __attribute__((always_inline)) -> uint2* { // 8-byte group idx of the row -> its place in the image
+        const int64_t blk = (row >> 4) * nsteps + (idx >> 3);
+        return reinterpret_cast<uint2*>(qA + (blk << 10) + (((idx >> 1) & 3) << 8) + ((row & 15) << 4) + ((idx & 1) << 3));
+    };
     if (amax_all < 0x7c00 && s_bits != 0) {
 #pragma unroll
         for (int v = 0; v < MAXV; ++v) {
             const int idx = v * 256 + tid;
-            if (idx < nvec) dst[idx] = quant_vec8_finite(x[v], s, rs);
+            if (idx < nvec) *slot(idx) = quant_vec8_finite(x[v], s, rs);
         }
     } else {
         for (int v = 0; v < MAXV; ++v) {
@@ -121,7 +129,7 @@ __device__ __forceinline__ void quant_row(const uint4 (&x)[MAXV], const uint16_t
                     int q1 = quant_one(h2f((uint16_t)(w[e] >> 16)), s);
                     o[e >> 1] |= (unsigned)(q0 | (q1 << 8)) << ((e & 1) * 16);
                 }
-                dst[idx] = make_uint2(o[0], o[1]);
+                *slot(idx) = make_uint2(o[0], o[1]);
             }
         }
     }
@@ -171,10 +179,11 @@ __global__ __launch_bounds__(256) void gemm_skinny_fusedq_kernel(const GemmParam
     }
     // the launch epoch of this XCD's word: ONE returning atomic per workgroup (memory-side, so every workgroup of the launch
     // reads the same value whatever its L2 holds); its latency runs under the row load
+    unsigned long long epoch = 0ull; // (kept in a register until the weight loads are out: its first USE is what waits for it)
     if (tid == 0) {
         unsigned long long zero = 0ull;
         asm volatile("" : "+v"(zero)); // (opaque: a constant 0 lets the compiler turn the RMW into an L2-served sc1 LOAD)
-        sh_tag = __hip_atomic_fetch_add(words + W_EPOCH + xcc * 16, zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
+        epoch = __hip_atomic_fetch_add(words + W_EPOCH + xcc * 16, zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
     const int nsteps = (p.K + 63) >> 6;
@@ -211,6 +220,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_fusedq_kernel(const GemmParam
         psw = *reinterpret_cast<const uint2*>(p.sW + min(fnb, p.N - 4));
     }
     dbg_stamp(p.dbg, 1);
+    if (tid == 0) sh_tag = epoch + 1ull;
     __syncthreads();
     const unsigned long long tag = sh_tag;
 
@@ -273,9 +283,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_fusedq_kernel(const GemmParam
         passed_before = __hip_atomic_fetch_add(words + W_PASSED, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     // ---- 4. the skinny GEMM (gemm_skinny_kernels.hip), first chunk out of the prefetched weights ------------------------
-    const int8_t* arow[MT];
-#pragma unroll
-    for (int t = 0; t < MT; ++t) arow[t] = qA + (int64_t)min(t * 16 + lr, p.M - 1) * K + lq * 16;
+    const int8_t* const aimg = qA + lane * 16; // fragment-major image: block (m tile t, k-step s) at (t * nsteps + s) KiB
     v4i acc[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[t] = v4i{0, 0, 0, 0};
@@ -299,11 +307,12 @@ __global__ __launch_bounds__(256) void gemm_skinny_fusedq_kernel(const GemmParam
             v4i af[8][MT];
 #pragma unroll
             for (int u = u0; u < u0 + 8; ++u) {
-                const int64_t kb = (int64_t)(s0 + u) * 64;
-                const bool ok = u < cnt && kb + lq * 16 < K;
+                const int su = min(s0 + u, s0 + max(cnt, 1) - 1); // (a step past the wave's range re-reads its last one: the weight
+                                                                  //  fragment of such a step is zero, so the product is too)
 #pragma unroll
-                for (int t = 0; t < MT; ++t) af[u - u0][t] = ok ? *reinterpret_cast<const v4i*>(arow[t] + kb) : zero4;
+                for (int t = 0; t < MT; ++t) af[u - u0][t] = *reinterpret_cast<const v4i*>(aimg + ((int64_t)(t * nsteps + su) << 10));
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = u0; u < u0 + 8; ++u)
 #pragma unroll
