@@ -571,8 +571,16 @@ def main():
         # (tools/pmc_bench.sh), committed under profiles/ -- counters cannot be read from inside the run
         t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         if t.get("chunk") == chunk and tp == 1 and args.variant == 0:
-            traffic = t["bytes_per_launch"]
-            traffic_source = "profiles/pmc_traffic.json (" + t.get("collected", "rocprofv3 --pmc, see profiles/README.md") + ")"
+            import hashlib
+            h = hashlib.sha256()
+            for rel in t.get("kernel_sources", []):
+                h.update(open(os.path.join(ROOT, rel), "rb").read())
+            if t.get("kernel_sources_sha256") == h.hexdigest():
+                traffic = t["bytes_per_launch"]
+                traffic_source = "profiles/pmc_traffic.json (" + t.get("collected", "rocprofv3 --pmc, see profiles/README.md") + ")"
+            else:  # the kernel changed since the counters were collected: do not replay another kernel's bytes
+                traffic_source = ("none: profiles/pmc_traffic.json was collected on other kernel sources (sha-256 mismatch); "
+                                  "re-run tools/pmc_bench.sh + tools/pmc_traffic_update.py")
     except Exception:
         traffic = None
     res = None

@@ -94,6 +94,36 @@ __device__ __forceinline__ void glds16_sbase(const char* sbase, unsigned voff, u
                  : "memory");
 }
 
+// The asm form with a per-lane 64-bit source address (for copies whose source is not base + 32-bit offset, e.g. a row
+// clamp or a redirection to the zero page).  Same rules: not counted by the compiler.
+__device__ __forceinline__ void glds16_vaddr(const void* gsrc, unsigned lds_addr)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %2\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_addr)
+                 : "memory");
+}
+
+// 16-byte load into registers, asm form (wave-uniform base + per-lane byte offset + immediate): NOT counted by the
+// compiler either, for loops that keep register prefetches in flight next to asm-form LDS-DMA copies (a counted load's
+// wait would be computed without the copies and drain part of them).  The destination must not be read before an explicit
+// `s_waitcnt vmcnt(n)` followed by vmem_landed() on it (which makes every later use depend on a statement behind the wait).
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+template <int IMM>
+__device__ __forceinline__ void gload16_sbase(v4u& dst, const char* sbase, unsigned voff)
+{
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(IMM) : "memory");
+}
+__device__ __forceinline__ void vmem_landed(v4u& a, v4u& b, v4u& c, v4u& d)
+{
+    asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
+}
+
 // One fp16 quotient with the reference's semantics (kernel/i8gemm.cu:103-104):
 //   (int8) __half2int_rn( __hdiv(x, s) )
 // __hdiv = correctly rounded fp16 division = RNE_fp16(fp32 IEEE quotient) (innocuous double rounding);

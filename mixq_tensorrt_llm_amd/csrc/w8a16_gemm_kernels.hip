@@ -80,8 +80,9 @@ __global__ __launch_bounds__(256 * WM) void w8a16_gemm_kernel(const uint16_t* __
     const int nst = s_end - s_begin;
 
     // ---- weight stream: lane (column n, 16-byte group parity kg) -------------------------------------------------------
+    // asm-form loads (wave-uniform base of the stage + this lane's offset), NOT counted by the compiler: see gload16_sbase
     const int ncol = min(n0w + lr, N - 1);        // clamped columns are computed, never stored
-    const uint8_t* const wbase = Wq + (int64_t)(ncol >> 1) * 2 * K + (ncol & 1) * 64 + lh * 16;
+    const unsigned wlane = (unsigned)(ncol >> 1) * 2u * (unsigned)K + (unsigned)((ncol & 1) * 64 + lh * 16); // N K < 2^32
     v2h scale2;
     {
         _Float16 sc;
@@ -90,16 +91,15 @@ __global__ __launch_bounds__(256 * WM) void w8a16_gemm_kernel(const uint16_t* __
         scale2 = v2h{sc, sc};
     }
     const bool khalf = (K % KB) != 0; // K % 64 == 0 is required, so the only ragged case is a last stage of 64 k
-    auto load_w = [&](uint4 (&w)[4], int s) __attribute__((always_inline)) {
+    auto load_w = [&](v4u (&w)[4], int s) __attribute__((always_inline)) {
         // groups (tbq, j): 64-row block 2s + tbq, 16-byte group 2j + kg of this lane's column
-        const uint8_t* b = wbase + (int64_t)s * 256;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int off = (q >> 1) * 128 + (q & 1) * 32;
-            // a ragged last stage has no second 64-row block: re-read the first (its products meet zero activations)
-            const bool dup = khalf && s == nst_all - 1 && (q >> 1) == 1;
-            w[q] = *reinterpret_cast<const uint4*>(b + (dup ? off - 128 : off));
-        }
+        const char* const b = reinterpret_cast<const char*>(Wq) + (int64_t)s * 256;
+        // a ragged last stage has no second 64-row block: re-read the first (its products meet zero activations)
+        const char* const b2 = (khalf && s == nst_all - 1) ? b : b + 128;
+        gload16_sbase<0>(w[0], b, wlane);
+        gload16_sbase<32>(w[1], b, wlane);
+        gload16_sbase<0>(w[2], b2, wlane);
+        gload16_sbase<32>(w[3], b2, wlane);
     };
 
     // ---- token tile -> LDS: chunk c = i * 256 + tid: row = c / 16, slot = c % 16 holds source chunk slot ^ (row & 15) ----
@@ -112,13 +112,16 @@ __global__ __launch_bounds__(256 * WM) void w8a16_gemm_kernel(const uint16_t* __
         asrc[i] = reinterpret_cast<const char*>(A) + (int64_t)min(row, M - 1) * K * 2 + chunk * 16;
         akoff[i] = chunk * 8; // first k of this chunk inside the stage
     }
+    // (asm-form copies, NOT counted by the compiler: with the builtin every use of a prefetched weight register and every
+    //  LDS read drained ALL outstanding VMEM operations -- the loop ran with no prefetch at all, see glds16_sbase)
+    const unsigned lds0 = (unsigned)(size_t)(MIXQ_LDS_PTR(smem));
     auto stage_a = [&](int buf, int s) __attribute__((always_inline)) {
         const int64_t k0 = (int64_t)s * KB;
 #pragma unroll
         for (int i = 0; i < AL; ++i) {
             const char* src = asrc[i] + k0 * 2;
             if (khalf && k0 + akoff[i] >= K) src = static_cast<const char*>(zeros);
-            glds16(src, smem + buf * STAGE + (i * T + wave * 64) * 16);
+            glds16_vaddr(src, lds0 + buf * STAGE + (i * T + wave * 64) * 16);
         }
     };
 
@@ -138,11 +141,11 @@ __global__ __launch_bounds__(256 * WM) void w8a16_gemm_kernel(const uint16_t* __
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
-    auto compute = [&](const uint4 (&w)[4], int buf) __attribute__((always_inline)) {
+    auto compute = [&](const v4u (&w)[4], int buf) __attribute__((always_inline)) {
         const char* base = smem + buf * STAGE + trow0 * ROWB;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const unsigned d[4] = {w[q].x, w[q].y, w[q].z, w[q].w};
+            const unsigned d[4] = {w[q][0], w[q][1], w[q][2], w[q][3]};
             v2h e2[4], o2[4];
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
@@ -164,7 +167,11 @@ __global__ __launch_bounds__(256 * WM) void w8a16_gemm_kernel(const uint16_t* __
     // ---- main loop: stage i's operands were issued NST-1 iterations earlier; one barrier per stage ----------------------
     // Issue order inside an iteration: weights of stage i + NST - 1 (4 loads), then its token copies (AL): a thread's VMEM
     // operations complete in order, so "at most (NST - 2) groups outstanding" means group i has landed.
-    uint4 w[NST][4];
+    v4u w[NST][4];
+#pragma unroll
+    for (int p = 0; p < NST; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[p][q] = v4u{0u, 0u, 0u, 0u};
 #pragma unroll
     for (int p = 0; p < NST - 1; ++p) {
         if (p < nst) {
@@ -183,6 +190,7 @@ __global__ __launch_bounds__(256 * WM) void w8a16_gemm_kernel(const uint16_t* __
             if (NST > 2 && i + NST - 2 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * GROUP_OPS) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads(); // stage i visible to every wave; everyone is done reading the buffer stage i+NST-1 will reuse
+            vmem_landed(w[u][0], w[u][1], w[u][2], w[u][3]);
             if (i + NST - 1 < nst) {
                 load_w(w[(u + NST - 1) % NST], s_begin + i + NST - 1);
                 stage_a((i + NST - 1) % NST, s_begin + i + NST - 1);
