@@ -557,6 +557,10 @@ void set_gemm_variant(int v)
         set_wo_force(300 + (v - 850), -2);
         return;
     }
+    if (v >= 845 && v <= 847) { // fpA_intB wide form, weights through registers instead of LDS: 845 automatic, 846 never, 847 always
+        set_wo_force(400 + (v - 845), -2);
+        return;
+    }
     if (v == 843 || v == 844) { // second pass of the two-pass form on 256- / 128-row tiles
         set_wo_force(v == 843 ? 203 : 204, -2);
         return;

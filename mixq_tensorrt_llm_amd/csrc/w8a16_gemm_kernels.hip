@@ -290,7 +290,11 @@ constexpr int WSTAGE = BNW * KBW; // weight bytes per stage
 // WMH = 3 ("K halves"): 8 waves like WMH = 2, but the second four take the SECOND k step of every stage for the same rows
 // instead of other rows; the two partial tiles meet in LDS after the loop.  For short tiles: two waves per SIMD (one's
 // dequantisation and LDS waits under the other's MFMAs) where a 4-wave workgroup leaves each SIMD a single wave.
-template <int MTW, int WMH, int NST, int ABL = 0>
+// RW ("register weights", WMH = 1 or 3 only: no other wave of the workgroup wants this wave's weight bytes): the weights
+// skip LDS -- each lane loads its own 16-byte groups straight into registers (asm form, gload16_sbase), NST - 1 stages
+// ahead like the token copies.  A register load costs the issuing wave a few cycles where an LDS-DMA copy costs 60-185,
+// and the ds_read_b128 of the weight groups disappear; LDS holds token stages only.
+template <int MTW, int WMH, int NST, int ABL = 0, bool RW = false>
 __global__ __launch_bounds__(256 * (WMH == 3 ? 2 : WMH)) void w8a16_gemm_wide_kernel(const uint16_t* __restrict__ A, const uint8_t* __restrict__ Wq,
                                                                const uint16_t* __restrict__ scale,
                                                                uint16_t* __restrict__ Out, int M, int N, int K, int ks,
@@ -301,10 +305,13 @@ __global__ __launch_bounds__(256 * (WMH == 3 ? 2 : WMH)) void w8a16_gemm_wide_ke
     constexpr int T = 256 * (KH ? 2 : WMH);       // WMH = 1: 4 waves (one per SIMD, each all rows), 2: 8 waves (two row halves)
     constexpr int ROWS = (KH ? 1 : WMH) * MTW * 32; // token rows of the workgroup tile
     constexpr int TA = KH ? 256 : T;              // threads that hold finished accumulators (K halves: waves 0-3 after the merge)
+    static_assert(!RW || WMH != 2, "register weights: one wave per column group and k step");
+    static_assert(!RW || ABL == 0, "");
     constexpr int ASTAGE = ROWS * ROWBW;          // token bytes of one stage
-    constexpr int STAGE = ASTAGE + WSTAGE;        // [tokens | raw weights]
+    constexpr int STAGE = ASTAGE + (RW ? 0 : WSTAGE); // [tokens | raw weights]
     constexpr int AL = ROWS * 8 / T;              // token copies (16 B) per thread per stage
-    constexpr int WL = WSTAGE / 16 / T;           // weight copies per thread per stage (2 or 4)
+    constexpr int NJ = KH ? 1 : 2;                // k steps of a stage this wave runs
+    constexpr int WL = RW ? 2 * NJ : WSTAGE / 16 / T; // weight copies (loads) per thread per stage (2 or 4)
     constexpr int GROUP_OPS = AL + WL;            // VMEM operations a thread issues per stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -354,9 +361,20 @@ __global__ __launch_bounds__(256 * (WMH == 3 ? 2 : WMH)) void w8a16_gemm_wide_ke
     }
 #pragma unroll
     for (int i = 0; i < WL; ++i) {
-        const int pl = (i * T + tid) >> 3, gq = (tid & 7) ^ ((pl >> 1) & 3);
-        woffv[i] = (unsigned)(min(pair0 + pl, npairs - 1) - pair0) * (unsigned)K * 2u + (unsigned)(gq << 4);
+        if constexpr (RW) { // load i = cb * NJ + j: this lane's group (column parity, 2 j + kg) of its column pair's 64-row block
+            const int cb = i / NJ, j = KH ? wmh : i % NJ;
+            const int pl = wn * 32 + cb * 16 + (lr >> 1), g = (lr & 1) * 4 + 2 * j + lh;
+            woffv[i] = (unsigned)(min(pair0 + pl, npairs - 1) - pair0) * (unsigned)K * 2u + (unsigned)(g << 4);
+        } else {
+            const int pl = (i * T + tid) >> 3, gq = (tid & 7) ^ ((pl >> 1) & 3);
+            woffv[i] = (unsigned)(min(pair0 + pl, npairs - 1) - pair0) * (unsigned)K * 2u + (unsigned)(gq << 4);
+        }
     }
+    v4u wreg[RW ? NST : 1][RW ? WL : 1]; // (RW) [stage buffer][cb * NJ + j]: raw 16-byte groups, NST - 1 stages ahead
+#pragma unroll
+    for (int b = 0; b < (RW ? NST : 1); ++b)
+#pragma unroll
+        for (int i = 0; i < (RW ? WL : 1); ++i) wreg[b][i] = v4u{0u, 0u, 0u, 0u};
     const unsigned lds0 = (unsigned)(size_t)(MIXQ_LDS_PTR(smem)) + wave * 1024;
     auto issue = [&](int rel, int buf) __attribute__((always_inline)) { // stage s_begin + rel -> buffer buf
         if ((ABL & 1) && rel >= NST - 1) return;
@@ -365,12 +383,16 @@ __global__ __launch_bounds__(256 * (WMH == 3 ? 2 : WMH)) void w8a16_gemm_wide_ke
 #pragma unroll
         for (int i = 0; i < AL; ++i) glds16_sbase(ab, aoffv[i], lds0 + buf * STAGE + i * T * 16);
 #pragma unroll
-        for (int i = 0; i < WL; ++i) glds16_sbase(wb, woffv[i], lds0 + buf * STAGE + ASTAGE + i * T * 16);
+        for (int i = 0; i < WL; ++i) {
+            if constexpr (RW) gload16_sbase<0>(wreg[buf][i], wb, woffv[i]);
+            else glds16_sbase(wb, woffv[i], lds0 + buf * STAGE + ASTAGE + i * T * 16);
+        }
     };
     // the same copies one piece at a time (p < GROUP_OPS: token pieces first), for spreading them over a stage's MFMA groups
     auto issue_piece = [&](int rel, int buf, int pc) __attribute__((always_inline)) {
         if ((ABL & 1) && rel >= NST - 1) return;
         if (pc < AL) glds16_sbase(abase + (int64_t)rel * (KBW * 2), aoffv[pc], lds0 + buf * STAGE + pc * T * 16);
+        else if constexpr (RW) gload16_sbase<0>(wreg[buf][pc - AL], wbase + (int64_t)rel * 128, woffv[pc - AL]);
         else glds16_sbase(wbase + (int64_t)rel * 128, woffv[pc - AL], lds0 + buf * STAGE + ASTAGE + (pc - AL) * T * 16);
     };
 
@@ -436,10 +458,14 @@ __global__ __launch_bounds__(256 * (WMH == 3 ? 2 : WMH)) void w8a16_gemm_wide_ke
         o2[2 * h + 1] = wo_dequant_pair(d1, 0x04030401u, sc);
     };
     // certify group g: the NST-2 groups issued after it may still be in flight (fewer near the end: drain instead)
-    auto certify = [&](int g) __attribute__((always_inline)) {
+    auto certify = [&](int g, int buf) __attribute__((always_inline)) {
         if (NST > 2 && g + NST - 2 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * GROUP_OPS) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if constexpr (RW) { // every later use of this stage's weight registers depends on a statement behind the wait
+#pragma unroll
+            for (int i = 0; i < WL; ++i) asm volatile("" : "+v"(wreg[buf][i])::"memory");
+        }
     };
     // one k step: MFMAs of (j, all row tiles) with the operands E[j] / O[j]; meanwhile `wnext` ([cb] raw groups) is
     // dequantised into E[j ^ 1] / O[j ^ 1] (DEQ) and the token fragments of the next (j, t) are read
@@ -511,7 +537,7 @@ __global__ __launch_bounds__(256 * (WMH == 3 ? 2 : WMH)) void w8a16_gemm_wide_ke
             {
                 // stage i certified at its top; step 0's weights are dequantised in the open, step 1's under step 0's MFMAs
                 // (K halves: each wave runs ONE step per stage, its own)
-                certify(i);
+                certify(i, u);
                 // the copies of stage i + NST - 1 are spread over this stage's tile steps: a global_load_lds costs the issuing
                 // wave 60-185 cycles, six or more of them in a row at the top of a stage are a third of a short tile's stage
                 const bool more = i + NST - 1 < nst;
@@ -529,8 +555,14 @@ __global__ __launch_bounds__(256 * (WMH == 3 ? 2 : WMH)) void w8a16_gemm_wide_ke
                 uint4 w0[2];
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb) {
-                    w0[cb] = *reinterpret_cast<const uint4*>(sb + woff[cb][0]);
-                    wr[cb] = *reinterpret_cast<const uint4*>(sb + woff[cb][1]);
+                    if constexpr (RW) {
+                        const v4u a = wreg[u][cb * NJ], b = wreg[u][cb * NJ + NJ - 1];
+                        w0[cb] = uint4{a[0], a[1], a[2], a[3]};
+                        wr[cb] = uint4{b[0], b[1], b[2], b[3]};
+                    } else {
+                        w0[cb] = *reinterpret_cast<const uint4*>(sb + woff[cb][0]);
+                        wr[cb] = *reinterpret_cast<const uint4*>(sb + woff[cb][1]);
+                    }
                 }
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb)
@@ -870,6 +902,7 @@ static std::atomic<int> g_wo_skinny_decode{-1}; // 2..4 tokens through the skinn
 static std::atomic<int> g_wo_skinny{1}; // the skinny form up to 32 tokens: 1 automatic, 0 off, 2..5 a fixed shape (measurements)
 static std::atomic<int> g_wo_twopass_tile{0}; // (measurements, with the form forced) row height of the second pass's tiles; 0: 256
 static std::atomic<int> g_wo_twopass{-1}; // -1 automatic, 0 never, 1 whenever the shape allows it (measurements, tests)
+static std::atomic<int> g_wo_rw{-1};   // weights through registers (configurations 1, 2, 5, 6): -1 automatic, 0 never, 1 always
 static std::atomic<int> g_wo_form{-1}; // measurement knob: -1 automatic, else the configuration index
 static std::atomic<int> g_wo_ks{-1};   // -1 automatic, else the K split of the wide form (where K allows)
 void set_wo_force(int form, int ks)
@@ -886,6 +919,10 @@ void set_wo_force(int form, int ks)
         g_wo_skinny.store(form == 300 ? 1 : form == 301 ? 0 : form - 300);
         return;
     }
+    if (form >= 400 && form <= 402) { // register weights: automatic / never / always
+        g_wo_rw.store(form == 400 ? -1 : form - 401);
+        return;
+    }
     if (form == 203 || form == 204) { // second pass of the two-pass form on 256- / 128-row tiles
         g_wo_twopass_tile.store(form == 203 ? 256 : 128);
         return;
@@ -898,7 +935,7 @@ void set_wo_force(int form, int ks)
         g_wo_abl.store(form - 100);
         return;
     }
-    if (form == -1) g_wo_abl.store(0), g_wo_twopass.store(-1), g_wo_twopass_tile.store(0), g_wo_skinny.store(1), g_wo_skinny_decode.store(-1);
+    if (form == -1) g_wo_abl.store(0), g_wo_twopass.store(-1), g_wo_twopass_tile.store(0), g_wo_skinny.store(1), g_wo_skinny_decode.store(-1), g_wo_rw.store(-1);
     if (form >= -1 && form <= 6) g_wo_form.store(form);
     if (ks >= -1) g_wo_ks.store(ks);
 }
@@ -1056,14 +1093,16 @@ static hipError_t launch_wo_skinny(const uint16_t* A, const uint8_t* Wq, const u
     return hipGetLastError();
 }
 
-template <int MTW, int WMH, int NST, int ABL = 0>
+template <int MTW, int WMH, int NST, int ABL = 0, bool RW = false>
 static hipError_t launch_wo_wide(const uint16_t* A, const uint8_t* Wq, const uint16_t* scale, uint16_t* Out, int M, int N,
                                  int K, int ks, void* scratch, hipStream_t st)
 {
     constexpr int rows = 32 * MTW * (WMH == 3 ? 1 : WMH);
-    constexpr size_t lds = (size_t)NST * (rows * wo::ROWBW + wo::WSTAGE);
+    constexpr size_t stages = (size_t)NST * (rows * wo::ROWBW + (RW ? 0 : wo::WSTAGE));
+    constexpr size_t merge = WMH == 3 ? (size_t)2 * MTW * 16 * 256 * sizeof(float) : 0; // K halves meet in LDS after the loop
+    constexpr size_t lds = stages > merge ? stages : merge;
     static_assert(lds <= 160 * 1024 - 64, "LDS budget");
-    auto kern = w8a16_gemm_wide_kernel<MTW, WMH, NST, ABL>;
+    auto kern = w8a16_gemm_wide_kernel<MTW, WMH, NST, ABL, RW>;
     static DeviceOnce once;
     if (hipError_t e = ensure_dynamic_lds(kern, lds, once); e != hipSuccess) return e;
     const int tiles = ((M + rows - 1) / rows) * ((N + wo::BNW - 1) / wo::BNW);
@@ -1131,6 +1170,15 @@ hipError_t launch_w8a16_gemm(const void* A, const uint8_t* Wq, const void* scale
             case 8: return launch_wo_wide<4, 3, 4, 8>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
             case 7: return launch_wo_wide<4, 3, 4, 7>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
             case 14: return launch_wo_wide<4, 3, 4, 14>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
+            default: break;
+            }
+        }
+        if (g_wo_rw.load() == 1 && g_wo_abl.load() == 0) {
+            switch (pl.cfg) {
+            case 1: return launch_wo_wide<1, 1, 6, 0, true>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
+            case 2: return launch_wo_wide<2, 1, 6, 0, true>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
+            case 5: return launch_wo_wide<2, 3, 6, 0, true>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
+            case 6: return launch_wo_wide<4, 3, 4, 0, true>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
             default: break;
             }
         }

@@ -112,6 +112,7 @@ def form():
     lib = _lib.load()
     yield lib.mixq_debug_set_gemm_variant
     lib.mixq_debug_set_gemm_variant(843)
+    lib.mixq_debug_set_gemm_variant(845)  # (weights through registers: automatic again)
     lib.mixq_debug_set_gemm_variant(80)   # (also: two-pass form automatic again)
     lib.mixq_debug_set_gemm_variant(85)
 
@@ -152,6 +153,29 @@ def test_every_configuration_of_the_wide_form(oracle, form, cfg, ks, M, N, K):
     got, _ = run(A, qi, sc, N, scratch=True)
     assert np.isfinite(got).all() and rel_err(got, want) < REL_TOL
     assert_elementwise(got, want, w8a16_slack(A, q, sc))
+
+
+@pytest.mark.parametrize("rw", [846, 847])
+@pytest.mark.parametrize("cfg", [831, 832, 835, 836])
+@pytest.mark.parametrize("ks", [85, 86, 88])
+@pytest.mark.parametrize("M,N,K", [(5, 130, 192), (33, 258, 320), (64, 128, 4160), (129, 640, 1088), (257, 256, 2048),
+                                   (300, 1026, 1600), (96, 2050, 1024)])
+def test_wide_form_with_weights_through_registers_or_lds(oracle, form, rw, cfg, ks, M, N, K):
+    """The configurations whose waves share no weight bytes (4-wave tiles and the K-halves forms) can take their weight groups
+    straight into registers (847) instead of through LDS (846): same arithmetic, same k order -- against the oracle, and bit
+    for bit against each other."""
+    A, q, sc = make(M, N, K, M + 3 * N + K + cfg)
+    qi = interleave(q)
+    want = oracle.w8a16_gemv(A, q, sc)
+    form(cfg)
+    form(ks)
+    form(rw)
+    got, _ = run(A, qi, sc, N, scratch=True)
+    assert np.isfinite(got).all() and rel_err(got, want) < REL_TOL
+    assert_elementwise(got, want, w8a16_slack(A, q, sc))
+    form(846 if rw == 847 else 847)
+    other, _ = run(A, qi, sc, N, scratch=True)
+    assert np.array_equal(got.view(np.uint16), other.view(np.uint16))
 
 
 @pytest.mark.parametrize("M,N,K", [(5, 8, 64), (33, 264, 320), (300, 1032, 1600), (700, 136, 448), (1300, 2304, 1088),
@@ -228,6 +252,7 @@ def test_randomised_soak_over_forms_and_shapes(oracle, form):
         form(85)
         form(f)
         form(k)
+        form(846 + it % 2)
         got, _ = run(A, qi, sc, N, scratch=bool(it % 3))
         assert np.isfinite(got).all(), (it, M, N, K, f, k)
         assert rel_err(got, want) < REL_TOL, (it, M, N, K, f, k, rel_err(got, want))
