@@ -569,7 +569,7 @@ void set_gemm_variant(int v)
         set_wo_force(200 + (v - 840), -2);
         return;
     }
-    if (v >= 831 && v <= 838) { // fpA_intB wide-form configuration 1..8 (w8a16_gemm_kernels.hip kWoCfg)
+    if (v >= 831 && v <= 836) { // fpA_intB wide-form configuration 1..4 (w8a16_gemm_kernels.hip kWoCfg)
         set_wo_force(v - 830, -2);
         return;
     }

@@ -294,29 +294,22 @@ constexpr int WSTAGE = BNW * KBW; // weight bytes per stage
 // skip LDS -- each lane loads its own 16-byte groups straight into registers (asm form, gload16_sbase), NST - 1 stages
 // ahead like the token copies.  A register load costs the issuing wave a few cycles where an LDS-DMA copy costs 60-185,
 // and the ds_read_b128 of the weight groups disappear; LDS holds token stages only.
-// WMH = 4 ("stage halves", always RW): 8 waves on the same rows like the K halves, but a stage is 128 k = two 64-row
-// blocks and the second four waves take the SECOND BLOCK of every stage: one barrier per 128 k, and each wave runs both k
-// steps of its block, so only the first step's dequantisation is in the open (the K halves dequantise every step in the
-// open and meet at a barrier every 64 k).  NST counts 128-k stages.
 template <int MTW, int WMH, int NST, int ABL = 0, bool RW = false>
-__global__ __launch_bounds__(256 * (WMH >= 3 ? 2 : WMH)) void w8a16_gemm_wide_kernel(const uint16_t* __restrict__ A, const uint8_t* __restrict__ Wq,
+__global__ __launch_bounds__(256 * (WMH == 3 ? 2 : WMH)) void w8a16_gemm_wide_kernel(const uint16_t* __restrict__ A, const uint8_t* __restrict__ Wq,
                                                                const uint16_t* __restrict__ scale,
                                                                uint16_t* __restrict__ Out, int M, int N, int K, int ks,
                                                                void* __restrict__ scratch)
 {
     using namespace wo;
-    constexpr bool KH = WMH == 3, SH = WMH == 4, K2 = KH || SH; // (K2: two wave groups on the same rows, merged after the loop)
-    constexpr int T = 256 * (K2 ? 2 : WMH);       // WMH = 1: 4 waves (one per SIMD, each all rows), 2: 8 waves (two row halves)
-    constexpr int ROWS = (K2 ? 1 : WMH) * MTW * 32; // token rows of the workgroup tile
-    constexpr int TA = K2 ? 256 : T;              // threads that hold finished accumulators (K halves: waves 0-3 after the merge)
+    constexpr bool KH = WMH == 3;
+    constexpr int T = 256 * (KH ? 2 : WMH);       // WMH = 1: 4 waves (one per SIMD, each all rows), 2: 8 waves (two row halves)
+    constexpr int ROWS = (KH ? 1 : WMH) * MTW * 32; // token rows of the workgroup tile
+    constexpr int TA = KH ? 256 : T;              // threads that hold finished accumulators (K halves: waves 0-3 after the merge)
     static_assert(!RW || WMH != 2, "register weights: one wave per column group and k step");
     static_assert(!RW || ABL == 0, "");
-    static_assert(!SH || (RW && MTW % 2 == 0), "stage halves: register weights, whole copies per block");
-    constexpr int BLK = SH ? 2 : 1;               // 64-row blocks (64 k) per stage
-    constexpr int ASTAGE = ROWS * ROWBW;          // token bytes of one block
-    constexpr int STAGE = BLK * ASTAGE + (RW ? 0 : WSTAGE); // [tokens (per block) | raw weights]
-    constexpr int AB = ROWS * 8 / T;              // token copies (16 B) per thread per block
-    constexpr int AL = BLK * AB;                  // ... per stage
+    constexpr int ASTAGE = ROWS * ROWBW;          // token bytes of one stage
+    constexpr int STAGE = ASTAGE + (RW ? 0 : WSTAGE); // [tokens | raw weights]
+    constexpr int AL = ROWS * 8 / T;              // token copies (16 B) per thread per stage
     constexpr int NJ = KH ? 1 : 2;                // k steps of a stage this wave runs
     constexpr int WL = RW ? 2 * NJ : WSTAGE / 16 / T; // weight copies (loads) per thread per stage (2 or 4)
     constexpr int GROUP_OPS = AL + WL;            // VMEM operations a thread issues per stage
@@ -346,12 +339,11 @@ __global__ __launch_bounds__(256 * (WMH >= 3 ? 2 : WMH)) void w8a16_gemm_wide_ke
     }
     const int m0 = tile_m * ROWS;
     const int n0w = tile_n * BNW + wn * 64;       // first column of this wave
-    const int trow0 = K2 ? 0 : wmh * MTW * 32;    // first token row of this wave inside the tile
+    const int trow0 = KH ? 0 : wmh * MTW * 32;    // first token row of this wave inside the tile
 
-    const int nst_all = K / KBW;                  // 64-row blocks of K; this workgroup's: [s_begin, s_end)
+    const int nst_all = K / KBW;
     const int s_begin = (int)((int64_t)nst_all * krank / ks), s_end = (int)((int64_t)nst_all * (krank + 1) / ks);
-    const int nblk = s_end - s_begin;
-    const int nst = (nblk + BLK - 1) / BLK;       // stages (stage halves: the last one may hold a single block)
+    const int nst = s_end - s_begin;
 
     // ---- stage copies: wave-uniform base + per-thread offset, destination = this wave's 1-KiB window of each 8-KiB row --
     // tokens: chunk c = i * T + tid: row = c / 8, slot = c % 8 holds source chunk slot ^ ((row / 2) % 8): rows are 128 B = half a
@@ -363,8 +355,8 @@ __global__ __launch_bounds__(256 * (WMH >= 3 ? 2 : WMH)) void w8a16_gemm_wide_ke
     const char* const wbase = reinterpret_cast<const char*>(Wq) + (int64_t)pair0 * 2 * K + (int64_t)s_begin * 128;
     unsigned aoffv[AL], woffv[WL];
 #pragma unroll
-    for (int i = 0; i < AL; ++i) { // copy i: block i / AB, piece i % AB of it
-        const int row = ((i % AB) * T + tid) >> 3, slot = tid & 7;
+    for (int i = 0; i < AL; ++i) {
+        const int row = (i * T + tid) >> 3, slot = tid & 7;
         aoffv[i] = (unsigned)(min(m0 + row, M - 1) - m0) * (unsigned)K * 2u + (unsigned)((slot ^ ((row >> 1) & 7)) << 4);
     }
 #pragma unroll
@@ -384,22 +376,24 @@ __global__ __launch_bounds__(256 * (WMH >= 3 ? 2 : WMH)) void w8a16_gemm_wide_ke
 #pragma unroll
         for (int i = 0; i < (RW ? WL : 1); ++i) wreg[b][i] = v4u{0u, 0u, 0u, 0u};
     const unsigned lds0 = (unsigned)(size_t)(MIXQ_LDS_PTR(smem)) + wave * 1024;
-    // one copy / load of stage `rel` (pc < GROUP_OPS: token pieces first).  Stage halves: a block past the end of a ragged
-    // last stage is fetched from the last real block instead (never read: the operation counts per stage stay fixed)
-    auto issue_piece = [&](int rel, int buf, int pc) __attribute__((always_inline)) {
+    auto issue = [&](int rel, int buf) __attribute__((always_inline)) { // stage s_begin + rel -> buffer buf
         if ((ABL & 1) && rel >= NST - 1) return;
-        if (pc < AL) {
-            const int blk = SH ? min(BLK * rel + pc / AB, nblk - 1) : rel;
-            glds16_sbase(abase + (int64_t)blk * (KBW * 2), aoffv[pc], lds0 + buf * STAGE + (pc / AB) * ASTAGE + (pc % AB) * T * 16);
-        } else {
-            const int blk = SH ? min(BLK * rel + wmh, nblk - 1) : rel; // (stage halves: this wave group's block)
-            if constexpr (RW) gload16_sbase<0>(wreg[buf][pc - AL], wbase + (int64_t)blk * 128, woffv[pc - AL]);
-            else glds16_sbase(wbase + (int64_t)blk * 128, woffv[pc - AL], lds0 + buf * STAGE + ASTAGE + (pc - AL) * T * 16);
+        const char* const ab = abase + (int64_t)rel * (KBW * 2);
+        const char* const wb = wbase + (int64_t)rel * 128;
+#pragma unroll
+        for (int i = 0; i < AL; ++i) glds16_sbase(ab, aoffv[i], lds0 + buf * STAGE + i * T * 16);
+#pragma unroll
+        for (int i = 0; i < WL; ++i) {
+            if constexpr (RW) gload16_sbase<0>(wreg[buf][i], wb, woffv[i]);
+            else glds16_sbase(wb, woffv[i], lds0 + buf * STAGE + ASTAGE + i * T * 16);
         }
     };
-    auto issue = [&](int rel, int buf) __attribute__((always_inline)) { // stage rel of this workgroup -> buffer buf
-#pragma unroll
-        for (int pc = 0; pc < GROUP_OPS; ++pc) issue_piece(rel, buf, pc);
+    // the same copies one piece at a time (p < GROUP_OPS: token pieces first), for spreading them over a stage's MFMA groups
+    auto issue_piece = [&](int rel, int buf, int pc) __attribute__((always_inline)) {
+        if ((ABL & 1) && rel >= NST - 1) return;
+        if (pc < AL) glds16_sbase(abase + (int64_t)rel * (KBW * 2), aoffv[pc], lds0 + buf * STAGE + pc * T * 16);
+        else if constexpr (RW) gload16_sbase<0>(wreg[buf][pc - AL], wbase + (int64_t)rel * 128, woffv[pc - AL]);
+        else glds16_sbase(wbase + (int64_t)rel * 128, woffv[pc - AL], lds0 + buf * STAGE + ASTAGE + (pc - AL) * T * 16);
     };
 
     // ---- fragment read offsets ----------------------------------------------------------------------------------------
@@ -538,8 +532,7 @@ __global__ __launch_bounds__(256 * (WMH >= 3 ? 2 : WMH)) void w8a16_gemm_wide_ke
             const int i = i0 + u;
             if (i >= nst) break;
             const char* const sb = smem + u * STAGE;
-            const char* const base = sb + (SH ? wmh * ASTAGE : trow0 * ROWBW);
-            const bool have = !SH || BLK * i + wmh < nblk; // (stage halves: a ragged last stage has no second block)
+            const char* const base = sb + trow0 * ROWBW;
             uint4 wr[2];
             {
                 // stage i certified at its top; step 0's weights are dequantised in the open, step 1's under step 0's MFMAs
@@ -548,10 +541,6 @@ __global__ __launch_bounds__(256 * (WMH >= 3 ? 2 : WMH)) void w8a16_gemm_wide_ke
                 // the copies of stage i + NST - 1 are spread over this stage's tile steps: a global_load_lds costs the issuing
                 // wave 60-185 cycles, six or more of them in a row at the top of a stage are a third of a short tile's stage
                 const bool more = i + NST - 1 < nst;
-                // (only the LAST stage can lack its second block, and the last stage issues no copies: the idle wave group has
-                //  nothing to do but keep the barrier count.  No asm load may sit on a path of its own: the register allocator
-                //  would be free to give it other destination registers and copy them -- before the data has landed)
-                if (!have) continue;
                 constexpr int TS = (KH ? 1 : 2) * MTW; // tile steps of a stage (per wave)
                 auto before_tile = [&](int jj, int tt) __attribute__((always_inline)) {
                     const int ts = (KH ? 0 : jj) * MTW + tt;
@@ -593,7 +582,7 @@ __global__ __launch_bounds__(256 * (WMH >= 3 ? 2 : WMH)) void w8a16_gemm_wide_ke
     }
 
     // ---- K halves: waves 4-7 hand their partial tile to waves 0-3 through LDS (the stage buffers are dead) ---------------
-    if constexpr (K2) {
+    if constexpr (KH) {
         __syncthreads();
         float* const xch = reinterpret_cast<float*>(smem) + (tid & 255);
         if (wmh == 1) {
@@ -614,7 +603,7 @@ __global__ __launch_bounds__(256 * (WMH >= 3 ? 2 : WMH)) void w8a16_gemm_wide_ke
                     for (int e = 0; e < 16; ++e) acc[cb][t][e] += xch[((cb * MTW + t) * 16 + e) * 256];
         }
     }
-    const bool holder = !K2 || wmh == 0; // this wave holds finished accumulators (the others only keep the barrier count)
+    const bool holder = !KH || wmh == 0; // this wave holds finished accumulators (the others only keep the barrier count)
 
     // ---- K split over workgroups: park, count in, the last one to arrive adds the parts in rank order -----------------
     if (ks > 1) {
@@ -892,7 +881,7 @@ static size_t wo_narrow_workspace(int rows, int N, int K)
 struct WoCfg {
     int rows, mtw, wmh;
 };
-static constexpr WoCfg kWoCfg[9] = {
+static constexpr WoCfg kWoCfg[7] = {
     {0, 0, 0},    // 0: the narrow form above, in passes of 256 tokens
     {32, 1, 1},   // 1: 4 waves x (32 rows x 64 columns)
     {64, 2, 1},   // 2: 4 waves x (64 x 64)
@@ -900,8 +889,6 @@ static constexpr WoCfg kWoCfg[9] = {
     {256, 4, 2},  // 4: 8 waves x (128 x 64)
     {64, 2, 3},   // 5: 8 waves x (64 x 64), the second four on the second k step of every stage ("K halves")
     {128, 4, 3},  // 6: 8 waves x (128 x 64), K halves: every weight dequantised once per workgroup
-    {64, 2, 4},   // 7: 8 waves x (64 x 64), stage halves: 128-k stages, the second four waves on the second 64-row block
-    {128, 4, 4},  // 8: 8 waves x (128 x 64), stage halves
 };
 // (Measured and dropped: 4 "fat" waves x (128 x 64) and 4 x (256 x 64), one wave per SIMD, every weight dequantised once
 // per workgroup instead of once per row half -- equal to / 5-8 % slower than the 8-wave forms of the same height.)
@@ -949,7 +936,7 @@ void set_wo_force(int form, int ks)
         return;
     }
     if (form == -1) g_wo_abl.store(0), g_wo_twopass.store(-1), g_wo_twopass_tile.store(0), g_wo_skinny.store(1), g_wo_skinny_decode.store(-1), g_wo_rw.store(-1);
-    if (form >= -1 && form <= 8) g_wo_form.store(form);
+    if (form >= -1 && form <= 6) g_wo_form.store(form);
     if (ks >= -1) g_wo_ks.store(ks);
 }
 
@@ -969,9 +956,8 @@ static WoWidePlan wo_wide_plan(int M, int N, int K, bool have_scratch)
     //  tiles by ~8 %: 12288 x 4096 22.1 vs 24.1 us, 16384 x 4096 24.0 vs 26.0; not at K = 8192)
     if (form < 0 && M > 48 && M <= 64 && N >= 10240 && K <= 6144) return {0, 1};
     const int cus = num_cus(), tn = (N + wo::BNW - 1) / wo::BNW, nst = K / wo::KBW;
-    static constexpr float kStage[9] = {0.f, 0.61f, 0.75f, 1.25f, 2.1f, 0.75f, 1.13f, 0.75f, 1.13f};
-    static constexpr float kHand0[9] = {0.f, 2.f, 3.f, 10.f, 12.f, 3.f, 10.f, 3.f, 10.f};
-    static constexpr float kHand1[9] = {0.f, 0.8f, 1.3f, 2.5f, 4.3f, 1.3f, 2.5f, 1.3f, 2.5f};
+    static constexpr float kStage[7] = {0.f, 0.61f, 0.75f, 1.25f, 2.1f, 0.75f, 1.13f};
+    static constexpr float kHand0[7] = {0.f, 2.f, 3.f, 10.f, 12.f, 3.f, 10.f}, kHand1[7] = {0.f, 0.8f, 1.3f, 2.5f, 4.3f, 1.3f, 2.5f};
     WoWidePlan best{3, 1};
     float best_t = 1e30f;
     for (int c = 1; c <= (form >= 5 ? form : 4); ++c) {
@@ -1111,16 +1097,16 @@ template <int MTW, int WMH, int NST, int ABL = 0, bool RW = false>
 static hipError_t launch_wo_wide(const uint16_t* A, const uint8_t* Wq, const uint16_t* scale, uint16_t* Out, int M, int N,
                                  int K, int ks, void* scratch, hipStream_t st)
 {
-    constexpr int rows = 32 * MTW * (WMH >= 3 ? 1 : WMH);
-    constexpr size_t stages = (size_t)NST * ((WMH == 4 ? 2 : 1) * rows * wo::ROWBW + (RW ? 0 : wo::WSTAGE));
-    constexpr size_t merge = WMH >= 3 ? (size_t)2 * MTW * 16 * 256 * sizeof(float) : 0; // K / stage halves meet in LDS after the loop
+    constexpr int rows = 32 * MTW * (WMH == 3 ? 1 : WMH);
+    constexpr size_t stages = (size_t)NST * (rows * wo::ROWBW + (RW ? 0 : wo::WSTAGE));
+    constexpr size_t merge = WMH == 3 ? (size_t)2 * MTW * 16 * 256 * sizeof(float) : 0; // K halves meet in LDS after the loop
     constexpr size_t lds = stages > merge ? stages : merge;
     static_assert(lds <= 160 * 1024 - 64, "LDS budget");
     auto kern = w8a16_gemm_wide_kernel<MTW, WMH, NST, ABL, RW>;
     static DeviceOnce once;
     if (hipError_t e = ensure_dynamic_lds(kern, lds, once); e != hipSuccess) return e;
     const int tiles = ((M + rows - 1) / rows) * ((N + wo::BNW - 1) / wo::BNW);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * ks)), dim3(256 * (WMH >= 3 ? 2 : WMH)), lds, st, A, Wq, scale, Out, M, N, K, ks,
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * ks)), dim3(256 * (WMH == 3 ? 2 : WMH)), lds, st, A, Wq, scale, Out, M, N, K, ks,
                        scratch);
     return hipGetLastError();
 }
@@ -1187,7 +1173,9 @@ hipError_t launch_w8a16_gemm(const void* A, const uint8_t* Wq, const void* scale
             default: break;
             }
         }
-        if (g_wo_rw.load() == 1 && g_wo_abl.load() == 0) {
+        // weights through registers wherever the configuration allows it (automatic): bit-identical, -7..-10 % on the 4-wave
+        // 64-row tiles, -0..-6 % on the K-halves forms (profiles/r03_w8a16_register_weights_probe.txt)
+        if (g_wo_rw.load() != 0 && g_wo_abl.load() == 0) {
             switch (pl.cfg) {
             case 1: return launch_wo_wide<1, 1, 6, 0, true>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
             case 2: return launch_wo_wide<2, 1, 6, 0, true>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
@@ -1196,8 +1184,6 @@ hipError_t launch_w8a16_gemm(const void* A, const uint8_t* Wq, const void* scale
             default: break;
             }
         }
-        if (pl.cfg == 7) return launch_wo_wide<2, 4, 4, 0, true>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
-        if (pl.cfg == 8) return launch_wo_wide<4, 4, 4, 0, true>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
         switch (pl.cfg) {
         case 1: return launch_wo_wide<1, 1, 6>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
         case 2: return launch_wo_wide<2, 1, 6>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
