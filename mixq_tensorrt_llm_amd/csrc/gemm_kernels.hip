@@ -194,6 +194,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KG * 64) void gemm_w8a8o16_kernel
     // ---- main loop -------------------------------------------------------------------------------------
     // NSTAGE LDS buffers, slices kt+1 .. kt+NSTAGE-1 in flight while slice kt is multiplied.  Small tiles are bound by
     // the HBM round trip of each slice, not by MFMA work: the deeper the prefetch, the more bytes in flight per CU.
+    // (Round 3, read off the ISA: with the BUILTIN copies used here hipcc puts `s_waitcnt vmcnt(0)` in front of every
+    //  __syncthreads() -- a pending LDS-DMA copy is a pending LDS write to the fence -- so in steady state only the slice issued
+    //  one iteration ago is in flight; NSTAGE > 2 buys the first NSTAGE - 1 slices up front.  The asm-form copies
+    //  (glds16_vaddr, explicit waits only) that really keep NSTAGE - 1 slices in flight measured +-1..3 % on 30 shapes from 48
+    //  to 512 tokens (profiles/r03_tile_kernel_asm_dma_ab.txt): several workgroups per CU already cover the round trip.  Left
+    //  as it was.)
     // (group g owns slices g, g + KG, ...: its it-th slice is kt = it * KG + g; every group runs the same number of
     //  iterations because the barrier is workgroup-wide)
 #pragma unroll
