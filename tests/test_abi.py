@@ -251,3 +251,18 @@ def test_scratch_of_any_shape_fits_the_plugin_workspace(lib):
             assert carved_m + lib.mixq_gemm_scratch_size(m, N, K) <= ws, (m, M, N, K)
     assert used > 20
     lib.mixq_destroy(h)
+
+
+def test_asm_load_registers_are_not_moved_before_they_land():
+    """The fpA_intB GEMM prefetches weights with asm-form loads the compiler does not track (mixq_device.h gload16_sbase); its
+    loops are written so that hipcc has no reason to copy a destination register while the load is in flight.  Checked on the
+    ISA this toolchain produces (tools/asm_load_check.py; ~12 s of hipcc): every kernel with such loads, no register move on
+    their destination registers between the top of the main loop and the last load."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("asm_load_check", os.path.join(ROOT, "tools", "asm_load_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.check_isa(mod.compile_to_isa(mod.DEFAULT[0]))
+    assert len(res) >= 8, [r[0] for r in res]          # narrow form x 4, register-weight wide forms x 4
+    for name, n_loads, bad in res:
+        assert n_loads > 0 and not bad, (name, bad[:4])
