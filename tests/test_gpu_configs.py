@@ -162,3 +162,48 @@ def test_bench_configuration_at_full_size_on_sampled_rows(oracle, name, N, K):
     assert np.array_equal(acc[ridx].cpu().numpy(), parts["acc"])
     del acc, out
     torch.cuda.empty_cache()
+
+
+def test_one_million_tokens_in_one_call_on_sampled_rows(oracle):
+    """Maximum size: BASELINE configs[2]'s 512 x 2048 = 1 048 576 tokens as ONE mixq_enqueue (the reference sizes its workspace
+    with `int` and overflows here; this library's sizes are size_t).  M K = 2^32 and M N = 2^32 exactly on
+    4096 x 4096: every row offset of the last rows needs more than 32 bits in the quantiser, the GEMM loads and the stores.
+    Oracle on 48 sampled rows incl. the first and last of the call and both sides of the 2^31- and 2^32-byte marks."""
+    import bench
+    from mixq_tensorrt_llm_amd import plugin
+    M, N, K = 1 << 20, 4096, 4096
+    dev = torch.device("cuda:0")
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40 << 30:
+        pytest.skip("needs ~25 GB of device memory")
+    gen = torch.Generator(device=dev).manual_seed(4242)
+    t = bench.synth_layer(N, K, dev, gen)
+    A = torch.empty((M, K), dtype=torch.float16, device=dev)
+    for m0 in range(0, M, 1 << 16):                      # (chunked fill: bounds the generator's fp32 temporaries)
+        A[m0:m0 + (1 << 16)] = bench.synth_activation(1 << 16, K, t["ind_i32"], dev, gen)
+    marks = [0, 1, 255, 256, (1 << 18) - 1, 1 << 18, (1 << 19) - 1, 1 << 19, (1 << 19) + 1, M - 257, M - 256, M - 2, M - 1]
+    rows = np.unique(np.concatenate([marks, np.random.default_rng(7).integers(0, M, 35)]))[:48]
+    ridx = torch.from_numpy(rows).to(dev)
+    plug = plugin.MixQPlugin.create(M, N, K)
+    out = plug.enqueue([A, t["weight"], t["weights_scaling_factor"], t["fp_weight"], t["fp_ind"], t["qweight"],
+                        t["weights_scaling_factor"]])
+    torch.cuda.synchronize()
+    assert tuple(out.shape) == (M, N)
+    got = out[ridx].cpu().numpy()
+    A_s = A[ridx].cpu().numpy()
+    W8 = t["weight"].view(torch.int8).reshape(N, K)
+    want, parts = oracle.linear_prefill(A_s, W8.cpu().numpy(), t["weights_scaling_factor"].cpu().numpy(),
+                                        t["fp_weight"].cpu().numpy(), t["ind_i32"].cpu().numpy(), return_parts=True)
+    assert np.isfinite(got).all()
+    assert rel_err(got, want) < REL_TOL
+    assert_elementwise(got, want, prefill_slack(parts, A_s, dict(fp_ind=t["ind_i32"].cpu().numpy().astype(np.int64),
+                                                                 fp_weight=t["fp_weight"].cpu().numpy())),
+                       "one million tokens in one call")
+    # rows are independent: the same rows as a 48-token call of their own give the same bits
+    small = plugin.MixQPlugin.create(64, N, K).enqueue([A[ridx].contiguous(), t["weight"], t["weights_scaling_factor"],
+                                                        t["fp_weight"], t["fp_ind"], t["qweight"],
+                                                        t["weights_scaling_factor"]])
+    torch.cuda.synchronize()
+    assert rel_err(small.cpu().numpy(), want) < REL_TOL
+    del out, A
+    torch.cuda.empty_cache()
