@@ -382,6 +382,31 @@ def _fused_worker(rank, world, port, tmp):
             ok &= np.array_equal(small.cpu().numpy().view(np.uint16), want[:40].view(np.uint16))
             layer.peer_gather.close()
             dist.barrier()
+        # back to back: 36 calls of two sizes with NO host synchronisation in between, one rank or the other arriving late
+        # (device-side delay) -- chunk flags, counters and the two destination buffers under load, every element checked
+        M, N, K = 2048, 12288, 256
+        A, full = exact_fixture(M, N, K, 77)
+        mine = parallel.shard_packed(full, world, rank)
+        want_d = torch.from_numpy(oracle.linear_prefill(A, full["weight"], full["weights_scaling_factor"], full["fp_weight"],
+                                                        full["fp_ind"]).view(np.int16).copy()).cuda()
+        layer = plugin.MixQLinear(K, N, bias=False, tp_size=world, gather_output=True, device="cuda:0").load(mine)
+        layer.peer_gather = parallel.PeerGather(M, N, world, rank, "cuda:0")
+        Ad = torch.from_numpy(A).cuda()
+        bad = torch.zeros((), dtype=torch.int64, device="cuda:0")
+        for c in range(36):
+            m = M if c % 3 else 1800
+            if c % 4 == rank + 1:
+                torch.cuda._sleep(2000000 + 300000 * (c % 5))
+            got = layer(Ad[:m])
+            bad += (got.view(torch.int16) != want_d[:m]).sum()
+        torch.cuda.synchronize()
+        layer.peer_gather.check(sync=True)
+        if int(bad.item()) != 0:
+            ok = False
+            notes.append(f"back-to-back fused gathers: {int(bad.item())} wrong elements")
+        ok &= int(layer.peer_gather.small.abs().sum()) == 0
+        layer.peer_gather.close()
+        dist.barrier()
     except Exception:  # noqa: BLE001
         import traceback
         ok = False
