@@ -956,8 +956,9 @@ static WoWidePlan wo_wide_plan(int M, int N, int K, bool have_scratch)
     //  tiles by ~8 %: 12288 x 4096 22.1 vs 24.1 us, 16384 x 4096 24.0 vs 26.0; not at K = 8192)
     if (form < 0 && M > 48 && M <= 64 && N >= 10240 && K <= 6144) return {0, 1};
     const int cus = num_cus(), tn = (N + wo::BNW - 1) / wo::BNW, nst = K / wo::KBW;
-    static constexpr float kStage[7] = {0.f, 0.61f, 0.75f, 1.25f, 2.1f, 0.75f, 1.13f};
-    static constexpr float kHand0[7] = {0.f, 2.f, 3.f, 10.f, 12.f, 3.f, 10.f}, kHand1[7] = {0.f, 0.8f, 1.3f, 2.5f, 4.3f, 1.3f, 2.5f};
+    // (round 3: 32- / 64-row tiles with their weights through registers: -9 / -8 %; K halves -2 %)
+    static constexpr float kStage[7] = {0.f, 0.56f, 0.69f, 1.25f, 2.1f, 0.73f, 1.11f};
+    static constexpr float kHand0[7] = {0.f, 2.f, 3.f, 10.f, 12.f, 3.f, 10.f}, kHand1[7] = {0.f, 0.8f, 2.1f, 2.5f, 4.3f, 2.1f, 2.5f};
     WoWidePlan best{3, 1};
     float best_t = 1e30f;
     for (int c = 1; c <= (form >= 5 ? form : 4); ++c) {
