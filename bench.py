@@ -643,11 +643,11 @@ def main():
 
         def bail():
             if rank == 0:
-                res["tp"] = {"tp": world, "error": "watchdog: the tp = N measurement did not finish in 600 s"}
+                res["tp"] = {"tp": world, "error": "watchdog: the tp = N measurement did not finish in 300 s"}
                 emit(res)
             os._exit(0)
 
-        wd = threading.Timer(600.0, bail)
+        wd = threading.Timer(300.0, bail)   # (a healthy leg takes well under a minute; a hung collective must not cost the line)
         wd.daemon = True
         wd.start()
         try:
@@ -665,8 +665,9 @@ def main():
                       "value": args.tokens * args.tp_steps / t_el, "unit": "tokens/s",
                       "ms_per_step": t_el / args.tp_steps * 1e3, "median_ms_per_step": t_med, "steps": args.tp_steps,
                       "warmup": 1, "scaling": "strong",
-                      "collective": "one all-gather of the fp16 output per linear per chunk, on a side stream (overlaps "
-                                    "the next GEMM)", "transport": tmodel.transport, "peer_wait_timed_out": timed_out,
+                      "collective": "one all-gather of the fp16 output per linear per chunk" + (
+                          ", written by the GEMM's own stores as its M chunks retire" if tmodel.fused
+                          else ", on a side stream (overlaps the next GEMM)"), "transport": tmodel.transport, "peer_wait_timed_out": timed_out,
                       "allgather_recv_GB_per_gpu_per_step": recv / 1e9,
                       "tokens_per_step": args.tokens}
             if timed_out:  # a stale gather is not a measurement
