@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--variant3", type=int, default=None, help="a third knob")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--what", default="both")
+    ap.add_argument("--scratch-bound", action="store_true", help="hand the GEMM a scratch of mixq_gemm_scratch_bound() bytes")
     ap.add_argument("--check", action="store_true", help="compare the output with the plain launch bit for bit (20 rounds)")
     ap.add_argument("--zero", action="store_true", help="zero-filled operands (DVFS ceiling probe)")
     ap.add_argument("--qa-mode", default="", help="power probe (wrong results): replace qA after the quantiser -- 'offset8' = "
@@ -57,6 +58,8 @@ def main():
         assert lib.mixq_quant_extract(M, K, p(A), p(qA), p(sA), p(fpA), p(ind), O, 0, st) == 0
 
     nscr = lib.mixq_gemm_scratch_size(M, N, K)   # > 0 only with --variant 72 / 74 / 79 (K split over workgroups)
+    if a.scratch_bound:                          # (measurement configurations that split K without a plan of their own)
+        nscr = max(nscr, lib.mixq_gemm_scratch_bound())
     scr = torch.zeros(max(nscr, 16), dtype=torch.uint8, device=dev)
 
     def gemm():
