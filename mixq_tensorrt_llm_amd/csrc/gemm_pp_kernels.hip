@@ -734,8 +734,11 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp_kernel(const GemmParams p
                 continue;
             }
             char* dst = dwave + (int64_t)row * p.N * 2 + dlane;
-            if (interior) *reinterpret_cast<uint4*>(dst) = v[q];
-            else if (n_ok && m0 + wm * 128 + row + (int)(ln >> 3) < p.M) *reinterpret_cast<uint4*>(dst) = v[q];
+            const v4i vv = {(int)v[q].x, (int)v[q].y, (int)v[q].z, (int)v[q].w};
+            // (non-temporal: the 2 M N output bytes are never read by this launch; streaming them past the L2 leaves it to the operand
+            //  panels: -0.7 / -1.6 / -2.6 % on 16384 x 12288 x 4096 / 11008 x 4096 / 4096 x 11008, profiles/r03_nt_store_ab.txt)
+            if (interior) __builtin_nontemporal_store(vv, reinterpret_cast<v4i*>(dst));
+            else if (n_ok && m0 + wm * 128 + row + (int)(ln >> 3) < p.M) __builtin_nontemporal_store(vv, reinterpret_cast<v4i*>(dst));
         }
     };
     // software pipeline over the 8 tiles (j-major): the MFMA chain of tile t+1 runs under the VALU work of tile t

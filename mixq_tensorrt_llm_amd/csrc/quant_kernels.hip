@@ -143,11 +143,20 @@ __global__ __launch_bounds__(QBLOCK) void quant_extract_kernel(uint16_t* __restr
         const int64_t blk = (r >> 4) * nsteps + (idx >> 3);                               // (tile, k-step)
         return reinterpret_cast<uint2*>(qA + (blk << 10) + (((idx >> 1) & 3) << 8) + ((r & 15) << 4) + ((idx & 1) << 3));
     };
+    const bool stream_out = FRAG == 0 && (int64_t)M * K >= ((int64_t)8 << 20); // (launch-uniform)
     if (amax_all < 0x7c00 && s_bits != 0) { // every element finite, scale finite and non-zero (row-uniform)
 #pragma unroll
         for (int v = 0; v < MAXV; ++v) {
             const int idx = v * TPR + t;
-            if (row_ok && idx < nvec) *slot(idx) = quant_vec8_finite(x[v], s, rs);
+            if (row_ok && idx < nvec) {
+                typedef unsigned v2u_ __attribute__((ext_vector_type(2)));
+                const uint2 q8 = quant_vec8_finite(x[v], s, rs);
+                // prefill-size images stream past the L2 (non-temporal): nothing of this launch reads them, and the GEMM that does
+                // starts after the end-of-kernel write-back anyway: -3.5..-7 % on the quantiser (profiles/r03_quant_nt_ab.txt).
+                // (Non-temporal LOADS of the row were measured too: +27 %, the outlier gather re-reads the row's lines.)
+                if (stream_out) __builtin_nontemporal_store(v2u_{q8.x, q8.y}, reinterpret_cast<v2u_*>(slot(idx)));
+                else *slot(idx) = q8;
+            }
         }
     } else { // inf / NaN elements, zero scale (zero or tiny row): quotients may be inf / NaN -> exact chain
         for (int v = 0; v < MAXV; ++v) {
