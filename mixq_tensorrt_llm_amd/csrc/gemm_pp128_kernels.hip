@@ -411,8 +411,9 @@ __global__ __launch_bounds__(512) void gemm_w8a8o16_pp128_kernel(const GemmParam
             if (q & 1) v[q] = uint4{v[q].z, v[q].w, v[q].x, v[q].y}; // rows with bit 3 set hold their 8-B halves swapped
             const int row = j * 32 + q * 8;     // wave-uniform
             char* dst = dwave + (int64_t)row * p.N * 2 + dlane;
-            if (interior) *reinterpret_cast<uint4*>(dst) = v[q];
-            else if (n_ok && m0 + wm * 64 + row + (lane >> 3) < p.M) *reinterpret_cast<uint4*>(dst) = v[q];
+            const v4i vv = {(int)v[q].x, (int)v[q].y, (int)v[q].z, (int)v[q].w}; // (non-temporal: see gemm_pp_kernels.hip)
+            if (interior) __builtin_nontemporal_store(vv, reinterpret_cast<v4i*>(dst));
+            else if (n_ok && m0 + wm * 64 + row + (lane >> 3) < p.M) __builtin_nontemporal_store(vv, reinterpret_cast<v4i*>(dst));
         }
     };
     {
