@@ -199,11 +199,17 @@ __global__ __launch_bounds__(NBLOCK) void rmsnorm_quant_kernel(const uint16_t* _
         const int64_t blk = (r >> 4) * ((K + 63) >> 6) + (idx >> 3);
         return reinterpret_cast<uint2*>(q + (blk << 10) + (((idx >> 1) & 3) << 8) + ((r & 15) << 4) + ((idx & 1) << 3));
     };
+    const bool stream_out = !FRAG && (int64_t)M * K >= ((int64_t)8 << 20); // prefill-size images: non-temporal stores (launch-uniform)
     if (amax_all < 0x7c00 && s_bits != 0) { // every element finite, scale finite and non-zero (row-uniform)
 #pragma unroll
         for (int v = 0; v < MAXV; ++v) {
             const int idx = v * TPR + t;
-            if (row_ok && idx < nvec) *slot(idx) = quant_vec8_finite(x[v], s, rs);
+            if (row_ok && idx < nvec) {
+                typedef unsigned v2u_ __attribute__((ext_vector_type(2)));
+                const uint2 q8 = quant_vec8_finite(x[v], s, rs);
+                if (stream_out) __builtin_nontemporal_store(v2u_{q8.x, q8.y}, reinterpret_cast<v2u_*>(slot(idx))); // (quant_kernels.hip)
+                else *slot(idx) = q8;
+            }
         }
     } else {
         for (int v = 0; v < MAXV; ++v) {
