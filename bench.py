@@ -136,9 +136,37 @@ def small_m_points(lib, TensorDesc, dev, gen, st_ptr, iters=300):
             assert rc == 0
 
         dt = graph_time_us(run, dev) * 1e-6
-        lib.mixq_destroy(h)
         out[name] = {"us_per_call": dt * 1e6, "weight_GBps": N * K / dt / 1e9, "hbm_frac": N * K / dt / 8e12,
-                     "launches_per_call": 2 if M > 4 else 1, "timing": "HIP graph of 100 calls (device-paced)"}
+                     "launches_per_call": 2 if M > 4 else 1, "timing": "HIP graph of 100 calls (device-paced)",
+                     "cache": "warm: every call re-reads the SAME layer's weights, which the 256 MiB Infinity Cache then serves"}
+        # the same point with COLD weights, as in a model's decode step (every layer's weights come from HBM once per step):
+        # the calls of the graph cycle through enough distinct copies of the streamed weight tensor to exceed the Infinity Cache
+        try:
+            widx = 1 if M > 4 else 5                      # `weight` (int8 [N, K]) feeds M > 4, `qweight` the decode path
+            copies = (320 << 20) // (N * K) + 2
+            alts = [ins[widx]] + [ins[widx].clone() for _ in range(copies - 1)]
+            ptr_sets = []
+            for wcopy in alts:
+                v = [x.data_ptr() for x in ins]
+                v[widx] = wcopy.data_ptr()
+                ptr_sets.append((ctypes.c_void_p * 7)(*v))
+            turn = [0]
+
+            def run_cold(st):
+                rc = lib.mixq_enqueue(h, in_desc, ctypes.byref(out_desc), ptr_sets[turn[0] % copies], out_ptrs,
+                                      ctypes.c_void_p(ws.data_ptr()), st)
+                turn[0] += 1
+                assert rc == 0
+
+            dc = graph_time_us(run_cold, dev) * 1e-6
+            out[name]["cold"] = {"us_per_call": dc * 1e6, "weight_GBps": N * K / dc / 1e9, "hbm_frac": N * K / dc / 8e12,
+                                 "weight_copies_cycled": copies,
+                                 "what": f"{copies} distinct copies of the weight tensor ({copies * N * K >> 20} MiB > the "
+                                         "Infinity Cache), one per call in turn: every call streams its weights from HBM"}
+            del alts
+        except Exception as e:  # noqa: BLE001
+            out[name]["cold"] = {"error": repr(e)}
+        lib.mixq_destroy(h)
     # BASELINE config 0 on the route the reference's PyTorch flavour really takes in decode (MixQ/src/mixquant/modules/fused/
     # norm.py:20-33 -> layernorm.cu:122-198, then linear.py's int8FusedDequantize): the RMSNorm in front of the linear -- a
     # launch the model runs anyway -- normalises, extracts the outliers and quantises in one pass, so the LINEAR is one launch
