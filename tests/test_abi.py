@@ -266,3 +266,23 @@ def test_asm_load_registers_are_not_moved_before_they_land():
     assert len(res) >= 8, [r[0] for r in res]          # narrow form x 4, register-weight wide forms x 4
     for name, n_loads, bad in res:
         assert n_loads > 0 and not bad, (name, bad[:4])
+
+
+def test_header_is_valid_c99_and_cxx11_and_the_c_host_links(tmp_path):
+    """include/mixq.h is the product's boundary: it must compile, warning-free and pedantic, as C99 and as C++11 (the
+    reference's plugin host is C++), and the plain C host of tests/c_abi/ must build and link against the library with
+    nothing but gcc, the HIP runtime and libm (it RUNS in tests/test_gpu_c_host.py)."""
+    import subprocess
+    inc = os.path.join(ROOT, "include")
+    for compiler, std, ext in (("gcc", "-std=c99", "c"), ("g++", "-std=c++11", "cpp")):
+        src = tmp_path / f"hdr.{ext}"
+        src.write_text('#include "mixq.h"\nint main(void) { return mixq_plugin_type() == 0; }\n')
+        r = subprocess.run([compiler, std, "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", inc, "-fsyntax-only", str(src)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    exe = tmp_path / "host_example"
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-Wno-unused-parameter", "-I", inc, "-I", "/opt/rocm/include",
+                        os.path.join(ROOT, "tests", "c_abi", "host_example.c"), "-o", str(exe), "-L",
+                        os.path.join(ROOT, "mixq_tensorrt_llm_amd"), "-l:libmixq_mi355x.so", "-L", "/opt/rocm/lib", "-lamdhip64", "-lm",
+                        "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0 and exe.exists(), r.stderr
