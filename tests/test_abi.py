@@ -268,7 +268,7 @@ def test_asm_load_registers_are_not_moved_before_they_land():
         assert n_loads > 0 and not bad, (name, bad[:4])
 
 
-def test_header_is_valid_c99_and_cxx11_and_the_c_host_links(tmp_path):
+def test_headers_are_valid_c99_and_cxx11_and_the_c_and_cxx_hosts_link(tmp_path):
     """include/mixq.h is the product's boundary: it must compile, warning-free and pedantic, as C99 and as C++11 (the
     reference's plugin host is C++), and the plain C host of tests/c_abi/ must build and link against the library with
     nothing but gcc, the HIP runtime and libm (it RUNS in tests/test_gpu_c_host.py)."""
@@ -280,9 +280,16 @@ def test_header_is_valid_c99_and_cxx11_and_the_c_host_links(tmp_path):
         r = subprocess.run([compiler, std, "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", inc, "-fsyntax-only", str(src)],
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
-    exe = tmp_path / "host_example"
-    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-Wno-unused-parameter", "-I", inc, "-I", "/opt/rocm/include",
-                        os.path.join(ROOT, "tests", "c_abi", "host_example.c"), "-o", str(exe), "-L",
-                        os.path.join(ROOT, "mixq_tensorrt_llm_amd"), "-l:libmixq_mi355x.so", "-L", "/opt/rocm/lib", "-lamdhip64", "-lm",
-                        "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
-    assert r.returncode == 0 and exe.exists(), r.stderr
+    # the C++ mirror of the reference's two plugin classes (include/mixq_plugin.hpp) is header-only C++11
+    src = tmp_path / "hpp.cpp"
+    src.write_text('#include "mixq_plugin.hpp"\nint main() { mixq_plugin::MixQPluginCreator c; return c.getPluginName() == nullptr; }\n')
+    r = subprocess.run(["g++", "-std=c++11", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", inc, "-fsyntax-only", str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    link = ["-L", os.path.join(ROOT, "mixq_tensorrt_llm_amd"), "-l:libmixq_mi355x.so", "-L", "/opt/rocm/lib", "-lamdhip64", "-lm",
+            "-Wl,-rpath,/opt/rocm/lib"]
+    for compiler, std, name in (("gcc", "-std=c99", "host_example.c"), ("g++", "-std=c++17", "host_example.cpp")):  # (HIP's headers want C++17)
+        exe = tmp_path / (name + ".out")
+        r = subprocess.run([compiler, std, "-Wall", "-Wextra", "-Werror", "-Wno-unused-parameter", "-I", inc, "-I", "/opt/rocm/include",
+                            os.path.join(ROOT, "tests", "c_abi", name), "-o", str(exe)] + link, capture_output=True, text=True)
+        assert r.returncode == 0 and exe.exists(), r.stderr
