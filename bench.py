@@ -417,6 +417,7 @@ def main():
     ap.add_argument("--order", choices=["layer", "chunk"], default="layer",
                     help="layer: each linear sees all tokens before the next one (batched prefill); chunk: chunked prefill")
     ap.add_argument("--no-tp-leg", action="store_true", help="skip the tp = N measurement at N > 1")
+    ap.add_argument("--no-tp-alternatives", action="store_true", help="tp = N leg: do not time the other transports (one step each)")
     ap.add_argument("--tp-steps", type=int, default=3, help="timed steps of the tp = N measurement")
     ap.add_argument("--variant", type=int, default=0, help="GEMM schedule: 0 auto, 1 two-barrier, 2 ping-pong (A/B runs)")
     args = ap.parse_args()
@@ -669,9 +670,14 @@ def main():
     elif not args.no_tp_leg:
         import threading
 
+        partial = {}   # what the leg has measured so far (the watchdog emits it instead of nothing)
+
         def bail():
             if rank == 0:
-                res["tp"] = {"tp": world, "error": "watchdog: the tp = N measurement did not finish in 300 s"}
+                if partial.get("tp"):
+                    res["tp"] = dict(partial["tp"], watchdog="the comparison of transports did not finish in time")
+                else:
+                    res["tp"] = {"tp": world, "error": "watchdog: the tp = N measurement did not finish in 300 s"}
                 emit(res)
             os._exit(0)
 
@@ -701,6 +707,32 @@ def main():
             if timed_out:  # a stale gather is not a measurement
                 tp_obj = {"tp": world, "world_size": world, "transport": tmodel.transport,
                           "error": "a peer-write wait timed out: the gathered outputs of this leg are not valid"}
+            partial["tp"] = tp_obj
+            # The other transports of the same layout, one timed step each (first contact with a multi-GPU node should say
+            # which one wins there; every rank takes the same branches: the transport was agreed on above).  Order: from the
+            # transport just measured down to plain RCCL; a failure here costs only this comparison.
+            if not timed_out and not args.no_tp_alternatives:
+                wd.cancel()
+                wd = threading.Timer(240.0, bail)
+                wd.daemon = True
+                wd.start()
+                alts = {}
+                try:
+                    keep = dict(tmodel.gatherers)
+                    if tmodel.fused:
+                        tmodel.fused = {}
+                        a_el, _, _, _ = timed_run(tmodel, None, 1, 1, False)
+                        alts["peer writes by a push kernel after the GEMM (mixq_tp_push_columns + flags)"] = {"ms_per_step": a_el * 1e3}
+                    if tmodel.gatherers:
+                        if any(g.timed_out() for g in tmodel.gatherers.values()):
+                            raise RuntimeError("a peer-write wait timed out")
+                        tmodel.gatherers = {}
+                        a_el, _, _, _ = timed_run(tmodel, None, 1, 1, False)
+                        alts["rccl all_gather_into_tensor + column placement"] = {"ms_per_step": a_el * 1e3}
+                        tmodel.gatherers = keep
+                except Exception as e:  # noqa: BLE001
+                    alts["error"] = repr(e)
+                tp_obj["alternatives_one_step_each"] = alts
         except Exception as e:  # noqa: BLE001 -- the main measurement must survive
             tp_obj = {"tp": world, "error": repr(e)}
         wd.cancel()

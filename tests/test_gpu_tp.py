@@ -338,6 +338,9 @@ def test_bench_self_launches_at_two_ranks(tmp_path):
     assert "error" not in tp, tp
     assert tp["world_size"] == 2 and tp["tp"] == 2 and tp["transport"] and tp["peer_wait_timed_out"] is False
     assert tp["value"] > 0
+    alts = tp.get("alternatives_one_step_each")   # the other transports of the same layout, one timed step each
+    assert isinstance(alts, dict) and "error" not in alts, alts
+    assert any("rccl" in k for k in alts) and all(v["ms_per_step"] > 0 for v in alts.values()), alts
 
 
 def _fused_worker(rank, world, port, tmp):
