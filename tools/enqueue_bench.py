@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--N", type=int, default=4096)
     ap.add_argument("--K", type=int, default=4096)
     ap.add_argument("--variant", type=int, default=None)
+    ap.add_argument("--variant2", type=int, default=None, help="a second knob set after --variant")
     ap.add_argument("--iters", type=int, default=2000)
     ap.add_argument("--stamps", action="store_true", help="one-launch operator (variant 81): print the in-kernel timeline "
                     "(wall-clock ticks of 10 ns) of one call")
@@ -30,6 +31,8 @@ def main():
     lib = _lib.load()
     if a.variant is not None:
         lib.mixq_debug_set_gemm_variant(a.variant)
+    if a.variant2:
+        lib.mixq_debug_set_gemm_variant(a.variant2)
     M, N, K = a.M, a.N, a.K
     g = torch.Generator(device=dev).manual_seed(0)
     W = torch.randn((N, K), device=dev, generator=g).mul_(32).round_().clamp_(-127, 127).to(torch.int8)
