@@ -211,6 +211,49 @@ def small_m_points(lib, TensorDesc, dev, gen, st_ptr, iters=300):
     return out
 
 
+def decode_step_points(lib, TensorDesc, model, dev, gen):
+    """Informational (never part of `value`): ONE decode step's worth of the path -- all 96 MixQ linears of Llama-2-7B, each with
+    ITS OWN weights (4.5 GB of int8 `weight` / `qweight`: cold by construction, no cache serves a layer twice), at batch 1, 4
+    and 32, captured as one HIP graph of 96 mixq_enqueue calls.  The regime of the reference's published numbers (README of
+    the reference: tokens/s at bs 32..512); linears only -- attention, norms and sampling are outside the path."""
+    out = {}
+    for bs in (1, 4, 32):
+        calls, max_ws, wbytes = [], 16, 0
+        acts, outs = {}, {}
+        for (t, ins) in model.keep:
+            N, K = t["weight"].shape[0], ins[0].shape[1]
+            if K not in acts:
+                acts[K] = synth_activation(bs, K, t["ind_i32"], dev, gen)
+            if N not in outs:
+                outs[N] = torch.empty((bs, N), dtype=torch.float16, device=dev)
+            v = [acts[K]] + list(ins[1:])
+            in_desc = (TensorDesc * 7)(*[TensorDesc.make(x.shape) for x in v])
+            out_desc = TensorDesc.make(outs[N].shape)
+            in_ptrs = (ctypes.c_void_p * 7)(*[x.data_ptr() for x in v])
+            out_ptrs = (ctypes.c_void_p * 1)(outs[N].data_ptr())
+            h = ctypes.c_void_p(lib.mixq_create(bs, N, K))
+            max_ws = max(max_ws, lib.mixq_workspace_size(h, bs, N, K))
+            calls.append((h, in_desc, out_desc, in_ptrs, out_ptrs))
+            wbytes += N * K
+        ws = torch.empty(max_ws, dtype=torch.uint8, device=dev)
+        turn = [0]
+
+        def run(st):
+            h, in_desc, out_desc, in_ptrs, out_ptrs = calls[turn[0] % len(calls)]
+            turn[0] += 1
+            assert lib.mixq_enqueue(h, in_desc, ctypes.byref(out_desc), in_ptrs, out_ptrs, ctypes.c_void_p(ws.data_ptr()), st) == 0
+
+        turn[0] = -1   # (graph_time_us makes one call outside the capture: the captured 96 then start at linear 0)
+        us = graph_time_us(run, dev, calls=len(calls), reps=10) * len(calls)
+        for c in calls:
+            lib.mixq_destroy(c[0])
+        out[f"bs{bs}"] = {"us_per_step": us, "linears": len(calls), "weight_GB": wbytes / 1e9, "weight_GBps": wbytes / us / 1e3,
+                          "hbm_frac": wbytes / (us * 1e-6) / 8e12, "tokens_per_s_bound_by_these_linears": bs / (us * 1e-6)}
+    out["what"] = ("one decode step of the 96 MixQ linears of Llama-2-7B (qkv, gate, proj x 32 layers), every layer its own weights, "
+                   "one HIP graph of 96 mixq_enqueue calls; M <= 4: the W8A16 path on qweight, M = 32: quantise + fused int8 GEMM")
+    return out
+
+
 def mid_m_points(lib, TensorDesc, dev, gen, st_ptr, iters=100):
     """Informational (never part of `value`): decode batches (32 / 128 / 512 rows) and a short prefill (1024 / 2048 tokens) of
     the same three linears, where the tiles no longer fill the chip and the library splits K over several workgroups per
@@ -646,6 +689,11 @@ def main():
             res["small_m"] = small_m_points(lib, TensorDesc, dev, gen, st_ptr)
         except Exception as e:  # noqa: BLE001
             res["small_m"] = {"error": repr(e)}
+        if world == 1:
+            try:
+                res["decode_step"] = decode_step_points(lib, TensorDesc, model, dev, gen)
+            except Exception as e:  # noqa: BLE001
+                res["decode_step"] = {"error": repr(e)}
         if args.mid_m:  # informational mid-M points (short prefill: tiles do not fill the chip); never part of `value`.
             # Opt-in: its launches of the ping-pong kernel would otherwise dilute that kernel's average in a
             # rocprofv3 --stats summary of this command, which has to agree with roofline.avg_launch_ms.
