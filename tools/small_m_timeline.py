@@ -28,9 +28,12 @@ def main():
     ap.add_argument("--N", type=int, default=4096)
     ap.add_argument("--K", type=int, default=4096)
     ap.add_argument("--calls", type=int, default=100)
+    ap.add_argument("--knobs", default="", help="comma list of mixq_debug_set_gemm_variant knobs to set first")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.load()
+    for _k in [int(x) for x in a.knobs.split(",") if x]:
+        lib.mixq_debug_set_gemm_variant(_k)
     M, N, K = a.M, a.N, a.K
     g = torch.Generator(device=dev).manual_seed(0)
     W = torch.randn((N, K), device=dev, generator=g).mul_(32).round_().clamp_(-127, 127).to(torch.int8)
