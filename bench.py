@@ -455,6 +455,7 @@ def main():
                     help="rows-of-W sharding degree of the MAIN measurement (1 = pure DP, no collective).  Whatever this "
                          "is, a run on N > 1 GPUs also reports the north-star layout (tp = N) in the `tp` object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode-step", action="store_true", help="skip the decode_step object (profiling runs: 3 graphs of 96 calls)")
     ap.add_argument("--mid-m", action="store_true",
                     help="add the informational 1024 / 2048-token prefill points (K split over workgroups) to the JSON line")
     ap.add_argument("--order", choices=["layer", "chunk"], default="layer",
@@ -689,7 +690,7 @@ def main():
             res["small_m"] = small_m_points(lib, TensorDesc, dev, gen, st_ptr)
         except Exception as e:  # noqa: BLE001
             res["small_m"] = {"error": repr(e)}
-        if world == 1:
+        if world == 1 and not args.no_decode_step:
             try:
                 res["decode_step"] = decode_step_points(lib, TensorDesc, model, dev, gen)
             except Exception as e:  # noqa: BLE001

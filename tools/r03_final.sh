@@ -10,7 +10,9 @@ echo "== mid-M leg"; timeout 600 python bench.py --tokens 65536 --steps 1 --warm
 echo "== rocprofv3 kernel trace + stats"
 rm -rf "$OUT/prof"; mkdir -p "$OUT/prof"
 ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/prof" -o mixq -- \
-    python "$OLDPWD/bench.py" --tokens 65536 --steps 2 --warmup 1 --no-cpu-baseline ) > "$OUT/rocprof.log" 2>&1
+    python "$OLDPWD/bench.py" --tokens 65536 --steps 2 --warmup 1 --no-cpu-baseline --no-decode-step ) > "$OUT/rocprof.log" 2>&1
 tail -2 "$OUT/rocprof.log"
 for f in $(find "$OUT/prof" -name "*kernel_stats.csv" | head -1); do cp $f $OUT/kernel_stats.csv; head -6 "$f" | cut -c1-200; done
+rm -rf "$OUT/prof"   # (raw traces: tens of MiB; gpurun copies back at most 64 MiB)
 echo "== PMC traffic"; bash tools/pmc_bench.sh > $OUT/pmc.log 2>&1; cp gpurun_out/pmc_bench/summary.txt $OUT/pmc_traffic_summary.txt; cat $OUT/pmc_traffic_summary.txt
+rm -rf gpurun_out/pmc_bench/FETCH_SIZE gpurun_out/pmc_bench/WRITE_SIZE
