@@ -31,6 +31,11 @@ import torch.distributed as dist  # noqa: E402
 
 LLAMA2_7B = dict(name="Llama-2-7B", layers=32, linears=[("attention.qkv", 12288, 4096), ("mlp.gate", 11008, 4096),
                                                        ("mlp.proj", 4096, 11008)])
+# BASELINE.json configs 4 and 5: the other two models, as the (N, K) of their MixQ linears on ONE GPU
+QWEN2_7B = dict(name="Qwen2-7B-Instruct", layers=28, linears=[("attention.qkv", 4608, 3584), ("mlp.gate", 18944, 3584),
+                                                            ("mlp.proj", 3584, 18944)])
+LLAMA2_70B_TP8 = dict(name="Llama-2-70B, one GPU's row shard at TP=8", layers=80,
+                      linears=[("attention.qkv", 10240 // 8, 8192), ("mlp.gate", 28672 // 8, 8192), ("mlp.proj", 8192 // 8, 28672)])
 NUM_OUTLIERS = 128
 INT8_MFMA_PEAK_TOPS = 5033.0  # dense int8 MFMA: 256 CU x 4 SIMD x 2048 op/clk x 2.4 GHz = 2x the 2.5 PF bf16 dense peak
                               # (MI355X_MICROARCH.md:394 "I8 ... ~2x bf16 rate", 16x16x64 ceiling >= 3944 TOPS; cdna_hip_programming.md:286:
@@ -350,17 +355,19 @@ class Model:
     """Resident state of one rank: the packed weights of all 96 MixQ linears (or this rank's row shard of each),
     rotating activation chunks, output buffers, the plugin workspace, and prepared ctypes argument blocks."""
 
-    def __init__(self, lib, TensorDesc, parallel, dev, gen, chunk, tp, tp_rank, acts=None):
+    def __init__(self, lib, TensorDesc, parallel, dev, gen, chunk, tp, tp_rank, acts=None, spec=None, nrot=8):
         self.lib, self.dev, self.chunk, self.tp = lib, dev, chunk, tp
+        self.spec = spec = spec if spec is not None else LLAMA2_7B
+        self.TensorDesc = TensorDesc
         self.calls, self.keep, self.outs, self.full = [], [], {}, {}
         self.acts = acts if acts is not None else {}
         max_ws = 0
-        for layer in range(LLAMA2_7B["layers"]):
-            for name, N, K in LLAMA2_7B["linears"]:
+        for layer in range(spec["layers"]):
+            for name, N, K in spec["linears"]:
                 n0, n1 = parallel.shard_bounds(N, tp, tp_rank) if tp > 1 else (0, N)
                 t = synth_layer(N, K, dev, gen, n0, n1)
-                if K not in self.acts:  # 8 rotating chunks per K (>1 GB: never resident in the 256 MiB Infinity Cache)
-                    self.acts[K] = [synth_activation(chunk, K, t["ind_i32"], dev, gen) for _ in range(8)]
+                if K not in self.acts:  # rotating chunks per K (>1 GB: never resident in the 256 MiB Infinity Cache)
+                    self.acts[K] = [synth_activation(chunk, K, t["ind_i32"], dev, gen) for _ in range(nrot)]
                 if (n1 - n0) not in self.outs:  # TP: two buffers per shape, so that the gather of call i overlaps GEMM i + 1
                     self.outs[n1 - n0] = [torch.empty((chunk, n1 - n0), dtype=torch.float16, device=dev)
                                           for _ in range(2 if tp > 1 else 1)]
@@ -384,6 +391,28 @@ class Model:
         self.transport = None
         self.n_call = 0
         self.gather_done = [None, None]   # event of the last gather that READ output buffer 0 / 1
+
+    def rechunked(self, chunk):
+        """The same resident weights driven in M-chunks of `chunk` <= self.chunk tokens: activation and output buffers are row
+        slices of this model's, the workspace is shared (mixq_workspace_size of the larger M covers every smaller one)."""
+        assert self.tp == 1 and chunk <= self.chunk
+        v = Model.__new__(Model)
+        v.lib, v.dev, v.chunk, v.tp, v.spec, v.TensorDesc = self.lib, self.dev, chunk, 1, self.spec, self.TensorDesc
+        v.acts, v.outs, v.full, v.keep = self.acts, self.outs, {}, self.keep
+        v.workspace, v.ws_ptr = self.workspace, self.ws_ptr
+        v.gatherers, v.fused, v.transport, v.n_call, v.gather_done = {}, {}, None, 0, [None, None]
+        v.calls = []
+        for (t, ins), old in zip(self.keep, self.calls):
+            n_loc, K, outs, N = old[5], old[6], old[7], old[8]
+            acts = [a[:chunk] for a in self.acts[K]]
+            o = [x[:chunk] for x in outs]
+            in_desc = (self.TensorDesc * 7)(*[self.TensorDesc.make(x.shape) for x in [acts[0]] + list(ins[1:])])
+            out_desc = self.TensorDesc.make(o[0].shape)
+            in_ptrs = [(ctypes.c_void_p * 7)(*([a.data_ptr()] + [x.data_ptr() for x in ins[1:]])) for a in acts]
+            out_ptrs = [(ctypes.c_void_p * 1)(x.data_ptr()) for x in o]
+            h = self.lib.mixq_create(chunk, n_loc, K)
+            v.calls.append((ctypes.c_void_p(h), in_desc, out_desc, in_ptrs, out_ptrs, n_loc, K, o, N))
+        return v
 
     def open_peer_transport(self, parallel, rank, group=None):
         """One-sided peer writes over xGMI for the output all-gather (csrc/tp_kernels.hip); falls back to RCCL -- on
@@ -456,6 +485,7 @@ def main():
                          "is, a run on N > 1 GPUs also reports the north-star layout (tp = N) in the `tp` object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode-step", action="store_true", help="skip the decode_step object (profiling runs: 3 graphs of 96 calls)")
+    ap.add_argument("--no-sweeps", action="store_true", help="skip the chunk_sweep and configs objects (profiling runs)")
     ap.add_argument("--mid-m", action="store_true",
                     help="add the informational 1024 / 2048-token prefill points (K split over workgroups) to the JSON line")
     ap.add_argument("--order", choices=["layer", "chunk"], default="layer",
@@ -536,7 +566,7 @@ def main():
     st_ptr = ctypes.c_void_p(stream.cuda_stream)
     comm_stream = torch.cuda.Stream(dev) if world > 1 else None
 
-    def schedule(model):
+    def schedule(model, n_chunks):
         # "layer": batched-prefill order -- every linear consumes all bs x seq tokens (as M-chunks) before the next
         # linear runs, as an engine executing layer by layer over the whole batch does; its weights are fetched from
         # HBM once per step.  "chunk": each token chunk walks through all 96 linears (chunked-prefill serving order).
@@ -549,9 +579,9 @@ def main():
                 for call in model.calls:
                     yield call, c
 
-    def one_step(model, group, events=None):
+    def one_step(model, group, events=None, n_chunks=n_chunks):
         ei = 0
-        for (h, in_desc, out_desc, in_ptrs_list, out_ptrs, n_loc, K, outs, N), c in schedule(model):
+        for (h, in_desc, out_desc, in_ptrs_list, out_ptrs, n_loc, K, outs, N), c in schedule(model, n_chunks):
             in_ptrs = in_ptrs_list[c % len(in_ptrs_list)]   # rotate the activation buffers of this K
             e0 = e1 = None
             if events is not None:
@@ -591,10 +621,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def timed_run(model, group, steps, warmup, with_gemm_events):
+    def timed_run(model, group, steps, warmup, with_gemm_events, n_chunks=n_chunks):
         """W warm-up steps, then EXACTLY `steps` steps between barrier + synchronize brackets; max over ranks."""
         for _ in range(warmup):
-            one_step(model, group)
+            one_step(model, group, None, n_chunks)
         launches = n_chunks * len(model.calls)
         events = [[(hip.event(), hip.event()) for _ in range(launches)] for _ in range(steps)] if with_gemm_events else None
         marks = [hip.event() for _ in range(steps + 1)]   # per-step boundaries on the compute stream (median)
@@ -602,7 +632,7 @@ def main():
         t0 = time.perf_counter()
         for s in range(steps):
             hip.record(marks[s], st_ptr)
-            one_step(model, group, events[s] if events else None)
+            one_step(model, group, events[s] if events else None, n_chunks)
         hip.record(marks[steps], st_ptr)
         sync_all()
         elapsed = time.perf_counter() - t0
@@ -702,6 +732,66 @@ def main():
                 res["mid_m"] = mid_m_points(lib, TensorDesc, dev, gen, st_ptr)
             except Exception as e:  # noqa: BLE001
                 res["mid_m"] = {"error": repr(e)}
+        if world == 1 and not args.no_sweeps:
+            # ---- chunk_sweep + configs (VERDICT r3 #1c): the same path off the whole-round sweet spot of the headline chunk, and
+            # on the other two BASELINE models.  Each point: whole model, every linear its own weights, GEMM events inside the
+            # timed region (roofline-style frac of the int8 peak); never part of `value`.
+            def measure(m, tokens, steps, warmup):
+                nch = max(tokens // m.chunk, 1)
+                names = {}
+                for (h, in_desc, out_desc, in_ptrs_list, out_ptrs, n_loc, K, outs, N) in m.calls[:len(m.spec["linears"])]:
+                    assert lib.mixq_enqueue(h, in_desc, ctypes.byref(out_desc), in_ptrs_list[0], out_ptrs[0], m.ws_ptr, st_ptr) == 0
+                    names[f"{n_loc}x{K}"] = lib.mixq_debug_last_gemm_kernel().decode().split(" ")[0]
+                el, med, ev, launches = timed_run(m, None, steps, warmup, True, nch)
+                g_ms = sum(hip.elapsed_ms(e0, e1) for st_ in ev for (e0, e1) in st_)
+                ops = sum(2.0 * m.chunk * c[5] * (c[6] + NUM_OUTLIERS) for c in m.calls) / len(m.calls)
+                avg = g_ms / 1e3 / (steps * launches)
+                gop_tok = sum(2.0 * n * k for _, n, k in m.spec["linears"]) * m.spec["layers"] / 1e9
+                return {"tokens_per_s": nch * m.chunk * steps / el, "ms_per_step": el / steps * 1e3, "tokens_per_step": nch * m.chunk,
+                        "m_chunk": m.chunk, "steps": steps, "warmup": warmup, "gemm_frac_of_int8_peak": ops / avg / 1e12 / INT8_MFMA_PEAK_TOPS,
+                        "gemm_avg_launch_ms": avg * 1e3, "gemm_share_of_wall": g_ms / 1e3 / el, "int8_gop_per_token": gop_tok,
+                        "gemm_tops_end_to_end": nch * m.chunk * steps / el * gop_tok / 1e3, "kernels": names}
+            try:
+                sweep = {}
+                for c in (8192, 16384):
+                    if c < chunk and args.tokens % c == 0:
+                        v = model.rechunked(c)
+                        sweep[f"chunk_{c}"] = measure(v, min(args.tokens, 262144), 3, 1)
+                        for call in v.calls:
+                            lib.mixq_destroy(call[0])
+                sweep[f"chunk_{chunk}"] = {"tokens_per_s": value, "ms_per_step": ms_per_step, "m_chunk": chunk,
+                                           "gemm_frac_of_int8_peak": achieved_tops / INT8_MFMA_PEAK_TOPS, "note": "the main measurement"}
+                sweep["what"] = ("Llama-2-7B, the same resident weights, driven in M-chunks of 8192 / 16384 tokens (256K tokens per step, "
+                                 "3 timed steps after 1): engines with max_num_tokens below 65536")
+                res["chunk_sweep"] = sweep
+            except Exception as e:  # noqa: BLE001
+                res["chunk_sweep"] = {"error": repr(e)}
+            try:
+                cfgs = {}
+                model.close()
+                model.acts, model.outs, model.workspace = {}, {}, None
+                torch.cuda.empty_cache()
+                for key, spec in (("qwen2_7b", QWEN2_7B), ("llama2_70b_tp8_shard", LLAMA2_70B_TP8)):
+                    m2 = Model(lib, TensorDesc, parallel, dev, gen, chunk, 1, 0, spec=spec, nrot=4)
+                    pt = measure(m2, args.tokens, 2, 1)
+                    pt["workload"] = (f"{spec['name']}: {spec['layers']} layers x " +
+                                      ", ".join(f"{nm} {n}x{k}" for nm, n, k in spec["linears"]) + f", bs x seq = {args.tokens} tokens")
+                    if key == "llama2_70b_tp8_shard":
+                        pt["note"] = ("ONE GPU's share of BASELINE config 5 (rows of W sharded 8 ways): tokens/s of the shard's GEMMs; the "
+                                      "all-gather of the fp16 outputs is the `tp` object's business and needs 8 GPUs")
+                    else:
+                        if chunk > 16384:
+                            v2 = m2.rechunked(16384)
+                            pt["chunk_16384"] = measure(v2, min(args.tokens, 262144), 2, 1)
+                            for call in v2.calls:
+                                lib.mixq_destroy(call[0])
+                    cfgs[key] = pt
+                    m2.close()
+                    del m2
+                    torch.cuda.empty_cache()
+                res["configs"] = cfgs
+            except Exception as e:  # noqa: BLE001
+                res["configs"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline()

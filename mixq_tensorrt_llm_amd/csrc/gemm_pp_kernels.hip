@@ -942,15 +942,28 @@ SplitPlan gemm_splitk_plan(int M, int N, int K)
     const int nk = (K + pp::KS - 1) / pp::KS;
     const int cus = num_cus() & ~7;
     if (tiles > cus) { // hybrid
-        const int tail = tiles % cus;
+        const int tail = tiles % cus, rounds = tiles / cus;
         if (tail == 0 || 2 * tail > cus || (force < 0 && M < 256)) return none; // (mixq_workspace_size reserves from 256 rows)
-        // measured: -10..-16 % with a tail on up to 1/4 of the CUs (4 ways), -4..-11 % up to ~0.4 of the CUs (2 ways),
-        // nothing left at 1/2 (the plain kernel's last wave overlaps the one before and runs at higher clocks)
-        int s = 4 * tail <= cus && nk >= 24 ? 4 : (16 * tail <= 7 * cus && nk >= 12 ? 2 : 0);
-        if (force == 2 && nk >= 8) s = 2;
-        if (force == 2 && s == 4) s = 2;
-        if (force == 4 && s != 4) s = 4 * tail <= cus && nk >= 16 ? 4 : 0;
-        if (force == 8) s = 8 * tail <= cus && nk >= 32 ? 8 : 0;
+        // Round 4: re-fitted in STEADY STATE (tools/splitk_select_sweep.py --hybrid --secs 0.35, profiles/r04_hybrid_sweep.txt: the
+        // power-capped clock a prefill runs at; round 1's 100-launch cells read the boost clock of an idle chip and over-sold the
+        // split).  What a split tail saves shrinks with the number of whole rounds before it -- by then the CUs are out of step
+        // and the plain kernel's partial round already overlaps the one before -- and grows with K (the exchange is a fixed
+        // 128..192 KiB per workgroup each way).  Rows: whole rounds 1 | 2 | 3-4 | 5-7 | 8+; columns: tail on <= 1/8 | 1/4 | 3/8 |
+        // 1/2 of the CUs; entry = the fewest 128-byte K slices from which the split measured >= ~2 % ahead of the plain launch
+        // (r = 1: -5..-23 %; r = 2: -3..-13 %; r = 5: -1..-6 %, only the long K).
+        int s = 0;
+        if (force < 0) {
+            static const int kMinNk[5][4] = {{24, 24, 24, 56}, {24, 24, 80, 80}, {24, 56, 100, 100}, {48, 128, 128, 128}, {64, 160, 160, 160}};
+            const int fb = 8 * tail <= cus ? 0 : 4 * tail <= cus ? 1 : 8 * tail <= 3 * cus ? 2 : 3;
+            const int rc = rounds == 1 ? 0 : rounds == 2 ? 1 : rounds <= 4 ? 2 : rounds <= 7 ? 3 : 4;
+            if (nk >= kMinNk[rc][fb]) s = fb >= 2 ? 2 : (rc == 0 && fb == 1 && nk < 48 ? 2 : 4); // (one round + a quarter, short K: 2 ways tie or win)
+        } else {
+            s = 4 * tail <= cus && nk >= 24 ? 4 : (nk >= 12 ? 2 : 0);
+            if (force == 2 && nk >= 8) s = 2;
+            if (force == 2 && s == 4) s = 2;
+            if (force == 4 && s != 4) s = 4 * tail <= cus && nk >= 16 ? 4 : 0;
+            if (force == 8) s = 8 * tail <= cus && nk >= 32 ? 8 : 0;
+        }
         return s ? SplitPlan{s, tiles - tail} : none;
     }
     if (force == 8) return 8 * tiles <= cus && nk >= 32 ? SplitPlan{8, 0} : none;

@@ -15,11 +15,16 @@ from . import _lib
 NUM_OUTLIERS = 128  # model_config_utils.py:444 fp_features
 
 
-def select_outlier_columns(act_scales: torch.Tensor, num: int = NUM_OUTLIERS) -> torch.Tensor:
+def select_outlier_columns(act_scales: torch.Tensor, num: int = NUM_OUTLIERS, stable: bool = False) -> torch.Tensor:
     """model_config_utils.py:446-448: indices of the ``num`` largest activation scales, ascending by scale.
-    A stable sort is used (the reference's torch.sort leaves the order inside tie groups unspecified)."""
+
+    The reference's very call -- ``torch.sort(layer_scales)[1][-128:]`` on a CPU tensor, NOT stable -- so that ``fp_ind``
+    (and with it the column order of ``fp_weight``) comes out as the reference stores it: real tables tie inside the top
+    128 (act_scales/Llama-2-1b.pt: 2..24 tied values per vector) and a stable sort orders those groups differently
+    (tests/golden/model_walk.npz pins the order).  The SET of columns is the same either way unless a tie straddles the
+    128th place; ``stable=True`` gives a build-independent order for callers that do not need the reference's."""
     s = act_scales.float().cpu()
-    return torch.sort(s, stable=True)[1][-num:].to(torch.int32)
+    return torch.sort(s, stable=stable)[1][-num:].to(torch.int32)
 
 
 def weight_scales(W: torch.Tensor) -> torch.Tensor:

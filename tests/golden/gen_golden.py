@@ -81,7 +81,88 @@ def main():
         fp_weight=fp_weight.numpy(), weight_int8=q.numpy(),
     )
     pflavour_fixture()
+    model_walk_fixture(mcu, mc, act)
     print("wrote", os.listdir(OUT))
+
+
+def model_walk_fixture(mcu, mc, act):
+    """model_walk.npz: the REFERENCE's model-level walk -- ``merge_qkv`` (model_config_utils.py:203-217) then
+    ``pack_linear_weights`` (:378-472), both executed from the reference file -- over two synthetic decoder layers
+    (tests/golden/synth_model.py) held in the reference's own dataclasses (ModelConfig / DecoderLayerConfig / AttentionConfig /
+    QKVConfig / MLPConfig / LinearConfig), driven by the real keys and vectors of act_scales/Llama-2-1b.pt.
+
+    What the reference function needs that this container lacks, and how it is satisfied WHILE IT RUNS (nothing of it ships):
+      * it opens the cwd-relative ``act_scales/Qwen2-72B.pt`` (:391): ``torch.load`` is pointed at a recording dict over
+        Llama-2-1b.pt's tensors, which also captures the sequence of keys the walk reads (the key map);
+      * ``mixlib.int8_matrix_to_half`` / ``mixlib.int_to_half`` (CUDA extension; bit-casts to fp16 carriers): bit-cast views;
+      * ``EETQ.quant_weights`` (CUDA extension): a placeholder -- ``qweight`` / ``scales`` are NOT captured here;
+      * ``Tensor.cuda`` -> identity.
+    Captured per (layer, module): the act-scale key read, fp_ind (int32 view of the carrier), weights_scaling_factor, and
+    SHA-256 digests of the int8 ``weight`` and of ``fp_weight`` (the tensors themselves are megabytes), plus the eight
+    act-scale vectors the test needs as inputs."""
+    import hashlib
+    sys.path.insert(0, OUT)
+    import synth_model as sm
+
+    sd = sm.state_dict()
+
+    def lin(name, layer):
+        c = mc.LinearConfig()
+        c.weight = sd[f"model.layers.{layer}.{name}.weight"].clone()
+        return c
+
+    layers = []
+    for i in range(sm.LAYERS):
+        qkv = mc.QKVConfig(q=lin("self_attn.q_proj", i), k=lin("self_attn.k_proj", i), v=lin("self_attn.v_proj", i))
+        att = mc.AttentionConfig(qkv=qkv)
+        mlp = mc.MLPConfig(fc=lin("mlp.gate_proj", i), gate=lin("mlp.up_proj", i), proj=lin("mlp.down_proj", i))  # layer_utils.py:753-786
+        layers.append(mc.DecoderLayerConfig(attention=att, mlp=mlp))
+    model_config = mc.ModelConfig(quantization=mc.QUANTIZATION_INT8_MIX, layers=layers)
+
+    class Recording(dict):
+        keys_read = []
+
+        def __getitem__(self, k):
+            Recording.keys_read.append(k)
+            return dict.__getitem__(self, k)
+
+    mixlib = types.ModuleType("mixlib")
+    mixlib.int8_matrix_to_half = lambda t: t.contiguous().view(torch.float16)
+    mixlib.int_to_half = lambda t: t.contiguous().view(torch.float16)
+    eetq = types.ModuleType("EETQ")
+    eetq.quant_weights = lambda w, dt, flag: (torch.zeros(w.shape, dtype=torch.int8), torch.zeros(w.shape[1], dtype=torch.float16))
+    eetq.preprocess_weights = eetq.w8_a16_gemm = None
+    keep = (torch.Tensor.cuda, torch.load, torch.cuda.empty_cache, sys.modules.get("mixlib"), sys.modules.get("EETQ"))
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.load = lambda *a, **k: Recording(act)
+    torch.cuda.empty_cache = lambda: None
+    sys.modules["mixlib"], sys.modules["EETQ"] = mixlib, eetq
+    try:
+        mcu.merge_qkv(model_config)
+        mcu.pack_linear_weights(model_config)
+    finally:
+        torch.Tensor.cuda, torch.load, torch.cuda.empty_cache = keep[0], keep[1], keep[2]
+        for name, old in (("mixlib", keep[3]), ("EETQ", keep[4])):
+            if old is None:
+                sys.modules.pop(name, None)
+            else:
+                sys.modules[name] = old
+    blob = {"keys_read": np.array(Recording.keys_read)}
+    for i, dec in enumerate(model_config.layers):
+        for which, cfg in (("attention.qkv", dec.attention.qkv), ("mlp.gate", dec.mlp.gate), ("mlp.proj", dec.mlp.proj)):
+            tag = f"L{i}.{which}"
+            w8 = cfg.weight.contiguous().view(torch.int8)          # the fp16 carrier [N, K/2] back to int8 [N, K]
+            blob[f"{tag}.fp_ind"] = cfg.fp_ind.contiguous().view(torch.int32).numpy()
+            blob[f"{tag}.weights_scaling_factor"] = cfg.weights_scaling_factor.numpy()
+            blob[f"{tag}.weight_shape"] = np.array(w8.shape)
+            blob[f"{tag}.weight_sha256"] = np.array(hashlib.sha256(w8.numpy().tobytes()).hexdigest())
+            blob[f"{tag}.fp_weight_sha256"] = np.array(hashlib.sha256(cfg.fp_weight.contiguous().numpy().tobytes()).hexdigest())
+            blob[f"{tag}.fp_weight_row0"] = cfg.fp_weight[0].contiguous().numpy()
+            blob[f"{tag}.weight_row0"] = w8[0].numpy().copy()
+    for i in range(sm.LAYERS):
+        for name in ("self_attn.q_proj", "mlp.gate_proj", "mlp.up_proj", "mlp.down_proj"):
+            blob[f"act.model.layers.{i}.{name}"] = act[f"model.layers.{i}.{name}"].float().contiguous().numpy()
+    np.savez_compressed(os.path.join(OUT, "model_walk.npz"), **blob)
 
 
 def pflavour_fixture():

@@ -16,3 +16,7 @@ def test_cpu_baseline_leg_fields():
     # 8.99 GOP of int8 work per token from the model table the bench uses
     gop = sum(2.0 * n * k for _, n, k in bench.LLAMA2_7B["linears"]) * bench.LLAMA2_7B["layers"] / 1e9
     assert abs(gop - 8.9926) < 1e-3
+    # the other two BASELINE models of the `configs` object (8.53 and 88.6 GOP / token; one GPU of TP = 8 carries an eighth)
+    gq = sum(2.0 * n * k for _, n, k in bench.QWEN2_7B["linears"]) * bench.QWEN2_7B["layers"] / 1e9
+    g70 = sum(2.0 * n * k for _, n, k in bench.LLAMA2_70B_TP8["linears"]) * bench.LLAMA2_70B_TP8["layers"] / 1e9
+    assert abs(gq - 8.53) < 0.01 and abs(8 * g70 - 88.6) < 0.1

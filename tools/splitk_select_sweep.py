@@ -2,7 +2,10 @@
 """Selection data for the K split over workgroups (gemm_pp_kernels.hip, SPLITK): one process, many shapes; per shape the
 fused GEMM time of the plain launch (variant 70), the forced 2-way / 4-way split (72 / 74) and torch._int_mm (the vendor's
 plain s8 GEMM, for scale), plus a bit-identity check of every split result against the plain launch.
-usage: python tools/splitk_select_sweep.py [--iters 100] [--vendor]"""
+--secs S times every cell in STEADY STATE (0.3 s of warm-up launches, then >= S seconds timed: the power-capped clock the
+bench runs at; 100-iteration cells read the boost clock of a chip that was idle a moment ago and favour the split forms);
+--hybrid = the grid of whole rounds + a partial one (N = 4096: tiles = 16 x M / 256) behind the "solo + split tail" rule.
+usage: python tools/splitk_select_sweep.py [--iters 100 | --secs 0.4] [--vendor] [--hybrid]"""
 import argparse
 import ctypes
 import os
@@ -22,6 +25,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--vendor", action="store_true")
+    ap.add_argument("--secs", type=float, default=0.0)
+    ap.add_argument("--hybrid", action="store_true")
     ap.add_argument("--shapes", default="", help='explicit list "M,N,K;M,N,K;..." instead of the built-in grid')
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -33,6 +38,9 @@ def main():
     scr = torch.zeros(72 << 20, dtype=torch.uint8, device=dev)
     print("M N K tiles nk | plain_us s2_us s4_us s8_us vendor_us | best")
     grid = [(N, K, MS) for N, K in NK]
+    if a.hybrid:   # rounds r in {1, 2, 5}, tail f in {1/8 .. 1/2} of the CUs: M = 256 * 16 * (r + f)
+        grid = [(4096, K, [int(4096 * (r + f)) for r in (1, 2, 5) for f in (0.125, 0.25, 0.375, 0.5)])
+                for K in (3584, 4096, 8192, 11008, 18944)]
     if a.shapes:
         grid = [(int(t.split(",")[1]), int(t.split(",")[2]), [int(t.split(",")[0])]) for t in a.shapes.split(";") if t]
     for N, K, ms in grid:
@@ -63,12 +71,19 @@ def main():
                 elif not torch.equal(ref, out):
                     print(f"MISMATCH M={M} N={N} K={K} variant={v}")
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                iters = a.iters
+                if a.secs > 0:
+                    e0.record(); fn(); fn(); e1.record(); torch.cuda.synchronize()
+                    est = e0.elapsed_time(e1) / 2 * 1e-3
+                    for _ in range(max(3, int(0.3 / est))):
+                        fn()
+                    iters = max(5, int(a.secs / est))
                 e0.record()
-                for _ in range(a.iters):
+                for _ in range(iters):
                     fn()
                 e1.record()
                 torch.cuda.synchronize()
-                res[v] = e0.elapsed_time(e1) / a.iters * 1e3
+                res[v] = e0.elapsed_time(e1) / iters * 1e3
             ven = float("nan")
             if a.vendor and M > 16:
                 Wt = W.t()
