@@ -116,6 +116,17 @@ MIXQ_API size_t mixq_reference_workspace_size(int64_t maxM, int64_t N, int64_t K
 MIXQ_API int mixq_enqueue(const mixq_handle* h, const mixq_tensor_desc* inputDesc, const mixq_tensor_desc* outputDesc,
                           const void* const* inputs, void* const* outputs, void* workspace, void* stream);
 
+/* MI355X extension (no reference counterpart; like mixq_qa_layout it changes no result): mixq_enqueue + a HINT naming the weight
+ * bytes the caller's NEXT call on this stream will stream -- the next layer's `qweight` (inputs[5]) when that call has M <= 4, its
+ * `weight` (inputs[1]) otherwise, N * K bytes either way.  Decode and decode batches are weight streams: every layer's weights come
+ * from HBM once per step, and a launch cannot start pulling them before the launch in front of it has ended.  With a hint, extra
+ * workgroups of THIS call's GEMM launch touch that range (one dword per 128-byte line), so the lines sit in the 256 MiB memory-side
+ * Infinity Cache when the next call asks for them, and the HBM stream of layer i + 1 runs under the compute of layer i.  Honoured
+ * by the weight-streaming forms (W8A16 skinny form for M <= 4 on wide shapes, int8 skinny GEMM for decode batches); any other form
+ * ignores it.  next_weights == NULL or next_bytes == 0: exactly mixq_enqueue.  Graph-capturable (the pointer is baked in). */
+MIXQ_API int mixq_enqueue_hint(const mixq_handle* h, const mixq_tensor_desc* inputDesc, const mixq_tensor_desc* outputDesc,
+                               const void* const* inputs, void* const* outputs, void* workspace, void* stream,
+                               const void* next_weights, size_t next_bytes);
 /* Same work, same launches; additionally records two caller-owned hipEvent_t (may be NULL) on `stream` immediately
  * before and after the fused-GEMM launch of the prefill path, so a harness can time the dominant kernel inside its
  * timed region without changing the path (bench.py "roofline"). */
@@ -394,6 +405,12 @@ MIXQ_API void mixq_debug_set_quant_stamp_buffer(void* device_u64_8_per_block);
 /* Reporting only: name of the kernel family the fused GEMM selected on its most recent launch in this process. */
 MIXQ_API const char* mixq_debug_last_gemm_kernel(void);
 MIXQ_API const char* mixq_version(void);
+/* ABI revision of THIS header.  It is bumped whenever an exported entry changes its argument list in place (revision 3: the
+ * mixq_tp_buffer_alloc / mixq_tp_push_columns / mixq_tp_wait signatures of round 3), so that a host built against an older
+ * header can refuse to run instead of passing shifted arguments: `if (mixq_abi_version() != MIXQ_ABI_VERSION) fail`.  The
+ * reference-named entries (initOpenAiTritonPlugins, the plugin lifecycle, mixq_enqueue) have not changed since revision 1. */
+#define MIXQ_ABI_VERSION 3
+MIXQ_API int mixq_abi_version(void);
 MIXQ_API const char* mixq_error_string(int code);
 
 #ifdef __cplusplus

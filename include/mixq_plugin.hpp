@@ -43,7 +43,10 @@ public:
     MixQPlugin* clone() const noexcept                                                   /* .cpp:237-242 */
     {
         mixq_handle* c = mixq_clone(h_);
-        return c ? new (std::nothrow) MixQPlugin(c) : nullptr;
+        MixQPlugin* p = c ? new (std::nothrow) MixQPlugin(c) : nullptr;
+        if (p) p->workspace_max_ = workspace_max_;   /* the reference's clone copies m_workspaceMaxSize (.cpp:236-241) */
+        else if (c) mixq_destroy(c);
+        return p;
     }
     /* out = inputs[0].dims with the last dimension replaced by inputs[1].d[0] (.cpp:244-261); 0 = ok */
     int getOutputDimensions(int outputIndex, const PluginTensorDesc* inputs, int nbInputs, PluginTensorDesc* out) const noexcept

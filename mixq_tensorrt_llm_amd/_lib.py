@@ -84,6 +84,8 @@ SIGNATURES = {
     "mixq_enqueue_scratch_size": (_sz, [_i64, _i64, _i64]),
     "mixq_enqueue": (_i, [_vp, ctypes.POINTER(TensorDesc), ctypes.POINTER(TensorDesc), ctypes.POINTER(_vp),
                           ctypes.POINTER(_vp), _vp, _vp]),
+    "mixq_enqueue_hint": (_i, [_vp, ctypes.POINTER(TensorDesc), ctypes.POINTER(TensorDesc), ctypes.POINTER(_vp),
+                               ctypes.POINTER(_vp), _vp, _vp, _vp, _sz]),
     "mixq_enqueue_profiled": (_i, [_vp, ctypes.POINTER(TensorDesc), ctypes.POINTER(TensorDesc), ctypes.POINTER(_vp),
                                    ctypes.POINTER(_vp), _vp, _vp, _vp, _vp]),
     "mixq_int8quant": (_i, [_i, _i, _vp, _vp, _vp, _vp]),
@@ -144,10 +146,12 @@ SIGNATURES = {
     "mixq_debug_set_quant_stamp_buffer": (None, [_vp]),
     "mixq_debug_last_gemm_kernel": (ctypes.c_char_p, []),
     "mixq_version": (ctypes.c_char_p, []),
+    "mixq_abi_version": (_i, []),
     "mixq_error_string": (ctypes.c_char_p, [_i]),
 }
 
 _lib = None
+ABI_VERSION = 3   # include/mixq.h MIXQ_ABI_VERSION
 
 
 def load():
@@ -169,6 +173,8 @@ def load():
         except AttributeError as e:
             raise MixQLibraryError(f"{LIB_PATH} does not export {name}") from e
         fn.restype, fn.argtypes = res, args
+    if lib.mixq_abi_version() != ABI_VERSION:   # a stale .so next to newer bindings would take shifted arguments
+        raise MixQLibraryError(f"{LIB_PATH} has ABI revision {lib.mixq_abi_version()}, these bindings need {ABI_VERSION}: rebuild it")
     _lib = lib
     return lib
 

@@ -613,6 +613,11 @@ void set_gemm_variant(int v)
         return;
     }
     set_skinny_kw(0);
+    if (v < 0) { // (mixq_debug_reset) forget a forced schedule: MIXQ_GEMM_VARIANT in the environment is read again
+        g_force_cfg.store(-1);
+        g_variant.store(-1);
+        return;
+    }
     if (v >= 10 && v < 100) { // 10 + i: the 2-barrier kernel in tile configuration i (measurements)
         g_force_cfg.store(v - 10);
         g_variant.store(1);
@@ -646,6 +651,17 @@ bool gemm_pp128_wins(int M, int N, int K)
     if (nk < 64) return 256 * t >= (int64_t)88 * cus;
     if (nk < 80) return 256 * t >= (int64_t)160 * cus;
     return false;
+}
+
+static thread_local const void* t_pf_ptr = nullptr;
+static thread_local size_t t_pf_bytes = 0;
+void set_weight_prefetch_hint(const void* next_weights, size_t bytes) { t_pf_ptr = next_weights, t_pf_bytes = next_weights ? bytes : 0; }
+bool take_weight_prefetch_hint(const void** next_weights, size_t* bytes)
+{
+    *next_weights = t_pf_ptr, *bytes = t_pf_bytes;
+    const bool have = t_pf_ptr != nullptr && t_pf_bytes != 0;
+    t_pf_ptr = nullptr, t_pf_bytes = 0;
+    return have;
 }
 
 static std::atomic<const char*> g_last_kernel{"none"}; // reporting only (bench.py's roofline.kernel)

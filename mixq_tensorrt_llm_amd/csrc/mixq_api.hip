@@ -117,7 +117,7 @@ void mixq_debug_reset(void)
     // every knob of the mixq_debug_* family back to the production default (see include/mixq.h "debug / measurement")
     g_dbg_stamps.store(nullptr);
     mixq::set_quant_stamp_buffer(nullptr);
-    for (int v : {0 /* schedule, tile configuration, skinny K width */, 79 /* K splits over workgroups automatic */, 69, 65, 91,
+    for (int v : {-1 /* schedule (back to the MIXQ_GEMM_VARIANT default), tile configuration, skinny K width */, 79 /* K splits over workgroups automatic */, 69, 65, 91,
                   80 /* fpA_intB forms automatic */, 85, 840, 843, 850, 858, 891 /* fragment-major qA on */, 893 /* skinny range: the rule */,
                   894 /* feature tiles automatic */})
         mixq::set_gemm_variant(v);
@@ -125,7 +125,8 @@ void mixq_debug_reset(void)
 
 const char* mixq_debug_last_gemm_kernel(void) { return mixq::last_gemm_kernel(); }
 
-const char* mixq_version(void) { return "mixq-mi355x 0.2 (gfx950)"; }
+const char* mixq_version(void) { return "mixq-mi355x 0.3 (gfx950)"; }
+int mixq_abi_version(void) { return MIXQ_ABI_VERSION; }
 
 const char* mixq_error_string(int code)
 {
@@ -852,6 +853,16 @@ int mixq_enqueue(const mixq_handle* h, const mixq_tensor_desc* inputDesc, const 
                  const void* const* inputs, void* const* outputs, void* workspace, void* stream)
 {
     return enqueue_impl(h, inputDesc, inputs, outputs, workspace, stream, nullptr, nullptr);
+}
+
+int mixq_enqueue_hint(const mixq_handle* h, const mixq_tensor_desc* inputDesc, const mixq_tensor_desc* /*outputDesc*/,
+                      const void* const* inputs, void* const* outputs, void* workspace, void* stream, const void* next_weights,
+                      size_t next_bytes)
+{
+    mixq::set_weight_prefetch_hint(next_weights, next_bytes);
+    const int rc = enqueue_impl(h, inputDesc, inputs, outputs, workspace, stream, nullptr, nullptr);
+    mixq::set_weight_prefetch_hint(nullptr, 0); // (a launch that does not support the hint leaves it behind: never leak it into another call)
+    return rc;
 }
 
 int mixq_enqueue_profiled(const mixq_handle* h, const mixq_tensor_desc* inputDesc,

@@ -31,6 +31,7 @@
 
 #include "mixq_device.h"
 #include "mixq_launch.h"
+#include <algorithm>
 
 namespace mixq {
 
@@ -718,9 +719,13 @@ typedef float v4f_ __attribute__((ext_vector_type(4)));
 template <int MT, int KW, int CG>
 __global__ __launch_bounds__(KW * 64) void w8a16_skinny_kernel(const uint16_t* __restrict__ A, const uint8_t* __restrict__ Wq,
                                                                 const uint16_t* __restrict__ scale,
-                                                                uint16_t* __restrict__ Out, int M, int N, int K)
+                                                                uint16_t* __restrict__ Out, int M, int N, int K, WeightPrefetch pf)
 {
     __shared__ v4f_ part[KW][CG][MT][64]; // [K part][column group][token tile][lane]
+    if (pf.nblocks != 0u && blockIdx.x >= gridDim.x - pf.nblocks) { // trailing blocks: touch the NEXT layer's weights (mixq_device.h)
+        weight_prefetch_block(pf, blockIdx.x - (gridDim.x - pf.nblocks));
+        return;
+    }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ln = lane & 15, kq = lane >> 4;
@@ -1089,8 +1094,16 @@ template <int MT, int KW, int CG>
 static hipError_t launch_wo_skinny(const uint16_t* A, const uint8_t* Wq, const uint16_t* scale, uint16_t* Out, int M, int N,
                                    int K, hipStream_t st)
 {
-    hipLaunchKernelGGL((w8a16_skinny_kernel<MT, KW, CG>), dim3((unsigned)((N + 16 * CG - 1) / (16 * CG))), dim3(KW * 64), 0, st,
-                       A, Wq, scale, Out, M, N, K);
+    WeightPrefetch pf{nullptr, 0u, 0u};
+    const void* nw = nullptr;
+    size_t nbytes = 0;
+    if (take_weight_prefetch_hint(&nw, &nbytes) && nbytes >= 128) {
+        pf.base = static_cast<const unsigned char*>(nw);
+        pf.nlines = (unsigned)std::min<size_t>(nbytes / 128, 0x7fffffffu);
+        pf.nblocks = (unsigned)std::min<size_t>((pf.nlines + KW * 64 * 8 - 1) / (KW * 64 * 8), 256); // 8 touches per lane, at most one block per CU
+    }
+    hipLaunchKernelGGL((w8a16_skinny_kernel<MT, KW, CG>), dim3((unsigned)((N + 16 * CG - 1) / (16 * CG)) + pf.nblocks), dim3(KW * 64), 0, st,
+                       A, Wq, scale, Out, M, N, K, pf);
     return hipGetLastError();
 }
 
@@ -1194,6 +1207,9 @@ hipError_t launch_w8a16_gemm(const void* A, const uint8_t* Wq, const void* scale
         default: return launch_wo_wide<4, 2, 3>(a, Wq, s, o, M, N, K, pl.ks, scratch, st);
         }
     }
+    // the narrow form addresses the weights with an absolute 32-bit per-lane offset (w8a16_gemm_kernel: wlane): a weight of 4 GiB
+    // or more (a 256k-entry head on K = 16384) would wrap silently -- refuse it (the wide / skinny forms use 64-bit bases)
+    if ((int64_t)N * (int64_t)K >= ((int64_t)1 << 32)) return hipErrorInvalidValue;
     for (int m0 = 0; m0 < M; m0 += 256) { // 256-token passes (each streams the weights once)
         const int rows = M - m0 < 256 ? M - m0 : 256;
         const size_t need = wo_narrow_workspace(rows, N, K);

@@ -17,7 +17,7 @@ __all__ = ["FindRowScale", "ExtractOutliersAndSetToZeros", "int8FusedDequantize"
            "int8_matrix_to_half", "w8_a16_gemm", "preprocess_weights", "mixq_linear", "int4FusedDequantize",
            "int4FusedDequantizeSilu", "unpack_int4_to_fp16", "int8FusedDequantizeSiluMul",
            "layernorm_forward_cuda_extract_outliers_int4", "ExtractOutliers", "dequantizeInt8Silu", "mixlinear_forward",
-           "qa_layout", "QA_ROW_MAJOR", "QA_FRAGMENT_MAJOR"]
+           "qa_layout", "qa_to_row_major", "QA_ROW_MAJOR", "QA_FRAGMENT_MAJOR"]
 
 QA_ROW_MAJOR, QA_FRAGMENT_MAJOR = 0, 1   # include/mixq.h MIXQ_QA_*
 
@@ -28,6 +28,15 @@ def qa_layout(M, N, K):
     else QA_ROW_MAJOR.  The reference-named ops below default to row-major; our own producers / consumers
     (``mixlinear.FasterTransformerRMSNorm``, ``MixLinear_GEMM``) pass the layout along in the cache."""
     return int(_lib.load().mixq_qa_layout(int(M), int(N), int(K)))
+
+
+def qa_to_row_major(q, M, K):
+    """The fragment-major int8 image (QA_FRAGMENT_MAJOR: 1-KiB blocks [16-row tile][64-byte k-step], lane l = row % 16 + 16 * (k / 16 % 4)
+    holding 16 bytes at l * 16 -- csrc/quant_kernels.hip FRAG) back to row-major [M, K].  A rare path: a consumer that shares a
+    producer's cache but whose own shape the weight-streaming skinny GEMM does not serve (mixlinear.MixLinear_GEMM)."""
+    tiles, steps = (M + 15) // 16, (K + 63) // 64
+    img = q.reshape(-1)[:tiles * steps * 1024].view(tiles, steps, 4, 16, 16)     # [tile, k-step, k quarter, row, byte]
+    return img.permute(0, 3, 1, 2, 4).reshape(tiles * 16, steps * 64)[:M, :K].contiguous()
 
 
 def _alloc_q(m, k, layout, device):
@@ -406,14 +415,23 @@ def mixq_linear(A, W_int8, sW, fp_weight, ind, out=None, workspace=None):
     return out
 
 
+@_on_tensor_device
 def mixlinear_forward(x, ind, q_weight, scale_col, weight_cache, x_scale, q_layout=0):
     """MixLinear_GEMM.forward (linear.py:163-286, bit = 8, static outlier set) in ONE library call and two launches (MI355X
     extension, include/mixq.h ``mixq_mixlinear_forward``): returns (out fp16 [M,N], q_x int8 [M,K], outliers fp16 [M,O]); zeroes
     the ``ind`` columns of ``x`` and fills ``x_scale`` like the reference's four-call sequence.  The wrapper does what one of
     the four wrappers does -- the host cost per linear drops ~4x (profiles/r03_mixlib_overhead.txt)."""
+    _dev(x, ind, q_weight, scale_col, x_scale)   # (the same guards as the four wrappers this call replaces: raw pointers go to C)
+    if weight_cache is not None:
+        _dev(weight_cache)
+    assert x.dtype == torch.float16 and ind.dtype == torch.int32 and q_weight.dtype == torch.int8
+    assert scale_col.dtype == torch.float16 and x_scale.dtype == torch.float16
     M, K = x.shape
     N = q_weight.shape[0]
     O = int(ind.shape[0])
+    assert q_weight.shape[1] == K and scale_col.numel() >= N, "mixlinear_forward: q_weight [N,K] / scale_col [N] do not match x [M,K]"
+    assert weight_cache is None or O == 0 or (weight_cache.dtype == torch.float16 and weight_cache.numel() >= N * O)
+    _rows_fit(x_scale, M, "mixlinear_forward")
     dev = x.device
     out = torch.empty((M, N), dtype=torch.float16, device=dev)
     q_x = _alloc_q(M, K, q_layout, dev)   # (q_layout = qa_layout(M, N, K): the opaque fragment-major image for decode batches)

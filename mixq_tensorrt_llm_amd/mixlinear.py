@@ -227,8 +227,9 @@ class MixLinear_GEMM:
 
         y = outlier_product(cache.activation_outliers, self.weight_cache) if self.ind.shape[0] else None
         if self.bit == 8:
-            y1 = mixlib.int8FusedDequantize(cache.q_xcache, self.q_weight, cache.x_scale, self.scale_col, y, M,
-                                            self.out_features, self.in_features, getattr(cache, "q_layout", 0))
+            q, lay = self._cached_q(cache, M)
+            y1 = mixlib.int8FusedDequantize(q, self.q_weight, cache.x_scale, self.scale_col, y, M,
+                                            self.out_features, self.in_features, lay)
         else:
             y1 = mixlib.int4FusedDequantize(cache.q_xcache, self.q_weight, cache.x_scale, self.scale_col, y, M,
                                             self.out_features, self.in_features // 2)
@@ -237,6 +238,17 @@ class MixLinear_GEMM:
         return y1.reshape(cache.shape)
 
     __call__ = forward
+
+    def _cached_q(self, cache, M):
+        """(q_xcache, layout) as THIS consumer's GEMM can read it.  The producer chose the image for one consumer's N (the
+        fragment-major one only where the weight-streaming skinny GEMM serves that shape); a consumer that shares the cache with
+        another N -- or runs after a selection knob changed -- may not be served by that kernel: it gets the row-major image
+        back (one small permute, cached) instead of an MIXQ_E_SHAPE in the middle of a decode step."""
+        lay = getattr(cache, "q_layout", 0)
+        if lay and mixlib.qa_layout(M, self.out_features, self.in_features) != lay:
+            cache.q_xcache = mixlib.qa_to_row_major(cache.q_xcache, M, self.in_features)
+            cache.q_layout = lay = 0
+        return cache.q_xcache, lay
 
     @torch.no_grad()
     def forward_without_preconditionFusedSilu(self, x, cache, mul=None):
@@ -263,12 +275,14 @@ class MixLinear_GEMM:
         y = outlier_product(cache.activation_outliers, self.weight_cache) if self.ind.shape[0] else None
         fused_mul = mul is not None and self.bit == 8 and self.bias is None
         if fused_mul:
-            y1 = mixlib.int8FusedDequantizeSiluMul(cache.q_xcache, self.q_weight, cache.x_scale, self.scale_col, y,
+            q, lay = self._cached_q(cache, M)
+            y1 = mixlib.int8FusedDequantizeSiluMul(q, self.q_weight, cache.x_scale, self.scale_col, y,
                                                    mul.reshape(M, self.out_features), M, self.out_features,
-                                                   self.in_features, getattr(cache, "q_layout", 0))
+                                                   self.in_features, lay)
         elif self.bit == 8:
-            y1 = mixlib.int8FusedDequantizeSilu(cache.q_xcache, self.q_weight, cache.x_scale, self.scale_col, y, M,
-                                                self.out_features, self.in_features, getattr(cache, "q_layout", 0))
+            q, lay = self._cached_q(cache, M)
+            y1 = mixlib.int8FusedDequantizeSilu(q, self.q_weight, cache.x_scale, self.scale_col, y, M,
+                                                self.out_features, self.in_features, lay)
         else:
             if y is None:
                 raise RuntimeError("int4 mod should have outliers !")  # :364

@@ -76,6 +76,7 @@ int main(int argc, char** argv)
     const int32_t M = atoi(argv[2]), N = atoi(argv[3]), K = atoi(argv[4]);
     const size_t mk = (size_t)M * K, nk = (size_t)N * K, mn = (size_t)M * N;
 
+    if (mixq_abi_version() != MIXQ_ABI_VERSION) return 9; /* a library built from another revision of mixq.h */
     /* the reference's loaders call this first (plugin.py:34-43) */
     if (!initOpenAiTritonPlugins(NULL, "tensorrt_llm") || !mixq_registry_has_creator("MixQ", "1", "tensorrt_llm")) return 4;
 

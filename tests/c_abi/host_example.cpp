@@ -65,6 +65,7 @@ int main(int argc, char** argv)
     const std::string dir = argv[1];
     const int32_t M = std::atoi(argv[2]), N = std::atoi(argv[3]), K = std::atoi(argv[4]);
     const size_t mk = (size_t)M * K, nk = (size_t)N * K, mn = (size_t)M * N;
+    if (mixq_abi_version() != MIXQ_ABI_VERSION) return 9;   // a library built from another revision of mixq.h
     if (!initOpenAiTritonPlugins(nullptr, "tensorrt_llm")) return 4;
 
     void* A = to_device(read_file(dir + "/A.f16", mk * 2));

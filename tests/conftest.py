@@ -96,6 +96,22 @@ def prefill_slack(parts, A=None, p=None):
     return slack
 
 
+def assert_prefill_parity(oracle, got, A, p, what="", bias=None):
+    """The W8A8O16 operator against the oracle, BOTH ways: north_star's 1e-3 of the output's maximum, and element by element
+    within one fp16 rounding step + the order slack of the outlier product (prefill_slack).  ``bias``: the fp16 addition the
+    caller applies after the operator (plugin.py:158-160) -- one more rounding, one more ulp of the un-biased value."""
+    want, parts = oracle.linear_prefill(A, p["weight"], p["weights_scaling_factor"], p["fp_weight"], p["fp_ind"], return_parts=True)
+    slack = prefill_slack(parts, A, p)
+    if bias is not None:
+        slack = slack + ulp16(want)
+        want = (want.astype(np.float16) + np.asarray(bias, np.float16)[None, :]).astype(np.float16)
+    g, w = got.astype(np.float64), want.astype(np.float64)
+    rel = np.abs(g - w).max() / max(np.abs(w).max(), 1e-30)
+    assert rel < 1e-3, f"{what}: max-normalised error {rel:.3e}"
+    assert_elementwise(got, want, slack, what)
+    return want
+
+
 def w8a16_slack(A, q_rm, scale):
     """Order slack of the fp16 x int8 paths: GAMMA x sum_k |a_k| |fp16(q_k s)|."""
     wd = np.abs((q_rm.astype(np.float32) * scale.astype(np.float32)[None, :]).astype(np.float16).astype(np.float32))

@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import make_layer
+from conftest import assert_prefill_parity, make_layer
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
@@ -17,7 +17,4 @@ def test_checkpoint_to_mixqlinear_forward(tmp_path, oracle):
     _, loaded = checkpoint.load_checkpoint(str(tmp_path))
     layer = checkpoint.load_linear(plugin.MixQLinear(512, 256, device="cuda:0"), loaded[prefix])
     got = layer(torch.from_numpy(A).to("cuda:0")).cpu().numpy()
-    want = oracle.linear_prefill(A, packed["weight"], packed["weights_scaling_factor"], packed["fp_weight"],
-                                 packed["fp_ind"])
-    err = np.abs(got.astype(np.float64) - want.astype(np.float64)).max() / np.abs(want.astype(np.float64)).max()
-    assert err < 1e-3
+    assert_prefill_parity(oracle, got, A, packed, "checkpoint -> MixQLinear")

@@ -9,7 +9,7 @@ import ctypes
 import numpy as np
 import pytest
 
-from conftest import assert_elementwise, make_layer, prefill_slack, ulp_histogram, w8a16_slack
+from conftest import assert_elementwise, assert_prefill_parity, make_layer, prefill_slack, ulp_histogram, w8a16_slack
 
 pytestmark = pytest.mark.gpu
 
@@ -207,8 +207,7 @@ def test_every_tile_configuration_of_the_two_barrier_kernel(oracle, variant, cfg
     A, W, act = make_layer(150, 272, 704, seed=cfg)
     p = oracle.pack_linear_weights(W, act)
     got = run_enqueue(A, p)
-    want = oracle.linear_prefill(A, p["weight"], p["weights_scaling_factor"], p["fp_weight"], p["fp_ind"])
-    assert rel_err(got, want) < REL_TOL
+    assert_prefill_parity(oracle, got, A, p, f"tile configuration {cfg}")
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 768, 1280), (700, 528, 2112), (520, 1024, 512), (257, 272, 704)])
@@ -219,8 +218,7 @@ def test_every_schedule_full_operator(oracle, variant, which, M, N, K):
     A, W, act = make_layer(M, N, K, seed=31)
     p = oracle.pack_linear_weights(W, act)
     got = run_enqueue(A, p)
-    want = oracle.linear_prefill(A, p["weight"], p["weights_scaling_factor"], p["fp_weight"], p["fp_ind"])
-    assert rel_err(got, want) < REL_TOL
+    assert_prefill_parity(oracle, got, A, p, f"schedule {which} {M}x{N}x{K}")
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 11008, 1024), (513, 5008, 448), (384, 12288, 512), (1500, 4096, 640)])
@@ -234,8 +232,7 @@ def test_mid_size_shapes_take_the_128x256_tiles_and_match_the_oracle(oracle, M, 
     p = oracle.pack_linear_weights(W, act)
     got = run_enqueue(A, p)
     assert b"pp128" in lib.mixq_debug_last_gemm_kernel(), lib.mixq_debug_last_gemm_kernel()
-    want = oracle.linear_prefill(A, p["weight"], p["weights_scaling_factor"], p["fp_weight"], p["fp_ind"])
-    assert rel_err(got, want) < REL_TOL
+    assert_prefill_parity(oracle, got, A, p, f"128x256 tiles {M}x{N}x{K}")
     lib.mixq_debug_set_gemm_variant(1)
     try:
         two_barrier = run_enqueue(A, p)

@@ -8,7 +8,7 @@ import ctypes
 import numpy as np
 import pytest
 
-from conftest import make_layer
+from conftest import assert_prefill_parity, make_layer
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
@@ -147,8 +147,7 @@ def test_split_form_through_enqueue_matches_the_oracle(oracle, lib, factor):
     assert lib.mixq_gemm_scratch_size(M, N, K) > 0
     got = run_enqueue(A, pk)
     assert np.array_equal(bits(got), bits(plain))
-    want = oracle.linear_prefill(A, pk["weight"], pk["weights_scaling_factor"], pk["fp_weight"], pk["fp_ind"])
-    assert rel_err(got, want) < REL_TOL
+    assert_prefill_parity(oracle, got, A, pk, f"K split {factor} ways through enqueue")
 
 
 def test_automatic_choice_and_graph_replay(lib):
