@@ -524,7 +524,7 @@ static hipError_t launch_epi(const GemmParams& p, hipStream_t st)
 
 // Schedule selection.  0 = auto (ping-pong 256x256 kernel when the problem fills the chip with 256x256 tiles, else the
 // 2-barrier kernel in a smaller tile), 1 = always the 2-barrier kernel, 2 = ping-pong whenever M > 4.
-// (The persistent ping-pong experiment of round 1 -- measured to lose -- lives in tools/experimental/, not in the library.)
+// (The persistent ping-pong experiment of round 1 -- measured to lose -- is in the history: tools/experimental/README.md.)
 // Set through mixq_debug_set_gemm_variant() (tests, A/B measurements) or MIXQ_GEMM_VARIANT=v1|pp in the environment.
 static std::atomic<int> g_variant{-1};
 static std::atomic<int> g_skinny_wide{0};
