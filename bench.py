@@ -216,7 +216,7 @@ def small_m_points(lib, TensorDesc, dev, gen, st_ptr, iters=300):
     return out
 
 
-def decode_step_points(lib, TensorDesc, model, dev, gen, hint_frac=1.0, batches=(1, 4, 32)):
+def decode_step_points(lib, TensorDesc, model, dev, gen, batches=(1, 4, 32)):
     """Informational (never part of `value`): ONE decode step's worth of the path -- all 96 MixQ linears of Llama-2-7B, each with
     ITS OWN weights (4.5 GB of int8 `weight` / `qweight`: cold by construction, no cache serves a layer twice), at batch 1, 4
     and 32, captured as one HIP graph of 96 mixq_enqueue calls.  The regime of the reference's published numbers (README of
@@ -238,36 +238,22 @@ def decode_step_points(lib, TensorDesc, model, dev, gen, hint_frac=1.0, batches=
             out_ptrs = (ctypes.c_void_p * 1)(outs[N].data_ptr())
             h = ctypes.c_void_p(lib.mixq_create(bs, N, K))
             max_ws = max(max_ws, lib.mixq_workspace_size(h, bs, N, K))
-            calls.append((h, in_desc, out_desc, in_ptrs, out_ptrs, v[5 if bs <= 4 else 1].data_ptr(), N * K))
+            calls.append((h, in_desc, out_desc, in_ptrs, out_ptrs))
             wbytes += N * K
         ws = torch.empty(max_ws, dtype=torch.uint8, device=dev)
         turn = [0]
 
         def run(st):
-            h, in_desc, out_desc, in_ptrs, out_ptrs, _, _ = calls[turn[0] % len(calls)]
+            h, in_desc, out_desc, in_ptrs, out_ptrs = calls[turn[0] % len(calls)]
             turn[0] += 1
             assert lib.mixq_enqueue(h, in_desc, ctypes.byref(out_desc), in_ptrs, out_ptrs, ctypes.c_void_p(ws.data_ptr()), st) == 0
 
-        def run_hint(st):   # the same step, every call naming the weights the NEXT call will stream (mixq_enqueue_hint)
-            i = turn[0] % len(calls)
-            h, in_desc, out_desc, in_ptrs, out_ptrs, _, _ = calls[i]
-            nxt = calls[(i + 1) % len(calls)]
-            turn[0] += 1
-            assert lib.mixq_enqueue_hint(h, in_desc, ctypes.byref(out_desc), in_ptrs, out_ptrs, ctypes.c_void_p(ws.data_ptr()), st,
-                                         ctypes.c_void_p(nxt[5]), int(nxt[6] * hint_frac) & ~127) == 0
-
         turn[0] = -1   # (graph_time_us makes one call outside the capture: the captured 96 then start at linear 0)
         us = graph_time_us(run, dev, calls=len(calls), reps=10) * len(calls)
-        turn[0] = -1
-        us_h = graph_time_us(run_hint, dev, calls=len(calls), reps=10) * len(calls)
         for c in calls:
             lib.mixq_destroy(c[0])
         out[f"bs{bs}"] = {"us_per_step": us, "linears": len(calls), "weight_GB": wbytes / 1e9, "weight_GBps": wbytes / us / 1e3,
-                          "hbm_frac": wbytes / (us * 1e-6) / 8e12, "tokens_per_s_bound_by_these_linears": bs / (us * 1e-6),
-                          "with_next_weight_hint": {"us_per_step": us_h, "weight_GBps": wbytes / us_h / 1e3,
-                                                    "hbm_frac": wbytes / (us_h * 1e-6) / 8e12,
-                                                    "what": "mixq_enqueue_hint: every call names the next layer's weight bytes; extra "
-                                                            "workgroups of its GEMM launch pull them into the Infinity Cache"}}
+                          "hbm_frac": wbytes / (us * 1e-6) / 8e12, "tokens_per_s_bound_by_these_linears": bs / (us * 1e-6)}
     out["what"] = ("one decode step of the 96 MixQ linears of Llama-2-7B (qkv, gate, proj x 32 layers), every layer its own weights, "
                    "one HIP graph of 96 mixq_enqueue calls; M <= 4: the W8A16 path on qweight, M = 32: quantise + fused int8 GEMM")
     return out

@@ -116,17 +116,6 @@ MIXQ_API size_t mixq_reference_workspace_size(int64_t maxM, int64_t N, int64_t K
 MIXQ_API int mixq_enqueue(const mixq_handle* h, const mixq_tensor_desc* inputDesc, const mixq_tensor_desc* outputDesc,
                           const void* const* inputs, void* const* outputs, void* workspace, void* stream);
 
-/* MI355X extension (no reference counterpart; like mixq_qa_layout it changes no result): mixq_enqueue + a HINT naming the weight
- * bytes the caller's NEXT call on this stream will stream -- the next layer's `qweight` (inputs[5]) when that call has M <= 4, its
- * `weight` (inputs[1]) otherwise, N * K bytes either way.  Decode and decode batches are weight streams: every layer's weights come
- * from HBM once per step, and a launch cannot start pulling them before the launch in front of it has ended.  With a hint, extra
- * workgroups of THIS call's GEMM launch touch that range (one dword per 128-byte line), so the lines sit in the 256 MiB memory-side
- * Infinity Cache when the next call asks for them, and the HBM stream of layer i + 1 runs under the compute of layer i.  Honoured
- * by the weight-streaming forms (W8A16 skinny form for M <= 4 on wide shapes, int8 skinny GEMM for decode batches); any other form
- * ignores it.  next_weights == NULL or next_bytes == 0: exactly mixq_enqueue.  Graph-capturable (the pointer is baked in). */
-MIXQ_API int mixq_enqueue_hint(const mixq_handle* h, const mixq_tensor_desc* inputDesc, const mixq_tensor_desc* outputDesc,
-                               const void* const* inputs, void* const* outputs, void* workspace, void* stream,
-                               const void* next_weights, size_t next_bytes);
 /* Same work, same launches; additionally records two caller-owned hipEvent_t (may be NULL) on `stream` immediately
  * before and after the fused-GEMM launch of the prefill path, so a harness can time the dominant kernel inside its
  * timed region without changing the path (bench.py "roofline"). */

@@ -84,8 +84,6 @@ SIGNATURES = {
     "mixq_enqueue_scratch_size": (_sz, [_i64, _i64, _i64]),
     "mixq_enqueue": (_i, [_vp, ctypes.POINTER(TensorDesc), ctypes.POINTER(TensorDesc), ctypes.POINTER(_vp),
                           ctypes.POINTER(_vp), _vp, _vp]),
-    "mixq_enqueue_hint": (_i, [_vp, ctypes.POINTER(TensorDesc), ctypes.POINTER(TensorDesc), ctypes.POINTER(_vp),
-                               ctypes.POINTER(_vp), _vp, _vp, _vp, _sz]),
     "mixq_enqueue_profiled": (_i, [_vp, ctypes.POINTER(TensorDesc), ctypes.POINTER(TensorDesc), ctypes.POINTER(_vp),
                                    ctypes.POINTER(_vp), _vp, _vp, _vp, _vp]),
     "mixq_int8quant": (_i, [_i, _i, _vp, _vp, _vp, _vp]),

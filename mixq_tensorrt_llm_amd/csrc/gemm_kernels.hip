@@ -653,17 +653,6 @@ bool gemm_pp128_wins(int M, int N, int K)
     return false;
 }
 
-static thread_local const void* t_pf_ptr = nullptr;
-static thread_local size_t t_pf_bytes = 0;
-void set_weight_prefetch_hint(const void* next_weights, size_t bytes) { t_pf_ptr = next_weights, t_pf_bytes = next_weights ? bytes : 0; }
-bool take_weight_prefetch_hint(const void** next_weights, size_t* bytes)
-{
-    *next_weights = t_pf_ptr, *bytes = t_pf_bytes;
-    const bool have = t_pf_ptr != nullptr && t_pf_bytes != 0;
-    t_pf_ptr = nullptr, t_pf_bytes = 0;
-    return have;
-}
-
 static std::atomic<const char*> g_last_kernel{"none"}; // reporting only (bench.py's roofline.kernel)
 const char* last_gemm_kernel() { return g_last_kernel.load(std::memory_order_relaxed); }
 void note_gemm_kernel(const char* name) { g_last_kernel.store(name, std::memory_order_relaxed); }

@@ -14,7 +14,6 @@
 // Reference lines replaced: see gemm_kernels.hip.
 #include "mixq_device.h"
 #include "mixq_launch.h"
-#include <algorithm>
 #include <atomic>
 #include <type_traits>
 
@@ -29,10 +28,6 @@ template <int MT, int EPI, int KW, int ABL = 0, bool AFRAG = false, int NT = 1>
 __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p)
 {
     __shared__ v4i part[KW][MT * NT][64]; // [K part][output tile][lane]
-    if (p.pf.nblocks != 0u && blockIdx.x >= gridDim.x - p.pf.nblocks) { // trailing blocks: touch the NEXT layer's weights (mixq_device.h)
-        weight_prefetch_block(p.pf, blockIdx.x - (gridDim.x - p.pf.nblocks));
-        return;
-    }
     dbg_stamp(p.dbg, 0); // (measurement only: p.dbg is NULL in production) entry
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -251,20 +246,9 @@ int skinny_feature_tiles(int M, int N, int K)
 }
 
 template <int EPI, int KW, int ABL = 0>
-static hipError_t launch_skinny_kw(const GemmParams& p_in, hipStream_t st)
+static hipError_t launch_skinny_kw(const GemmParams& p, hipStream_t st)
 {
-    GemmParams p = p_in;
-    p.pf = WeightPrefetch{nullptr, 0u, 0u};
-    {   // the thread's next-layer weight hint, if any: trailing blocks of this launch touch that range (mixq_device.h)
-        const void* nw = nullptr;
-        size_t nbytes = 0;
-        if (take_weight_prefetch_hint(&nw, &nbytes) && nbytes >= 128 && ABL == 0) {
-            p.pf.base = static_cast<const unsigned char*>(nw);
-            p.pf.nlines = (unsigned)std::min<size_t>(nbytes / 128, 0x7fffffffu);
-            p.pf.nblocks = (unsigned)std::min<size_t>((p.pf.nlines + KW * 64 * 8 - 1) / (KW * 64 * 8), 256);
-        }
-    }
-    const dim3 grid((unsigned)((p.N + 15) / 16) + p.pf.nblocks), block(KW * 64);
+    const dim3 grid((unsigned)((p.N + 15) / 16)), block(KW * 64);
     const int mt = (p.M + 15) / 16;
     if constexpr (KW == 4 && ABL == 0 && EPI != EPI_INT32) {
         if (p.a_frag == 1) { // (decode batches: M <= 32)
@@ -272,7 +256,7 @@ static hipError_t launch_skinny_kw(const GemmParams& p_in, hipStream_t st)
             if (mt == 3) { hipLaunchKernelGGL((gemm_skinny_kernel<3, EPI, KW, 0, true>), grid, block, 0, st, p); return hipGetLastError(); }
             if (mt == 4) { hipLaunchKernelGGL((gemm_skinny_kernel<4, EPI, KW, 0, true>), grid, block, 0, st, p); return hipGetLastError(); }
             if (skinny_feature_tiles(p.M, p.N, p.K) == 2) { // 32 features per workgroup
-                const dim3 grid2((unsigned)((p.N + 31) / 32) + p.pf.nblocks);
+                const dim3 grid2((unsigned)((p.N + 31) / 32));
                 if (mt == 1) hipLaunchKernelGGL((gemm_skinny_kernel<1, EPI, KW, 0, true, 2>), grid2, block, 0, st, p);
                 else hipLaunchKernelGGL((gemm_skinny_kernel<2, EPI, KW, 0, true, 2>), grid2, block, 0, st, p);
                 return hipGetLastError();

@@ -855,16 +855,6 @@ int mixq_enqueue(const mixq_handle* h, const mixq_tensor_desc* inputDesc, const 
     return enqueue_impl(h, inputDesc, inputs, outputs, workspace, stream, nullptr, nullptr);
 }
 
-int mixq_enqueue_hint(const mixq_handle* h, const mixq_tensor_desc* inputDesc, const mixq_tensor_desc* /*outputDesc*/,
-                      const void* const* inputs, void* const* outputs, void* workspace, void* stream, const void* next_weights,
-                      size_t next_bytes)
-{
-    mixq::set_weight_prefetch_hint(next_weights, next_bytes);
-    const int rc = enqueue_impl(h, inputDesc, inputs, outputs, workspace, stream, nullptr, nullptr);
-    mixq::set_weight_prefetch_hint(nullptr, 0); // (a launch that does not support the hint leaves it behind: never leak it into another call)
-    return rc;
-}
-
 int mixq_enqueue_profiled(const mixq_handle* h, const mixq_tensor_desc* inputDesc,
                           const mixq_tensor_desc* /*outputDesc*/, const void* const* inputs, void* const* outputs,
                           void* workspace, void* stream, void* ev_gemm_start, void* ev_gemm_stop)

@@ -3,8 +3,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "mixq_launch.h"
-
 namespace mixq {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -21,30 +19,6 @@ __device__ __forceinline__ void dbg_stamp(void* buf, int slot)
 {
     if (buf != nullptr && threadIdx.x == 0)
         static_cast<unsigned long long*>(buf)[(size_t)blockIdx.x * 8 + slot] = wall_clock64();
-}
-
-// NEXT-LAYER WEIGHT PREFETCH (round 4; decode and decode batches are weight streams, every layer's weights come from HBM once per step
-// and a launch cannot start pulling them before the launch in front of it has ended).  A launch that carries a hint gets `nblocks`
-// EXTRA workgroups at the end of its grid which only TOUCH the hinted byte range -- one dword per 128-byte line, results discarded --
-// so that the lines are resident in the 256 MiB memory-side Infinity Cache when the next launch asks for them (an XCD's L2 does not
-// keep lines across a kernel boundary: profiles/r04_quant_weight_prefetch.txt).  Separate workgroups, not extra loads in the streaming
-// waves: loads return in order, a slow HBM touch in front of the stream's own loads would stall every counted wait behind it.
-// (struct WeightPrefetch: mixq_launch.h)
-__device__ __forceinline__ void weight_prefetch_block(const WeightPrefetch pf, unsigned pb)
-{
-    const unsigned T = blockDim.x, stride = pf.nblocks * T;
-    unsigned sink = 0u;
-    for (unsigned line = pb * T + threadIdx.x; line < pf.nlines; line += 8u * stride) {
-        unsigned v[8];
-#pragma unroll
-        for (unsigned u = 0; u < 8u; ++u) {
-            const unsigned l = line + u * stride;
-            v[u] = *reinterpret_cast<const unsigned*>(pf.base + (size_t)(l < pf.nlines ? l : pf.nlines - 1u) * 128u);
-        }
-#pragma unroll
-        for (unsigned u = 0; u < 8u; ++u) sink |= v[u];
-    }
-    asm volatile("" ::"v"(sink)); // (the loads must be issued; their values are not used)
 }
 
 #define MIXQ_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))

@@ -60,13 +60,6 @@ int tp_chunk_tile_rows(int M);     // tile rows per flag word for an M-row call:
 int tp_flag_words(int M);          // flag words a consumer must wait for = ceil(tile rows / chunk_tile_rows) <= kTpFlagWords
 bool gemm_tp_fused_supported(int M, int N, int K, int O); // launch_gemm would take the plain 256 x 256 ping-pong kernel
 
-// next-layer weight prefetch: trailing blocks of a launch touch a byte range (mixq_device.h weight_prefetch_block has the story)
-struct WeightPrefetch {
-    const unsigned char* base; // null: no prefetch blocks in the grid
-    unsigned nlines;           // 128-byte lines to touch
-    unsigned nblocks;          // trailing blocks of the grid that do it
-};
-
 struct GemmParams {
     const int8_t* A;      // qA [M,K]
     const int8_t* B;      // W  [N,K]
@@ -88,7 +81,6 @@ struct GemmParams {
     unsigned splitk_patience; // (set by launch_gemm_pp_splitk) wall-clock ticks a workgroup waits for its partners before
                               // it defers its share to the last arriver
     TpEpilogue tp;        // (launch_gemm_pp_tp only) peer-write epilogue, else ndst == 0
-    WeightPrefetch pf;    // (gemm_skinny_kernel only, set by its launcher from the thread's hint) else {null, 0, 0}
     void* splitk_ws;      // device scratch of gemm_splitk_workspace_size bytes whose arrival words are zero, or null: lets
                           // launch_gemm split K over 2 / 4 workgroups per 256x256 tile when the tiles alone cover at
                           // most half / a quarter of the CUs (gemm_pp_kernels.hip)
@@ -170,10 +162,6 @@ hipError_t launch_w8a16(const void* A, const uint8_t* Wq, const void* scale, voi
                         hipStream_t st);
 
 void note_gemm_kernel(const char* name);
-// next-layer weight prefetch (mixq_device.h WeightPrefetch): a THREAD-LOCAL hint, consumed (and cleared) by the next launch of this
-// thread that supports it -- the W8A16 skinny form and the int8 skinny GEMM; any other launch just clears it
-void set_weight_prefetch_hint(const void* next_weights, size_t bytes);
-bool take_weight_prefetch_hint(const void** next_weights, size_t* bytes);
 // TP all-gather of the output columns as one-sided peer writes + flags (tp_kernels.hip)
 hipError_t launch_tp_push(const void* src, void* const* dst_bases, unsigned* const* dst_flags, int ndst, int M, int n_loc,
                           int N, int col0, unsigned seq, int nflags, unsigned* done_counter, hipStream_t st);

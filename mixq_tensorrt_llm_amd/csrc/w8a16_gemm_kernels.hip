@@ -31,7 +31,6 @@
 
 #include "mixq_device.h"
 #include "mixq_launch.h"
-#include <algorithm>
 
 namespace mixq {
 
@@ -719,13 +718,9 @@ typedef float v4f_ __attribute__((ext_vector_type(4)));
 template <int MT, int KW, int CG>
 __global__ __launch_bounds__(KW * 64) void w8a16_skinny_kernel(const uint16_t* __restrict__ A, const uint8_t* __restrict__ Wq,
                                                                 const uint16_t* __restrict__ scale,
-                                                                uint16_t* __restrict__ Out, int M, int N, int K, WeightPrefetch pf)
+                                                                uint16_t* __restrict__ Out, int M, int N, int K)
 {
     __shared__ v4f_ part[KW][CG][MT][64]; // [K part][column group][token tile][lane]
-    if (pf.nblocks != 0u && blockIdx.x >= gridDim.x - pf.nblocks) { // trailing blocks: touch the NEXT layer's weights (mixq_device.h)
-        weight_prefetch_block(pf, blockIdx.x - (gridDim.x - pf.nblocks));
-        return;
-    }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ln = lane & 15, kq = lane >> 4;
@@ -1094,16 +1089,8 @@ template <int MT, int KW, int CG>
 static hipError_t launch_wo_skinny(const uint16_t* A, const uint8_t* Wq, const uint16_t* scale, uint16_t* Out, int M, int N,
                                    int K, hipStream_t st)
 {
-    WeightPrefetch pf{nullptr, 0u, 0u};
-    const void* nw = nullptr;
-    size_t nbytes = 0;
-    if (take_weight_prefetch_hint(&nw, &nbytes) && nbytes >= 128) {
-        pf.base = static_cast<const unsigned char*>(nw);
-        pf.nlines = (unsigned)std::min<size_t>(nbytes / 128, 0x7fffffffu);
-        pf.nblocks = (unsigned)std::min<size_t>((pf.nlines + KW * 64 * 8 - 1) / (KW * 64 * 8), 256); // 8 touches per lane, at most one block per CU
-    }
-    hipLaunchKernelGGL((w8a16_skinny_kernel<MT, KW, CG>), dim3((unsigned)((N + 16 * CG - 1) / (16 * CG)) + pf.nblocks), dim3(KW * 64), 0, st,
-                       A, Wq, scale, Out, M, N, K, pf);
+    hipLaunchKernelGGL((w8a16_skinny_kernel<MT, KW, CG>), dim3((unsigned)((N + 16 * CG - 1) / (16 * CG))), dim3(KW * 64), 0, st,
+                       A, Wq, scale, Out, M, N, K);
     return hipGetLastError();
 }
 
