@@ -196,9 +196,17 @@ dot_s8(const int8_t* a, const int8_t* b, int64_t K)
 ORACLE_API void mixq_oracle_gemm_s8s8s32(int64_t M, int64_t N, int64_t K, const int8_t* qA, const int8_t* W,
                                          int32_t* acc)
 {
+    /* cache-blocked (round 4): a 16-row block of qA against a 64-row block of W, both resident in L2 while their 1024 dot
+     * products are taken -- the unblocked loop streamed all of W from memory once per token row.  Integer sums: same bits. */
+    const int64_t MB = 16, NB = 64;
+    const int64_t mb = (M + MB - 1) / MB, nb = (N + NB - 1) / NB;
 #pragma omp parallel for schedule(static)
-    for (int64_t m = 0; m < M; ++m)
-        for (int64_t n = 0; n < N; ++n) acc[m * N + n] = dot_s8(qA + m * K, W + n * K, K);
+    for (int64_t blk = 0; blk < mb * nb; ++blk) {
+        const int64_t m0 = (blk / nb) * MB, n0 = (blk % nb) * NB;
+        const int64_t m1 = m0 + MB < M ? m0 + MB : M, n1 = n0 + NB < N ? n0 + NB : N;
+        for (int64_t n = n0; n < n1; ++n)
+            for (int64_t m = m0; m < m1; ++m) acc[m * N + n] = dot_s8(qA + m * K, W + n * K, K);
+    }
 }
 
 /* ------------------------------------------- a3: fp16 outlier side GEMM -- */

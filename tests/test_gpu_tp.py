@@ -328,26 +328,29 @@ def test_lost_peer_surfaces_as_an_error_not_a_stale_tensor(tmp_path):
         assert res == "1", f"rank {r}: {res}"
 
 
-def test_bench_self_launches_at_two_ranks(tmp_path):
-    """`python bench.py --gpus 2 ...` exactly as the driver types it (no torch.distributed.run in front, no WORLD_SIZE):
-    bench.py spawns its own ranks; rank 0 prints the ONE JSON line; the north-star layout (tp = 2) ran with a named
-    transport and no error.  Both ranks share the one GPU of the box (MIXQ_BENCH_SINGLE_GPU_RANKS=1: gloo for the
-    harness collectives) -- control flow, not a measurement."""
+@pytest.mark.parametrize("gpus", [2, 8])
+def test_bench_self_launches(tmp_path, gpus):
+    """`python bench.py --gpus N ...` exactly as the driver types it (no torch.distributed.run in front, no WORLD_SIZE):
+    bench.py spawns its own ranks; rank 0 prints the ONE JSON line; the north-star layout (tp = N) ran with a named
+    transport and no error.  All ranks share the one GPU of the box (MIXQ_BENCH_SINGLE_GPU_RANKS=1: gloo for the
+    harness collectives) -- control flow, not a measurement.  N = 8 is the driver's largest run: its shard widths
+    (1536 / 1376 / 512 rows), eight-way transport self-tests and the transport comparison execute here first."""
     import json
     import subprocess
     env = dict(os.environ, MIXQ_BENCH_SINGLE_GPU_RANKS="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--tokens", "16384", "--steps", "1",
+    tokens = "16384" if gpus == 2 else "8192"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--tokens", tokens, "--steps", "1",
                         "--warmup", "1"], capture_output=True, text=True, env=env, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout[-2000:]
     rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["config"]["parallelism"] == "dp2"
+    assert rec["n_gpus"] == gpus and rec["value"] > 0 and rec["config"]["parallelism"] == f"dp{gpus}"
     tp = rec["tp"]
     assert "error" not in tp, tp
-    assert tp["world_size"] == 2 and tp["tp"] == 2 and tp["transport"] and tp["peer_wait_timed_out"] is False
+    assert tp["world_size"] == gpus and tp["tp"] == gpus and tp["transport"] and tp["peer_wait_timed_out"] is False
     assert tp["value"] > 0
     alts = tp.get("alternatives_one_step_each")   # the other transports of the same layout, one timed step each
     assert isinstance(alts, dict) and "error" not in alts, alts

@@ -6,7 +6,7 @@ OUT="$PWD/gpurun_out/pmc_bench"; rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/$c" -o p -- \
-      python "$OLDPWD/bench.py" --tokens 65536 --steps 1 --warmup 0 --no-cpu-baseline --no-decode-step ) > "$OUT/$c.log" 2>&1
+      python "$OLDPWD/bench.py" --tokens 65536 --steps 1 --warmup 0 --no-cpu-baseline --no-decode-step --no-sweeps ) > "$OUT/$c.log" 2>&1
 done
 python - "$OUT" <<'PY' | tee "$OUT/summary.txt"
 import csv, glob, sys, collections
