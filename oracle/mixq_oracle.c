@@ -611,6 +611,14 @@ ORACLE_API int mixq_oracle_num_threads(void)
 #endif
 }
 
+/* the Python side caps the team at the CPUs the process may really use (cgroup quota): a host process that loaded an OpenMP
+ * runtime earlier (torch does) has already sized it from the CPUs it can see */
+ORACLE_API void mixq_oracle_set_num_threads(int n)
+{
+    if (n > 0) omp_set_num_threads(n);
+}
+
+
 /* ------------------- next row f1: fused RMSNorm -> extract -> quantise ------------------ */
 /*
  * quantkernel/mix_cuda/layernorm/layernorm.cu:122-198 generalT5LayerNorm_extract_outliers (T5 style: no mean, no bias):

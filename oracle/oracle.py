@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libmixq_oracle.so")
 
 __all__ = [
-    "build", "lib", "num_threads", "quant_rows", "extract_outliers", "gemm_s8s8s32", "gemm_fp16",
+    "build", "lib", "num_threads", "usable_cpus", "quant_rows", "extract_outliers", "gemm_s8s8s32", "gemm_fp16",
     "dequant_epilogue", "dequantization", "dequantization_silu", "w8a16_gemv_reforder", "linear_prefill", "weight_scales", "quantize_weight",
     "select_outliers", "pack_linear_weights", "eetq_symmetric_quantize", "eetq_preprocess", "w8a16_gemv",
     "int_to_half", "int8_matrix_to_half", "rmsnorm_extract_quant", "find_outliers", "dequant_weight_columns",
@@ -38,9 +38,42 @@ def lib():
     if _lib is None:
         if not os.path.exists(_LIB_PATH):
             build()
+        # OpenMP sizes its team from the CPUs it can SEE; a container's CPU quota is not one of them (the GPU boxes of this pool
+        # show 256 logical CPUs under a cgroup quota of 16: 128 threads ran the same GEMM 20 % SLOWER than 16,
+        # tools/cpu_probe.py).  Cap the team at what the process may actually use, before libgomp reads the environment.
+        usable = usable_cpus()
+        try:
+            asked = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+        except ValueError:
+            asked = 0
+        if asked <= 0 or asked > usable:
+            os.environ["OMP_NUM_THREADS"] = str(usable)
         _lib = ctypes.CDLL(_LIB_PATH)
         _lib.mixq_oracle_num_threads.restype = ctypes.c_int
+        if _lib.mixq_oracle_num_threads() > usable:   # (an OpenMP runtime loaded before us -- torch's -- already read the environment)
+            _lib.mixq_oracle_set_num_threads(usable)
     return _lib
+
+
+def usable_cpus():
+    """CPUs this process may really use: min(affinity mask, cgroup v2 / v1 CPU quota)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                n = min(n, max(1, -(-q // per)))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
 
 
 def num_threads():

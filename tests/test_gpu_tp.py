@@ -70,7 +70,8 @@ def _worker(rank, world, port, tmp):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    os.environ["OMP_NUM_THREADS"] = str(max(1, (os.cpu_count() or 8) // world))   # `world` oracles run side by side
+    from oracle.oracle import usable_cpus
+    os.environ["OMP_NUM_THREADS"] = str(max(1, usable_cpus() // world))   # `world` oracles run side by side
     import torch.distributed as dist
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -465,7 +466,6 @@ def _eight_worker(rank, world, port, tmp):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    os.environ["OMP_NUM_THREADS"] = str(max(1, (os.cpu_count() or 8) // world))
     import torch.distributed as dist
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
