@@ -645,11 +645,14 @@ static int gemm_variant()
 bool gemm_pp128_wins(int M, int N, int K)
 {
     if (M <= 128) return false;
-    const int64_t t = (int64_t)((M + 127) / 128) * ((N + 255) / 256);
+    const int64_t tm = (M + 127) / 128, t = tm * ((N + 255) / 256);
     const int nk = (K + 127) / 128, cus = num_cus();
     if (t > cus) return false;
-    if (nk < 64) return 256 * t >= (int64_t)88 * cus;
-    if (nk < 80) return 256 * t >= (int64_t)160 * cus;
+    // tiles weighted by the share of their rows that exist (round 4, tools/midm_cfg_sweep.py in steady state: 192 x 12288 x 4096 = 96
+    // tiles three quarters full ran 26.2 us here against 23.8 us on plain 64 x 64 tiles; every other mid-M cell within 2 % of its best)
+    const int64_t t_rows = tm <= 2 ? t * M : t * 128, full = tm <= 2 ? tm * 128 : 128; // (measured for one / two tile rows only)
+    if (nk < 64) return 256 * t_rows >= (int64_t)88 * cus * full;
+    if (nk < 80) return 256 * t_rows >= (int64_t)160 * cus * full;
     return false;
 }
 
