@@ -5,7 +5,7 @@ set -u
 cd "$(dirname "$0")/.."
 OUT=gpurun_out/r04_final; mkdir -p $OUT
 export TMPDIR=/tmp
-echo "== pytest -m gpu"; timeout 2400 python -m pytest tests -m gpu -q --timeout 1500 2>&1 | tail -6 | tee $OUT/pytest_gpu.log
+echo "== pytest -m gpu"; timeout 2400 python -m pytest tests -m gpu -q --timeout 1500 --durations=8 2>&1 | tail -18 | tee $OUT/pytest_gpu.log
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -4
 echo "== bench.py (defaults)"; T0=$SECONDS; timeout 1500 python bench.py 2>$OUT/bench.err | tail -1 | tee $OUT/bench_full.json | cut -c1-500; echo "bench wall $((SECONDS - T0)) s"
 echo "== rocprofv3 kernel trace + stats"
