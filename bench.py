@@ -143,7 +143,11 @@ def small_m_points(lib, TensorDesc, dev, gen, st_ptr, iters=300):
         dt = graph_time_us(run, dev) * 1e-6
         out[name] = {"us_per_call": dt * 1e6, "weight_GBps": N * K / dt / 1e9, "hbm_frac": N * K / dt / 8e12,
                      "launches_per_call": 2 if M > 4 else 1, "timing": "HIP graph of 100 calls (device-paced)",
-                     "cache": "warm: every call re-reads the SAME layer's weights, which the 256 MiB Infinity Cache then serves"}
+                     "cache": "warm: every call re-reads the SAME layer's weights, which the 256 MiB Infinity Cache then serves"
+                              + (" -- except that M <= 4 calls on weights of 32 MiB and more stream them with non-temporal loads (no cache "
+                                 "allocation: a model's decode step reads each layer once and can never find it resident; -4.6 % per decode "
+                                 "step), so this loop no longer gains from re-reading one layer; the cold twin is what a decode step sees"
+                                 if (M <= 4 and N * K >= (32 << 20)) else "")}
         # the same point with COLD weights, as in a model's decode step (every layer's weights come from HBM once per step):
         # the calls of the graph cycle through enough distinct copies of the streamed weight tensor to exceed the Infinity Cache
         try:

@@ -563,6 +563,10 @@ void set_gemm_variant(int v)
         set_wo_force(300 + (v - 850), -2);
         return;
     }
+    if (v == 848 || v == 849) { // fpA_intB skinny form, non-temporal loads of weights >= 32 MiB: 848 on (default), 849 off
+        set_wo_force(v == 848 ? 500 : 501, -2);
+        return;
+    }
     if (v >= 845 && v <= 847) { // fpA_intB wide form, weights through registers instead of LDS: 845 automatic, 846 never, 847 always
         set_wo_force(400 + (v - 845), -2);
         return;

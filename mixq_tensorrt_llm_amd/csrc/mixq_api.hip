@@ -118,7 +118,7 @@ void mixq_debug_reset(void)
     g_dbg_stamps.store(nullptr);
     mixq::set_quant_stamp_buffer(nullptr);
     for (int v : {-1 /* schedule (back to the MIXQ_GEMM_VARIANT default), tile configuration, skinny K width */, 79 /* K splits over workgroups automatic */, 69, 65, 91,
-                  80 /* fpA_intB forms automatic */, 85, 840, 843, 850, 858, 891 /* fragment-major qA on */, 893 /* skinny range: the rule */,
+                  80 /* fpA_intB forms automatic */, 85, 840, 843, 848 /* non-temporal loads of large weights on */, 850, 858, 891 /* fragment-major qA on */, 893 /* skinny range: the rule */,
                   894 /* feature tiles automatic */})
         mixq::set_gemm_variant(v);
 }

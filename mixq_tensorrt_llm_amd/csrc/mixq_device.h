@@ -21,6 +21,15 @@ __device__ __forceinline__ void dbg_stamp(void* buf, int slot)
         static_cast<unsigned long long*>(buf)[(size_t)blockIdx.x * 8 + slot] = wall_clock64();
 }
 
+// 16-byte weight-stream load, optionally NON-TEMPORAL (no L2 / Infinity-Cache allocation): for weight tensors so large that a model's
+// decode step, which reads every layer's weights exactly once, can never find them cache-resident (w8a16_gemm_kernels.hip, NTW)
+template <bool NT>
+__device__ __forceinline__ uint4 wload16(const void* ptr)
+{
+    if constexpr (NT) return __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const v4i*>(ptr)));
+    else return *reinterpret_cast<const uint4*>(ptr);
+}
+
 #define MIXQ_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define MIXQ_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 

@@ -715,7 +715,13 @@ __global__ __launch_bounds__(256 * (WMH == 3 ? 2 : WMH)) void w8a16_gemm_wide_ke
 typedef float v4f_ __attribute__((ext_vector_type(4)));
 
 // CG: 16-column groups per wave (2 or 4: the token fragments are shared by CG MFMA A operands)
-template <int MT, int KW, int CG>
+// NTW: the weight loads are non-temporal.  Round 4, A/B on one box (profiles/r04_nt_weight_loads_ab.txt): a decode step of Llama-2-7B's
+// 96 linears (every layer its own weights: cold by construction) 1087 -> 1037 us at batch 1, 1124 -> 1070 at batch 4; single cold
+// calls on 45-50 MB of weights -3.5..-4.4 %; 16.8 MB of weights +2.4 % cold; and +25..30 % for a loop that re-reads ONE layer (the
+// Infinity Cache serves such a loop, the hint gives that up).  Hence only for weights of wo_nt_weight_bytes() (32 MiB) and more: a
+// model with layers that large streams them from HBM once per step whatever the policy.  The int8 decode-batch GEMM measured +2 %
+// with the same hint and keeps plain loads.
+template <int MT, int KW, int CG, bool NTW = false>
 __global__ __launch_bounds__(KW * 64) void w8a16_skinny_kernel(const uint16_t* __restrict__ A, const uint8_t* __restrict__ Wq,
                                                                 const uint16_t* __restrict__ scale,
                                                                 uint16_t* __restrict__ Out, int M, int N, int K)
@@ -759,7 +765,7 @@ __global__ __launch_bounds__(KW * 64) void w8a16_skinny_kernel(const uint16_t* _
         for (int u = 0; u < UB; ++u) {
             const int b = min(b0 + u, b_end - 1); // (the tail re-reads the last block; its products are skipped below)
 #pragma unroll
-            for (int cg = 0; cg < CG; ++cg) wv[u][cg] = *reinterpret_cast<const uint4*>(wsrc[cg] + (int64_t)b * 128);
+            for (int cg = 0; cg < CG; ++cg) wv[u][cg] = wload16<NTW>(wsrc[cg] + (int64_t)b * 128);
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
                 av[u][t][0] = *reinterpret_cast<const uint4*>(asrc[t] + b * 64);
@@ -898,6 +904,8 @@ struct WoWidePlan {
 };
 
 static std::atomic<int> g_wo_abl{0};
+static std::atomic<int> g_wo_nt{1};    // non-temporal weight loads in the skinny form for weights of 32 MiB and more: 1 on (default), 0 off
+static inline int64_t wo_nt_weight_bytes() { return (int64_t)32 << 20; }
 static std::atomic<int> g_wo_skinny_decode{-1}; // 2..4 tokens through the skinny form: -1 where it wins (measured), 0 never, 1 always
 static std::atomic<int> g_wo_skinny{1}; // the skinny form up to 32 tokens: 1 automatic, 0 off, 2..5 a fixed shape (measurements)
 static std::atomic<int> g_wo_twopass_tile{0}; // (measurements, with the form forced) row height of the second pass's tiles; 0: 256
@@ -907,6 +915,10 @@ static std::atomic<int> g_wo_form{-1}; // measurement knob: -1 automatic, else t
 static std::atomic<int> g_wo_ks{-1};   // -1 automatic, else the K split of the wide form (where K allows)
 void set_wo_force(int form, int ks)
 {
+    if (form == 500 || form == 501) { // non-temporal weight loads of the skinny form (large weights): 500 on (default), 501 off
+        g_wo_nt.store(form == 500 ? 1 : 0);
+        return;
+    }
     if (form == 309 || form == 310) { // (measurements, up to 16 tokens) 16 columns per wave x 8 / 16 waves
         g_wo_skinny.store(form == 309 ? 6 : 7);
         return;
@@ -1089,8 +1101,14 @@ template <int MT, int KW, int CG>
 static hipError_t launch_wo_skinny(const uint16_t* A, const uint8_t* Wq, const uint16_t* scale, uint16_t* Out, int M, int N,
                                    int K, hipStream_t st)
 {
-    hipLaunchKernelGGL((w8a16_skinny_kernel<MT, KW, CG>), dim3((unsigned)((N + 16 * CG - 1) / (16 * CG))), dim3(KW * 64), 0, st,
-                       A, Wq, scale, Out, M, N, K);
+    const dim3 grid((unsigned)((N + 16 * CG - 1) / (16 * CG))), block(KW * 64);
+    if constexpr (MT == 1) { // (decode and the smallest decode batches: the forms a model's decode step runs)
+        if (g_wo_nt.load() != 0 && (int64_t)N * K >= wo_nt_weight_bytes()) {
+            hipLaunchKernelGGL((w8a16_skinny_kernel<MT, KW, CG, true>), grid, block, 0, st, A, Wq, scale, Out, M, N, K);
+            return hipGetLastError();
+        }
+    }
+    hipLaunchKernelGGL((w8a16_skinny_kernel<MT, KW, CG>), grid, block, 0, st, A, Wq, scale, Out, M, N, K);
     return hipGetLastError();
 }
 

@@ -350,3 +350,26 @@ def test_argument_validation():
     assert lib.mixq_w8a16_gemm_forward_ws(16, 16, 16, 16, 8, 64, 96, None, 0, None) == 2           # K % 64
     assert lib.mixq_w8a16_gemm_forward_ws(16, 16, 16, 16, 8, 63, 64, None, 0, None) == 2           # odd N
     assert lib.mixq_w8a16_gemm_workspace_size(4, 4096, 4096) == 0                                   # GEMV: no scratch
+
+
+@pytest.mark.parametrize("N,K", [(8192, 4096), (12288, 4096), (4096, 11008)])
+def test_non_temporal_weight_loads_change_no_bit(oracle, N, K):
+    """Weights of 32 MiB and more are streamed with non-temporal loads by the skinny form (a cache-policy hint, round 4): knob 849
+    switches it off; same bits either way, and the oracle's within the usual bound.  1 .. 16 tokens = the forms that carry the hint."""
+    from mixq_tensorrt_llm_amd import _lib
+    lib = _lib.load()
+    assert N * K >= (32 << 20)
+    A, q, sc = make(16, N, K, N + K)
+    qi = oracle.eetq_preprocess(q)
+    want = oracle.w8a16_gemv(A, q, sc)
+    for M in (1, 3, 4, 9, 16):
+        outs = []
+        for knob in (848, 849):
+            lib.mixq_debug_set_gemm_variant(knob)
+            try:
+                got, _ = run(A[:M], qi, sc, N, scratch=False)
+            finally:
+                lib.mixq_debug_set_gemm_variant(848)
+            outs.append(got)
+        assert np.array_equal(outs[0].view(np.uint16), outs[1].view(np.uint16)), (M, N, K)
+        assert_elementwise(outs[0], want[:M], w8a16_slack(A[:M], q, sc), f"nt weight loads {M}x{N}x{K}")
