@@ -101,3 +101,38 @@ def test_act_scales_may_be_a_pt_path(tmp_path):
     b = quantize.quantize_model(sm.state_dict(), act_table(), 1)
     for prefix in a:
         np.testing.assert_array_equal(a[prefix]["weight"], b[prefix]["weight"])
+
+
+def test_bf16_and_fp32_state_dicts_pack_like_their_fp16_rounding():
+    """The reference casts every weight to the export dtype first (layer_utils.py:585 `.type(dtype)`): a bf16 / fp32 state dict
+    must give the tensors of its fp16-rounded twin."""
+    sd16 = sm.state_dict()
+    want = quantize.quantize_layer(sd16, act_table(), 0, "mlp.gate")
+    for dt in (torch.float32, torch.bfloat16):
+        sd = {k: v.to(dt) for k, v in sd16.items()}
+        ref = quantize.quantize_layer({k: v.to(torch.float16) for k, v in sd.items()}, act_table(), 0, "mlp.gate")
+        got = quantize.quantize_layer(sd, act_table(), 0, "mlp.gate")
+        for name in ("weight", "weights_scaling_factor", "fp_weight", "fp_ind", "qweight"):
+            np.testing.assert_array_equal(np.ascontiguousarray(got[name]).view(np.uint8), np.ascontiguousarray(ref[name]).view(np.uint8), err_msg=f"{dt} {name}")
+        if dt == torch.float32:   # fp16 -> fp32 -> fp16 is the identity
+            np.testing.assert_array_equal(got["weight"], want["weight"])
+
+
+def test_walk_rejects_inconsistent_inputs():
+    sd = sm.state_dict(with_bias=True)
+    del sd["model.layers.0.self_attn.k_proj.bias"]          # K and V should have a bias when Q has one (model_config.py:146-150)
+    with pytest.raises(AssertionError):
+        quantize.quantize_layer(sd, act_table(), 0, "attention.qkv")
+    with pytest.raises(KeyError):                            # a table without the key the walk reads
+        quantize.quantize_layer(sm.state_dict(), {}, 0, "mlp.proj")
+    with pytest.raises(AssertionError):                      # 64 | 32 | 32 rows do not split 3 ways
+        quantize.rank_major_rows((64, 32, 32), 3)
+    with pytest.raises(AssertionError):
+        quantize.quantize_model(sm.state_dict(), act_table(), 1, qkv_layout="interleaved")
+
+
+def test_oracle_team_is_capped_by_the_cpu_quota():
+    import oracle
+    n = oracle.usable_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    assert oracle.num_threads() <= n
