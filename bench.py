@@ -555,11 +555,14 @@ def main():
                 tp_group = grp
     tp_rank = rank % tp
 
+    if args.variant != 0:
+        os.environ.setdefault("MIXQ_DEBUG_KNOBS", "1")
     from mixq_tensorrt_llm_amd import _lib, parallel
     from mixq_tensorrt_llm_amd._lib import TensorDesc
     lib = _lib.load()
     assert lib.initOpenAiTritonPlugins(None, b"tensorrt_llm")
-    lib.mixq_debug_set_gemm_variant(args.variant)
+    if args.variant != 0:   # (A/B runs only; the knob acts only where MIXQ_DEBUG_KNOBS=1 -- a default run never touches it)
+        lib.mixq_debug_set_gemm_variant(args.variant)
     hip = Hip()
 
     chunk = min(args.chunk, args.tokens)

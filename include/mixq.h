@@ -378,6 +378,10 @@ MIXQ_API int mixq_unprocess_weights_int8(int8_t* row_major, const uint8_t* prepr
  * in-kernel timelines.  The operator boundary above holds no such state: with the knobs at their defaults --
  * mixq_debug_reset() -- the selection is a pure function of (M, N, K, scratch).  No knob changes results beyond what the
  * tests pin (every form is bit-identical or within the stated tolerance), except the ablation ranges marked "wrong results". */
+/* The set_* knobs below act ONLY in a process whose environment holds MIXQ_DEBUG_KNOBS=1 when the first of them is called (read
+ * once); anywhere else they are ignored, so that no code path of a production process can change the kernel selection.
+ * mixq_debug_knobs_enabled() says which kind of process this is.  mixq_debug_reset() and the reporting entries always work. */
+MIXQ_API int mixq_debug_knobs_enabled(void);
 MIXQ_API void mixq_debug_reset(void);
 /* Test / measurement knob: main-loop schedule of the fused GEMM.  0 = auto (default), 1 = 2-barrier double-buffered
  * kernel only, 2 = 256x256 ping-pong kernel for every M > 4.  Results are identical bit for bit in all modes. */

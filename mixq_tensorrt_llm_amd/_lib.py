@@ -140,6 +140,7 @@ SIGNATURES = {
     "mixq_unprocess_weights_int8": (_i, [_vp, _vp, _sz, _sz]),
     "mixq_debug_set_gemm_variant": (None, [_i]),
     "mixq_debug_reset": (None, []),
+    "mixq_debug_knobs_enabled": (_i, []),
     "mixq_debug_set_stamp_buffer": (None, [_vp]),
     "mixq_debug_set_quant_stamp_buffer": (None, [_vp]),
     "mixq_debug_last_gemm_kernel": (ctypes.c_char_p, []),
@@ -171,6 +172,16 @@ def load():
         except AttributeError as e:
             raise MixQLibraryError(f"{LIB_PATH} does not export {name}") from e
         fn.restype, fn.argtypes = res, args
+    # the measurement knobs are ignored by the library unless MIXQ_DEBUG_KNOBS=1 was in the environment (include/mixq.h): make a
+    # forgotten opt-in loud on the Python side instead of a silently unchanged selection
+    raw_set = lib.mixq_debug_set_gemm_variant
+
+    def set_gemm_variant(v):
+        if not lib.mixq_debug_knobs_enabled():
+            raise MixQLibraryError("mixq_debug_set_gemm_variant: measurement knobs are off in this process -- export "
+                                   "MIXQ_DEBUG_KNOBS=1 before the first knob call (tests/conftest.py and the scripts under tools/ do)")
+        raw_set(v)
+    lib.mixq_debug_set_gemm_variant = set_gemm_variant
     if lib.mixq_abi_version() != ABI_VERSION:   # a stale .so next to newer bindings would take shifted arguments
         raise MixQLibraryError(f"{LIB_PATH} has ABI revision {lib.mixq_abi_version()}, these bindings need {ABI_VERSION}: rebuild it")
     _lib = lib

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -106,11 +107,33 @@ int mixq_registry_has_creator(const char* name, const char* version, const char*
 const char* mixq_plugin_type(void) { return "MixQ"; }
 const char* mixq_plugin_version(void) { return "1"; }
 static std::atomic<void*> g_dbg_stamps{nullptr}; // measurement knob only (NULL in production)
-void mixq_debug_set_stamp_buffer(void* device_u64_8_per_block) { g_dbg_stamps.store(device_u64_8_per_block); }
+// The measurement knobs are PROCESS-GLOBAL, so a production process must not be one stray call away from another kernel
+// selection: they act only in a process that opted in with MIXQ_DEBUG_KNOBS=1 in its environment BEFORE the first
+// knob call (read once).  mixq_debug_reset() and the reporting entries are always allowed.
+static bool debug_knobs_enabled()
+{
+    static const bool on = [] {
+        const char* e = getenv("MIXQ_DEBUG_KNOBS");
+        return e != nullptr && e[0] == '1';
+    }();
+    return on;
+}
+int mixq_debug_knobs_enabled(void) { return debug_knobs_enabled() ? 1 : 0; }
 
-void mixq_debug_set_quant_stamp_buffer(void* device_u64_8_per_block) { mixq::set_quant_stamp_buffer(device_u64_8_per_block); }
+void mixq_debug_set_stamp_buffer(void* device_u64_8_per_block)
+{
+    if (debug_knobs_enabled() || device_u64_8_per_block == nullptr) g_dbg_stamps.store(device_u64_8_per_block);
+}
 
-void mixq_debug_set_gemm_variant(int variant) { mixq::set_gemm_variant(variant < 0 ? 0 : variant); }
+void mixq_debug_set_quant_stamp_buffer(void* device_u64_8_per_block)
+{
+    if (debug_knobs_enabled() || device_u64_8_per_block == nullptr) mixq::set_quant_stamp_buffer(device_u64_8_per_block);
+}
+
+void mixq_debug_set_gemm_variant(int variant)
+{
+    if (debug_knobs_enabled()) mixq::set_gemm_variant(variant < 0 ? 0 : variant);
+}
 
 void mixq_debug_reset(void)
 {

@@ -1,6 +1,8 @@
 import os
 import sys
 
+os.environ.setdefault("MIXQ_DEBUG_KNOBS", "1")   # the tests force kernel forms through mixq_debug_*: opt in before the library loads
+
 import numpy as np
 import pytest
 

@@ -293,3 +293,25 @@ def test_headers_are_valid_c99_and_cxx11_and_the_c_and_cxx_hosts_link(tmp_path):
         r = subprocess.run([compiler, std, "-Wall", "-Wextra", "-Werror", "-Wno-unused-parameter", "-I", inc, "-I", "/opt/rocm/include",
                             os.path.join(ROOT, "tests", "c_abi", name), "-o", str(exe)] + link, capture_output=True, text=True)
         assert r.returncode == 0 and exe.exists(), r.stderr
+
+
+def test_measurement_knobs_need_an_opt_in():
+    """mixq_debug_set_* act only in a process that exported MIXQ_DEBUG_KNOBS=1 (include/mixq.h): a production process cannot have
+    its kernel selection changed by a stray call; the Python binding makes a forgotten opt-in loud."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from mixq_tensorrt_llm_amd import _lib\n"
+            "lib = _lib.load()\n"
+            "print(lib.mixq_debug_knobs_enabled())\n"
+            "try:\n"
+            "    lib.mixq_debug_set_gemm_variant(1); print('set')\n"
+            "except _lib.MixQLibraryError: print('refused')\n"
+            "lib.mixq_debug_reset(); print('reset ok')\n") % ROOT
+    for env_val, want in ((None, ["0", "refused", "reset ok"]), ("1", ["1", "set", "reset ok"]), ("0", ["0", "refused", "reset ok"])):
+        env = {k: v for k, v in os.environ.items() if k != "MIXQ_DEBUG_KNOBS"}
+        if env_val is not None:
+            env["MIXQ_DEBUG_KNOBS"] = env_val
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert r.stdout.split("\n")[:3] == want, (env_val, r.stdout)

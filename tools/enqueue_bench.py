@@ -4,6 +4,8 @@ usage: python tools/enqueue_bench.py --M 32 --N 4096 --K 4096 [--variant 80|81] 
 import argparse
 import ctypes
 import os
+
+os.environ.setdefault("MIXQ_DEBUG_KNOBS", "1")   # measurement script: the library honours its knobs only in a process that opts in
 import sys
 import time
 

@@ -4,6 +4,8 @@ usage: python tools/gemm_bench.py [--M 8192 --N 12288 --K 4096 --O 128 --variant
 import argparse
 import ctypes
 import os
+
+os.environ.setdefault("MIXQ_DEBUG_KNOBS", "1")   # measurement script: the library honours its knobs only in a process that opts in
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -5,6 +5,8 @@ the forced K splits (72 / 74 / 78).  us per launch.  usage: python tools/midm_cf
 import argparse
 import ctypes
 import os
+
+os.environ.setdefault("MIXQ_DEBUG_KNOBS", "1")   # measurement script: the library honours its knobs only in a process that opts in
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -11,6 +11,8 @@ usage: python tools/round_table.py [--secs 0.5] [--Ms 8192,16384,65536] [--shape
 import argparse
 import ctypes
 import os
+
+os.environ.setdefault("MIXQ_DEBUG_KNOBS", "1")   # measurement script: the library honours its knobs only in a process that opts in
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -19,6 +19,8 @@ usage: python tools/selection_check.py [--tolerance 0.10] [--quick]"""
 import argparse
 import ctypes
 import os
+
+os.environ.setdefault("MIXQ_DEBUG_KNOBS", "1")   # measurement script: the library honours its knobs only in a process that opts in
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -8,6 +8,8 @@ GEMM's stamps.  usage: python tools/small_m_timeline.py [--M 32 --N 4096 --K 409
 import argparse
 import ctypes
 import os
+
+os.environ.setdefault("MIXQ_DEBUG_KNOBS", "1")   # measurement script: the library honours its knobs only in a process that opts in
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

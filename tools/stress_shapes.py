@@ -4,6 +4,8 @@ integer matrix product and fused outputs bit-identical to a fixed reference conf
 the two-barrier kernel, one workgroup per tile); the default selection includes the K splits over workgroups (the mixlib
 wrappers bring their per-stream scratch).  Not part of pytest (minutes, not seconds): python tools/stress_shapes.py [count] [seed]"""
 import os
+
+os.environ.setdefault("MIXQ_DEBUG_KNOBS", "1")   # measurement script: the library honours its knobs only in a process that opts in
 import sys
 import time
 

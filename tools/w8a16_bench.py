@@ -4,6 +4,8 @@ usage: python tools/w8a16_bench.py --N 12288 --K 4096 [--Ms 5,16,32,64,128,256,5
 import argparse
 import ctypes
 import os
+
+os.environ.setdefault("MIXQ_DEBUG_KNOBS", "1")   # measurement script: the library honours its knobs only in a process that opts in
 import sys
 import time
 
