@@ -172,6 +172,22 @@ def small_m_points(lib, TensorDesc, dev, gen, st_ptr, iters=300):
                                  "weight_copies_cycled": copies,
                                  "what": f"{copies} distinct copies of the weight tensor ({copies * N * K >> 20} MiB > the "
                                          "Infinity Cache), one per call in turn: every call streams its weights from HBM"}
+            if M > 4:   # the same two loops with a registered weight image per copy (mixq_weight_image_*: + N K bytes, same bits)
+                imgs = [torch.empty(N * K, dtype=torch.int8, device=dev) for _ in alts]
+                try:
+                    st0 = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+                    for wcopy, im in zip(alts, imgs):
+                        assert lib.mixq_weight_image_register(ctypes.c_void_p(wcopy.data_ptr()), N, K, ctypes.c_void_p(im.data_ptr()), st0) == 0
+                    torch.cuda.synchronize(dev)
+                    tw, tcold = graph_time_us(run, dev), graph_time_us(run_cold, dev)
+                    out[name]["with_weight_image"] = {"us_per_call": tw, "cold_us_per_call": tcold, "hbm_frac": N * K / (tw * 1e-6) / 8e12,
+                                                      "cold_hbm_frac": N * K / (tcold * 1e-6) / 8e12,
+                                                      "what": "the layer's `weight` registered with mixq_weight_image_register: the "
+                                                              "decode-batch GEMM streams a fragment-major copy (contiguous reads)"}
+                finally:
+                    for wcopy in alts:
+                        lib.mixq_weight_image_unregister(ctypes.c_void_p(wcopy.data_ptr()))
+                    del imgs
             del alts
         except Exception as e:  # noqa: BLE001
             out[name]["cold"] = {"error": repr(e)}
@@ -254,10 +270,33 @@ def decode_step_points(lib, TensorDesc, model, dev, gen, batches=(1, 4, 32)):
 
         turn[0] = -1   # (graph_time_us makes one call outside the capture: the captured 96 then start at linear 0)
         us = graph_time_us(run, dev, calls=len(calls), reps=10) * len(calls)
-        for c in calls:
-            lib.mixq_destroy(c[0])
         out[f"bs{bs}"] = {"us_per_step": us, "linears": len(calls), "weight_GB": wbytes / 1e9, "weight_GBps": wbytes / us / 1e3,
                           "hbm_frac": wbytes / (us * 1e-6) / 8e12, "tokens_per_s_bound_by_these_linears": bs / (us * 1e-6)}
+        if bs > 4:   # the same step with a registered weight image per layer (mixq_weight_image_*: + N K bytes per layer, same bits)
+            try:
+                imgs = []
+                st0 = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+                for (t, ins) in model.keep:
+                    N, K = t["weight"].shape[0], ins[0].shape[1]
+                    im = torch.empty(N * K, dtype=torch.int8, device=dev)
+                    assert lib.mixq_weight_image_register(ctypes.c_void_p(t["weight"].data_ptr()), N, K, ctypes.c_void_p(im.data_ptr()), st0) == 0
+                    imgs.append(im)
+                torch.cuda.synchronize(dev)
+                turn[0] = -1
+                us_i = graph_time_us(run, dev, calls=len(calls), reps=10) * len(calls)
+                out[f"bs{bs}"]["with_weight_images"] = {
+                    "us_per_step": us_i, "weight_GBps": wbytes / us_i / 1e3, "hbm_frac": wbytes / (us_i * 1e-6) / 8e12,
+                    "tokens_per_s_bound_by_these_linears": bs / (us_i * 1e-6), "extra_HBM_GB": wbytes / 1e9,
+                    "what": "every layer's `weight` registered with mixq_weight_image_register (a fragment-major copy the decode-batch "
+                            "GEMM streams with contiguous reads; the calls are the same mixq_enqueue calls, bit-identical outputs)"}
+            except Exception as e:  # noqa: BLE001
+                out[f"bs{bs}"]["with_weight_images"] = {"error": repr(e)}
+            finally:
+                for (t, ins) in model.keep:
+                    lib.mixq_weight_image_unregister(ctypes.c_void_p(t["weight"].data_ptr()))
+                imgs = None
+        for c in calls:
+            lib.mixq_destroy(c[0])
     out["what"] = ("one decode step of the 96 MixQ linears of Llama-2-7B (qkv, gate, proj x 32 layers), every layer its own weights, "
                    "one HIP graph of 96 mixq_enqueue calls; M <= 4: the W8A16 path on qweight, M = 32: quantise + fused int8 GEMM")
     return out

@@ -186,6 +186,24 @@ MIXQ_API size_t mixq_gemm_scratch_bound(void);
 MIXQ_API int mixq_gemm_mixed_scratch(const int8_t* qA, const int8_t* W, const void* sA, const void* sW, const void* fpA,
                                      const void* fpW, void* Out, int M, int N, int K, int O, void* scratch,
                                      size_t scratch_bytes, void* stream);
+/* ---- weight images (MI355X extension; no reference counterpart, no result changes) -----------------------------------------
+ * The reference stores `weight` (inputs[1]) row-major int8 [N, K].  Decode batches (5 .. 64 rows) are weight streams, and the
+ * weight-streaming GEMM's MFMA fragment load takes 64 bytes of 16 rows that lie K bytes apart.  A runtime that can spare N * K
+ * bytes per layer registers a FRAGMENT-MAJOR copy once at load time; from then on every call on that `weight` POINTER whose shape
+ * the decode-batch GEMM serves -- mixq_enqueue, mixq_gemm_mixed*, mixq_int8_fused_dequantize*, mixq_mixlinear_forward -- reads
+ * the copy (one contiguous 1-KiB read per load; images of 32 MiB and more with non-temporal loads).  Bit-identical results;
+ * operator time at 32 rows -10..-15 % (profiles/r04_weight_image_probe.txt).  Every other kernel keeps reading `weight` itself,
+ * which must stay valid and unchanged.
+ *   mixq_weight_image_bytes(N, K)        bytes the image needs (N * K), or 0 if the shape has no image (N % 16 or K % 64 != 0)
+ *   mixq_weight_image_register(...)      builds the image of `weight` into caller-owned device memory `image` (one launch on
+ *                                        `stream`) and registers it under the pointer `weight`; registering again replaces it
+ *   mixq_weight_image_unregister(weight) forgets it -- REQUIRED before `weight` or `image` is freed or rewritten: the registry is
+ *                                        keyed by address and cannot see a reallocation (a shape that no longer matches is ignored)
+ * Process-global, thread-safe (readers share a lock; with nothing registered a lookup is one atomic load). */
+MIXQ_API size_t mixq_weight_image_bytes(int64_t N, int64_t K);
+MIXQ_API int mixq_weight_image_register(const int8_t* weight, int64_t N, int64_t K, void* image, void* stream);
+MIXQ_API int mixq_weight_image_unregister(const int8_t* weight);
+
 /* ---- qA layouts (MI355X extension; decode batches) --------------------------------------------------------------------------
  * The int8 activation image between a producer (quantiser, fused norm) and the fused GEMM is the library's own intermediate,
  * so the producer may write the layout the consuming kernel reads fastest.  ROW_MAJOR [M,K] is what every reference-named

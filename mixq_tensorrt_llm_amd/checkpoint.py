@@ -104,6 +104,8 @@ def load_checkpoint(ckpt_dir: str, rank: int = 0) -> (dict, Dict[str, Dict[str, 
 def load_linear(layer, tensors: Dict[str, torch.Tensor]):
     """Install one module's carrier tensors into a plugin.MixQLinear (names match plugin.py:99-123)."""
     dev = layer.weight.device
+    if getattr(layer, "weight_image", None) is not None:   # (a registered streaming copy belongs to the tensor being replaced)
+        layer.prepare_decode_batches(False)
     for name in MIXQ_TENSORS:
         want = tuple(getattr(layer, name).shape)
         got = tuple(tensors[name].shape)

@@ -533,6 +533,10 @@ bool qa_frag_enabled() { return g_qa_frag.load() != 0; }
 
 void set_gemm_variant(int v)
 {
+    if (v >= 880 && v <= 883) { // registered weight images in the decode-batch GEMM: 880 automatic, 881 plain loads, 882 non-temporal loads, 883 ignored
+        set_skinny_wfrag(v - 880);
+        return;
+    }
     if (v >= 894 && v <= 896) { // fragment-major skinny form: feature tiles per workgroup automatic / 1 / 2
         set_skinny_nt(v - 894);
         return;

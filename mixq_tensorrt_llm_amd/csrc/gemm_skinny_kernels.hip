@@ -15,6 +15,9 @@
 #include "mixq_device.h"
 #include "mixq_launch.h"
 #include <atomic>
+#include <mutex>
+#include <shared_mutex>
+#include <unordered_map>
 #include <type_traits>
 
 namespace mixq {
@@ -24,7 +27,7 @@ namespace mixq {
 // (32 output features per workgroup): the workgroups of a WIDE output then pull half as many qA bytes in total (N / 32 x M x K
 // instead of N / 16 x M x K) while the chip is still full (N = 12288: 384 workgroups).  Output tile tt = nt * MT + t of the
 // workgroup is finished by wave tt % KW.
-template <int MT, int EPI, int KW, int ABL = 0, bool AFRAG = false, int NT = 1>
+template <int MT, int EPI, int KW, int ABL = 0, bool AFRAG = false, int NT = 1, int WFRAG = 0>
 __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p)
 {
     __shared__ v4i part[KW][MT * NT][64]; // [K part][output tile][lane]
@@ -108,7 +111,16 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
             int off = su * 64;                                        // byte offset inside the row, + lq * 16 per lane
             if (!FULL) off = min(off + lq * 16, koff_last) - lq * 16;
 #pragma unroll
-            for (int c = 0; c < NT; ++c) wf[u][c] = (ABL & 2) ? zero4 : *reinterpret_cast<const v4i*>(wrow[c] + off);
+            for (int c = 0; c < NT; ++c) {
+                if (WFRAG != 0) { // W from its registered fragment-major image (weight_image_kernel below): one contiguous 1-KiB read of
+                                  // whole cache lines per load instead of 64 bytes of 16 rows K bytes apart; WFRAG == 2: non-temporal
+                    const int8_t* src = p.B + ((int64_t)(min((n0 >> 4) + c, (p.N >> 4) - 1) * nsteps + su) << 10) + lane * 16; // (clamped tiles are computed, never stored)
+                    if (WFRAG == 2) wf[u][c] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(src));
+                    else wf[u][c] = *reinterpret_cast<const v4i*>(src);
+                } else {
+                    wf[u][c] = (ABL & 2) ? zero4 : *reinterpret_cast<const v4i*>(wrow[c] + off);
+                }
+            }
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
                 if (AFRAG) // fragment-major qA (quant_kernels.hip FRAG): block (m tile, k-step), lane l at l * 16 -- ONE
@@ -245,25 +257,113 @@ int skinny_feature_tiles(int M, int N, int K)
     return (wgs > cus && 8 * wgs < 11 * cus) ? 2 : 1; // (256, 352) workgroups on 256 CUs
 }
 
+// ---- weight images (MI355X extension, round 4) ---------------------------------------------------------------------------------
+// The reference stores `weight` row-major int8 [N, K]; the skinny GEMM's MFMA A-fragment load then takes 64 bytes of 16 rows that
+// lie K bytes apart: half a cache line per row per instruction.  A caller that can spare N K bytes per layer registers a
+// FRAGMENT-MAJOR copy of the weight -- 1-KiB blocks [16-feature tile][64-byte k-step], lane l = feature % 16 + 16 * (k / 16 % 4)
+// holding its 16 bytes at l * 16, the layout the quantiser already uses for qA -- and every decode-batch call on that weight
+// pointer reads the copy instead: one contiguous 1-KiB read per load.  Same bytes into the same MFMA lanes: same bits.  Measured
+// (tools/wfrag_probe.py, operator = quantiser + GEMM, 32 rows): 12288 x 4096 16.3 -> 14.4 us warm, 21.0 -> 18.1 cold;
+// 4096 x 4096 (BASELINE configs[0]) 9.1 -> 8.3 warm, 10.9 -> 9.8 cold; 4096 x 11008 18.0 -> 15.8 / 22.3 -> 19.3.
+// Loads of an image of 32 MiB or more are non-temporal (cold by construction in any model, see w8a16_gemm_kernels.hip NTW).
+__global__ __launch_bounds__(256) void weight_image_kernel(const int8_t* __restrict__ W, int8_t* __restrict__ img, int N, int K)
+{
+    const int nsteps = K >> 6;
+    const int64_t chunk = (int64_t)blockIdx.x * 256 + threadIdx.x;        // 16-byte chunk of the image
+    const int64_t total = (int64_t)(N >> 4) * nsteps * 64;
+    if (chunk >= total) return;
+    const int lane = (int)(chunk & 63);
+    const int64_t blk = chunk >> 6;
+    const int64_t tile = blk / nsteps;
+    const int step = (int)(blk - tile * nsteps);
+    const int8_t* src = W + (tile * 16 + (lane & 15)) * (int64_t)K + step * 64 + (lane >> 4) * 16;
+    *reinterpret_cast<v4i*>(img + (chunk << 4)) = *reinterpret_cast<const v4i*>(src);
+}
+
+hipError_t launch_weight_image(const int8_t* W, int8_t* img, int N, int K, hipStream_t st)
+{
+    if (N <= 0 || K <= 0 || N % 16 || K % 64) return hipErrorInvalidValue;
+    const int64_t total = (int64_t)(N >> 4) * (K >> 6) * 64;
+    hipLaunchKernelGGL(weight_image_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, img, N, K);
+    return hipGetLastError();
+}
+
+namespace {
+struct WeightImage {
+    const void* image;
+    int N, K;
+};
+std::shared_mutex g_wimg_mutex;
+std::unordered_map<const void*, WeightImage> g_wimg;
+std::atomic<int> g_wimg_count{0};
+} // namespace
+
+void register_weight_image(const void* weight, const void* image, int N, int K)
+{
+    std::unique_lock<std::shared_mutex> lk(g_wimg_mutex);
+    g_wimg[weight] = WeightImage{image, N, K};
+    g_wimg_count.store((int)g_wimg.size(), std::memory_order_release);
+}
+bool unregister_weight_image(const void* weight)
+{
+    std::unique_lock<std::shared_mutex> lk(g_wimg_mutex);
+    const bool had = g_wimg.erase(weight) != 0;
+    g_wimg_count.store((int)g_wimg.size(), std::memory_order_release);
+    return had;
+}
+const void* find_weight_image(const void* weight, int N, int K)
+{
+    if (g_wimg_count.load(std::memory_order_acquire) == 0) return nullptr; // (the common case costs one atomic load)
+    std::shared_lock<std::shared_mutex> lk(g_wimg_mutex);
+    const auto it = g_wimg.find(weight);
+    return it != g_wimg.end() && it->second.N == N && it->second.K == K ? it->second.image : nullptr; // (another shape: stale, ignored)
+}
+
+static std::atomic<int> g_skinny_wfrag{0}; // knob 880 automatic | 881 images with plain loads | 882 with non-temporal loads | 883 images ignored
+void set_skinny_wfrag(int mode) { g_skinny_wfrag.store(mode); }
+
 template <int EPI, int KW, int ABL = 0>
-static hipError_t launch_skinny_kw(const GemmParams& p, hipStream_t st)
+static hipError_t launch_skinny_kw_impl(const GemmParams& p, hipStream_t st);
+
+template <int EPI, int KW, int ABL = 0>
+static hipError_t launch_skinny_kw(const GemmParams& p_in, hipStream_t st)
+{
+    GemmParams p = p_in;
+    p.b_frag = 0;
+    const int mode = g_skinny_wfrag.load(std::memory_order_relaxed);
+    if (p.a_frag == 1 && mode != 3 && EPI != EPI_INT32 && p.K % 64 == 0 && p.N % 16 == 0) {
+        if (const void* img = find_weight_image(p.B, p.N, p.K)) {
+            p.B = static_cast<const int8_t*>(img);
+            p.b_frag = mode == 1 ? 1 : mode == 2 ? 2 : ((int64_t)p.N * p.K >= ((int64_t)32 << 20) ? 2 : 1);
+        }
+    }
+    return launch_skinny_kw_impl<EPI, KW, ABL>(p, st);
+}
+
+template <int MT, int EPI, int KW, int NT>
+static hipError_t launch_skinny_frag(const GemmParams& p, dim3 grid, dim3 block, hipStream_t st)
+{
+    if (p.b_frag == 1) hipLaunchKernelGGL((gemm_skinny_kernel<MT, EPI, KW, 0, true, NT, 1>), grid, block, 0, st, p);
+    else if (p.b_frag == 2) hipLaunchKernelGGL((gemm_skinny_kernel<MT, EPI, KW, 0, true, NT, 2>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((gemm_skinny_kernel<MT, EPI, KW, 0, true, NT>), grid, block, 0, st, p);
+    return hipGetLastError();
+}
+
+template <int EPI, int KW, int ABL>
+static hipError_t launch_skinny_kw_impl(const GemmParams& p, hipStream_t st)
 {
     const dim3 grid((unsigned)((p.N + 15) / 16)), block(KW * 64);
     const int mt = (p.M + 15) / 16;
     if constexpr (KW == 4 && ABL == 0 && EPI != EPI_INT32) {
-        if (p.a_frag == 1) { // (decode batches: M <= 32)
+        if (p.a_frag == 1) { // (decode batches: M <= 64)
             if (mt > 4) return hipErrorInvalidValue;
-            if (mt == 3) { hipLaunchKernelGGL((gemm_skinny_kernel<3, EPI, KW, 0, true>), grid, block, 0, st, p); return hipGetLastError(); }
-            if (mt == 4) { hipLaunchKernelGGL((gemm_skinny_kernel<4, EPI, KW, 0, true>), grid, block, 0, st, p); return hipGetLastError(); }
+            if (mt == 3) return launch_skinny_frag<3, EPI, KW, 1>(p, grid, block, st);
+            if (mt == 4) return launch_skinny_frag<4, EPI, KW, 1>(p, grid, block, st);
             if (skinny_feature_tiles(p.M, p.N, p.K) == 2) { // 32 features per workgroup
                 const dim3 grid2((unsigned)((p.N + 31) / 32));
-                if (mt == 1) hipLaunchKernelGGL((gemm_skinny_kernel<1, EPI, KW, 0, true, 2>), grid2, block, 0, st, p);
-                else hipLaunchKernelGGL((gemm_skinny_kernel<2, EPI, KW, 0, true, 2>), grid2, block, 0, st, p);
-                return hipGetLastError();
+                return mt == 1 ? launch_skinny_frag<1, EPI, KW, 2>(p, grid2, block, st) : launch_skinny_frag<2, EPI, KW, 2>(p, grid2, block, st);
             }
-            if (mt == 1) hipLaunchKernelGGL((gemm_skinny_kernel<1, EPI, KW, 0, true>), grid, block, 0, st, p);
-            else hipLaunchKernelGGL((gemm_skinny_kernel<2, EPI, KW, 0, true>), grid, block, 0, st, p);
-            return hipGetLastError();
+            return mt == 1 ? launch_skinny_frag<1, EPI, KW, 1>(p, grid, block, st) : launch_skinny_frag<2, EPI, KW, 1>(p, grid, block, st);
         }
     }
     if (p.a_frag != 0) return hipErrorInvalidValue;

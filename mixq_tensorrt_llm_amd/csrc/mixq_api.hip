@@ -142,7 +142,7 @@ void mixq_debug_reset(void)
     mixq::set_quant_stamp_buffer(nullptr);
     for (int v : {-1 /* schedule (back to the MIXQ_GEMM_VARIANT default), tile configuration, skinny K width */, 79 /* K splits over workgroups automatic */, 69, 65, 91,
                   80 /* fpA_intB forms automatic */, 85, 840, 843, 848 /* non-temporal loads of large weights on */, 850, 858, 891 /* fragment-major qA on */, 893 /* skinny range: the rule */,
-                  894 /* feature tiles automatic */})
+                  894 /* feature tiles automatic */, 880 /* skinny-GEMM weight image off */})
         mixq::set_gemm_variant(v);
 }
 
@@ -622,6 +622,25 @@ static int gemm_mixed_impl(const int8_t* qA, const int8_t* W, const void* sA, co
     p.Y = static_cast<const uint16_t*>(Out), p.O = 0;
     return hip_rc(mixq::launch_gemm(p, mixq::EPI_DEQUANT, st));
 }
+
+// ---- weight images (MI355X extension): a fragment-major copy of `weight` for the decode-batch GEMM ------------------------------
+size_t mixq_weight_image_bytes(int64_t N, int64_t K)
+{
+    if (N <= 0 || K <= 0 || N % 16 || K % 64 || N > INT32_MAX || K > INT32_MAX) return 0;
+    return (size_t)N * (size_t)K;
+}
+
+int mixq_weight_image_register(const int8_t* weight, int64_t N, int64_t K, void* image, void* stream)
+{
+    if (!weight || !image) return MIXQ_E_BADARG;
+    if (mixq_weight_image_bytes(N, K) == 0) return MIXQ_E_SHAPE;
+    if (!aligned16(weight) || !aligned16(image)) return MIXQ_E_ALIGN;
+    const int rc = hip_rc(mixq::launch_weight_image(weight, static_cast<int8_t*>(image), (int)N, (int)K, static_cast<hipStream_t>(stream)));
+    if (rc == MIXQ_OK) mixq::register_weight_image(weight, image, (int)N, (int)K);
+    return rc;
+}
+
+int mixq_weight_image_unregister(const int8_t* weight) { return weight && mixq::unregister_weight_image(weight) ? MIXQ_OK : MIXQ_E_BADARG; }
 
 // ---- qA layouts (MI355X extension): the producer may write the image its consumer reads fastest ---------------------------
 int mixq_qa_layout(int M, int N, int K)

@@ -160,6 +160,16 @@ class MixLinear_GEMM:
             q.bias.copy_(bias.to(dev).half())
         return q
 
+    def prepare_decode_batches(self, enable=True):
+        """MI355X extension: register a fragment-major streaming copy of ``q_weight`` (bit = 8) for decode batches of 5 .. 64 rows
+        (mixlib.WeightImage; same bits, -10..-15 % per call, N * K more bytes).  Call after the weights are final."""
+        if getattr(self, "weight_image", None) is not None:
+            self.weight_image.close()
+        self.weight_image = None
+        if enable and self.bit == 8 and not self.weight_only:
+            self.weight_image = mixlib.WeightImage(self.q_weight)
+        return self
+
     def FindOutliers(self, activation):
         """linear.py:155-161."""
         return find_outliers(activation, float(self.sigma[0, 0]))

@@ -176,6 +176,19 @@ class MixQLinear:
         self._plugin = None
         self.peer_gather = None   # optional parallel.PeerGather: one-sided peer writes instead of the RCCL all-gather
         self.peer_gather_alias = False  # True: forward() returns a VIEW of the gather buffer (valid until two more gathers)
+        self.weight_image = None  # optional mixlib.WeightImage (prepare_decode_batches): a streaming-friendly copy of `weight`
+
+    def prepare_decode_batches(self, enable: bool = True):
+        """MI355X extension (include/mixq.h ``mixq_weight_image_*``): register a fragment-major copy of ``weight`` so that decode
+        batches (5 .. 64 rows) stream it with contiguous reads -- same bits, -10..-15 % per call, N * K more bytes of HBM.  Call
+        after the weights are loaded; ``enable=False`` drops the copy."""
+        from . import mixlib
+        if self.weight_image is not None:
+            self.weight_image.close()
+            self.weight_image = None
+        if enable:
+            self.weight_image = mixlib.WeightImage(self.weight.view(torch.int8))
+        return self
 
     def load(self, packed: dict):
         """Install the tensors produced by ``pack.pack_linear_weights`` (true dtypes) as fp16 carriers."""
@@ -186,6 +199,8 @@ class MixQLinear:
             return t.to(dev)
 
         N, K = self.out_features, self.in_features
+        had_image = self.weight_image is not None
+        self.prepare_decode_batches(False)               # (a registered copy belongs to the OLD weight tensor)
         self.weight = carrier(packed["weight"], (N, K // 2))
         self.fp_weight = carrier(packed["fp_weight"], (N, NUM_OUTLIERS))
         self.fp_ind = carrier(packed["fp_ind"].astype(np.int32), (NUM_OUTLIERS * 2,))
@@ -195,6 +210,8 @@ class MixQLinear:
             b = torch.from_numpy(np.ascontiguousarray(packed["bias"])).to(dev)
             assert tuple(b.shape) == (N,), f"bias {tuple(b.shape)} vs this rank's {N} output features"
             self.bias = b.to(self.bias.dtype)
+        if had_image:
+            self.prepare_decode_batches(True)
         return self
 
     def forward(self, A: torch.Tensor) -> torch.Tensor:

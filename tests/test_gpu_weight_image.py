@@ -1,0 +1,114 @@
+"""GPU (-m gpu): weight images (include/mixq.h ``mixq_weight_image_*``, MI355X extension): a registered fragment-major copy of the
+int8 weight is what decode-batch calls on that weight pointer stream.  Same bytes into the same MFMA lanes -- every result must be
+the bits of the unregistered call; the image must be the documented layout; unregistering must restore the plain path."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import assert_prefill_parity, make_layer
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _layer(oracle, N, K, seed):
+    from mixq_tensorrt_llm_amd import plugin
+    A, W, act = make_layer(64, N, K, seed=seed)
+    p = oracle.pack_linear_weights(W, act)
+    return A, p, plugin.MixQLinear(K, N, device="cuda:0").load(p)
+
+
+def test_image_is_the_documented_layout_and_shapes_without_one_are_refused():
+    from mixq_tensorrt_llm_amd import _lib, mixlib
+    lib = _lib.load()
+    g = torch.Generator(device="cuda:0").manual_seed(3)
+    N, K = 272, 704 - 704 % 64   # 17 feature tiles x 10 k-steps
+    W = torch.randint(-128, 128, (N, K), dtype=torch.int32, device="cuda:0", generator=g).to(torch.int8)
+    img = mixlib.WeightImage(W)
+    torch.cuda.synchronize()
+    want = W.view(N // 16, 16, K // 64, 4, 16).permute(0, 2, 3, 1, 4).contiguous().view(-1)   # [tile][k-step][k quarter][feature][16 B]
+    assert torch.equal(img.image, want)
+    img.close()
+    assert lib.mixq_weight_image_unregister(ctypes.c_void_p(W.data_ptr())) != 0     # already gone
+    assert lib.mixq_weight_image_bytes(N, K) == N * K
+    assert lib.mixq_weight_image_bytes(N + 8, K) == 0 and lib.mixq_weight_image_bytes(N, K + 16) == 0
+    with pytest.raises(ValueError):
+        mixlib.WeightImage(torch.zeros((24, 64), dtype=torch.int8, device="cuda:0"))
+
+
+@pytest.mark.parametrize("N,K", [(4096, 4096), (5120, 5120), (12288, 1024), (512, 8192), (272, 704)])
+def test_registered_calls_are_bit_identical(oracle, N, K):
+    """5 .. 64 rows: one to four 16-row tiles, 16 and 32 features per workgroup (5120 x 5120), shapes the skinny GEMM does not serve
+    (the image is then simply not read), K with a ragged last k-step (704: no image exists), both load policies."""
+    from mixq_tensorrt_llm_amd import _lib
+    lib = _lib.load()
+    A, p, layer = _layer(oracle, N, K, seed=N + K)
+    plain = {}
+    for M in (5, 16, 17, 32, 33, 48, 64, 3, 200):
+        x = torch.from_numpy(np.concatenate([A] * 4)[:M]).to("cuda:0")
+        plain[M] = (x, layer(x).clone(), lib.mixq_debug_last_gemm_kernel())
+    if K % 64:
+        with pytest.raises(ValueError):
+            layer.prepare_decode_batches()
+        return
+    layer.prepare_decode_batches()
+    try:
+        for knob in (880, 881, 882):
+            lib.mixq_debug_set_gemm_variant(knob)
+            for M, (x, want, kern) in plain.items():
+                got = layer(x)
+                torch.cuda.synchronize()
+                assert torch.equal(got, want), (knob, M)
+                assert lib.mixq_debug_last_gemm_kernel() == kern   # an image never changes the selection
+    finally:
+        lib.mixq_debug_set_gemm_variant(880)
+    A32 = np.concatenate([A] * 4)[:32]
+    assert_prefill_parity(oracle, layer(torch.from_numpy(A32).to("cuda:0")).cpu().numpy(), A32, p, f"weight image {N}x{K}")
+    # the image follows the weight POINTER: rewriting the weights without re-registering would stream stale bytes, so load() re-registers
+    A2, p2, _ = _layer(oracle, N, K, seed=N + K + 1)
+    layer.load(p2)
+    assert layer.weight_image is not None
+    x = torch.from_numpy(A2[:32]).to("cuda:0")
+    got = layer(x).cpu().numpy()
+    assert_prefill_parity(oracle, got, A2[:32], p2, f"weight image after reload {N}x{K}")
+    layer.prepare_decode_batches(False)
+    assert layer.weight_image is None
+    assert np.array_equal(layer(x).cpu().numpy().view(np.uint16), got.view(np.uint16))
+
+
+def test_graph_replay_and_the_mixlib_flavour(oracle):
+    """HIP-graph capture bakes the image pointer in; MixLinear_GEMM (P-flavour, one-call forward) picks its own image up."""
+    from mixq_tensorrt_llm_amd import mixlinear
+    A, p, layer = _layer(oracle, 4096, 1024, seed=9)
+    x = torch.from_numpy(A[:24]).to("cuda:0")
+    want = layer(x).clone()
+    layer.prepare_decode_batches()
+    gr = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        layer(x)
+        s.synchronize()
+        with torch.cuda.graph(gr, stream=s):
+            out = layer(x)
+    for _ in range(3):
+        gr.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    layer.prepare_decode_batches(False)
+    # P-flavour
+    rng = np.random.default_rng(4)
+    Wf = torch.from_numpy((rng.standard_normal((2048, 1024)) * 0.02).astype(np.float16))
+    cache = mixlinear.MixLibCache(inputdim=64, device="cuda:0")
+    lin = mixlinear.MixLinear_GEMM.from_linear(Wf, None, bit=8, cache=cache, dev="cuda:0")
+    lin.ind = torch.from_numpy(rng.permutation(1024)[:128].astype(np.int32)).to("cuda:0")
+    lin.weight_cache = mixlinear.dequant_weight_columns(lin.q_weight, lin.scale_col, lin.ind)
+    lin.add_outliers = False
+    xa = torch.from_numpy(A[:40, :1024].copy()).to("cuda:0")
+    y0 = lin.forward(xa.clone(), cache, True).clone()
+    lin.prepare_decode_batches()
+    y1 = lin.forward(xa.clone(), cache, True)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    lin.prepare_decode_batches(False)
