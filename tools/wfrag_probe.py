@@ -29,6 +29,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", default="4096 4096;12288 4096;11008 4096;4096 11008")
     ap.add_argument("--Ms", default="8,32")
+    ap.add_argument("--combos", default="883;881;882;880", help="';'-separated knob lists, e.g. '880;880,896' (896 = two feature tiles per workgroup)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.load()
@@ -65,8 +66,11 @@ def main():
                 assert lib.mixq_gemm_mixed_layout(p(q), p(ws), p(sA), p(sW), p(fpA), p(fpW), p(out), M, N, K, O, lay, None, 0, st) == 0
 
             cells, ref = [], None
-            for knob, ws in ((883, rows), (881, rows), (882, rows), (880, rows)):
-                lib.mixq_debug_set_gemm_variant(knob)
+            for combo in a.combos.split(";"):
+                knob, ws = combo, rows
+                lib.mixq_debug_reset()
+                for k in combo.split(","):
+                    lib.mixq_debug_set_gemm_variant(int(k))
                 st0 = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
                 out.zero_()
                 op(st0, ws[0])
@@ -83,7 +87,7 @@ def main():
                     turn[0] += 1
                 tw, tc = bench.graph_time_us(warm, dev), bench.graph_time_us(cold, dev)
                 cells.append(f"[{knob}{'' if same else ' MISMATCH'}] {tw:5.2f}/{tc:5.2f}")
-            lib.mixq_debug_set_gemm_variant(880)
+            lib.mixq_debug_reset()
             print(f"M={M:3d} N={N:6d} K={K:6d} operator warm/cold us: " + "  ".join(cells) + f"   [{lib.mixq_debug_last_gemm_kernel().decode()}]", flush=True)
         for w in rows:
             assert lib.mixq_weight_image_unregister(p(w)) == 0
