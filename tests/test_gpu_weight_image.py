@@ -37,9 +37,9 @@ def test_image_is_the_documented_layout_and_shapes_without_one_are_refused():
         mixlib.WeightImage(torch.zeros((24, 64), dtype=torch.int8, device="cuda:0"))
 
 
-@pytest.mark.parametrize("N,K", [(4096, 4096), (5120, 5120), (12288, 1024), (512, 8192), (272, 704)])
+@pytest.mark.parametrize("N,K", [(4096, 4096), (5120, 5120), (4816, 1024), (12288, 1024), (512, 8192), (272, 704)])
 def test_registered_calls_are_bit_identical(oracle, N, K):
-    """5 .. 64 rows: one to four 16-row tiles, 16 and 32 features per workgroup (5120 x 5120), shapes the skinny GEMM does not serve
+    """5 .. 64 rows: one to four 16-row tiles, 16 and 32 features per workgroup (5120 x 5120; 4816 = 301 feature tiles: the last workgroup's second tile does not exist), shapes the skinny GEMM does not serve
     (the image is then simply not read), K with a ragged last k-step (704: no image exists), both load policies."""
     from mixq_tensorrt_llm_amd import _lib
     lib = _lib.load()
