@@ -685,8 +685,19 @@ bool gemm_takes_skinny(const GemmParams& p, int epi)
     // long K: the small tiles with K split over workgroups -- unless the image is there, N / 16 workgroups fill the chip and K is
     // not longer than 12288 (operator us, K split vs skinny on the image: 4096 x 11008 at 32 / 48 rows 20.9 / 21.4 vs 17.6 / 20.0,
     // 8192 x 8192 at 32 22.4 vs 19.9; 3584 x 18944 25.6 vs 36.9 and 1024 x 28672 24.2 vs 50.0 stay with the K split)
+    // (round 4, re-fitted on COLD weights -- a model's decode step never finds a layer's weights cache-resident --
+    //  profiles/r04_decode_batch_longk_probe.txt, operator us, small-tile K split vs skinny on the qA image, 32 rows: 1280 x 8192 16.8 / 15.1,
+    //  2048 x 8192 17.0 / 15.1, 3584 x 8192 18.6 / 16.2, 1024 x 8192 16.3 / 14.4; beyond K = 8192 the K split stays (5120 x 13824 32.9 /
+    //  35.0, 8192 x 16384 41.2 / 47.5, 3584 x 18944 29.8 / 39.7, 1024 x 28672 27.9 / 52.1) -- UNLESS the weight has a registered image
+    //  (gemm_skinny_kernels.hip), which the skinny kernel streams 15-20 % faster: 5120 x 13824 27.8, 8192 x 16384 37.2, 4096 x 16384 29.2
+    //  -> 24.1, 2560 x 12288 21.6 -> 18.2, 512 x 8192 15.8 -> 12.5; at 48 rows 3584 x 8192 19.7 -> 17.0, 1280 x 8192 16.7 -> 16.0.)
+    const bool img = frag && p.B != nullptr && find_weight_image(p.B, p.N, p.K) != nullptr;
+    const int c16 = 16 * num_cus();
+    const bool skinny_on_image = frag && ((p.N >= c16 && p.K <= 12288) || (p.M <= 32 && p.N >= 1024 && p.K <= 8192) ||
+                                          (img && p.M <= 32 && p.N >= 512 && p.K <= 16384) ||
+                                          (img && p.M <= 48 && p.N >= 1024 && p.N <= c16 && p.K <= 12288));
     const bool xsplit_wins = epi != EPI_INT32 && p.splitk_ws != nullptr && p.K >= 8192 && gemm_xsplit_factor(p.M, p.N, p.K) != 0 &&
-                             !(frag && p.N >= 16 * num_cus() && p.K <= 12288);
+                             !skinny_on_image;
     return gemm_variant() != 1 && !xsplit_wins && gemm_skinny_supported(p) &&
            (p.M <= 16 || (p.M <= 32 && (p.N <= 12288 || g_skinny_wide.load() != 0)) ||
             (frag && ((p.M <= 48 && p.N <= 12288) || (p.M <= 64 && p.N <= 6144))) || (p.M <= 64 && g_skinny_wide.load() == 2));

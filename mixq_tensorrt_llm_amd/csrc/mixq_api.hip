@@ -705,7 +705,7 @@ int mixq_gemm_mixed_layout(const int8_t* qA, const int8_t* W, const void* sA, co
     if (qa_layout == MIXQ_QA_FRAGMENT_MAJOR) {
         if (O > kNumOutliers || M <= 0 || N <= 0 || K <= 0) return MIXQ_E_SHAPE;
         mixq::GemmParams probe{};
-        probe.M = M, probe.N = N, probe.K = K, probe.O = O, probe.a_frag = 1;
+        probe.M = M, probe.N = N, probe.K = K, probe.O = O, probe.a_frag = 1, probe.B = W;
         probe.splitk_ws = (scratch && scratch_bytes >= gemm_scratch_bytes(M, N, K) && gemm_scratch_bytes(M, N, K)) ? scratch : nullptr;
         if (!mixq::gemm_takes_skinny(probe, mixq::EPI_DEQUANT)) return MIXQ_E_SHAPE; // (the image has ONE reader)
     }
@@ -876,6 +876,7 @@ static int enqueue_impl(const mixq_handle* h, const mixq_tensor_desc* inputDesc,
             mixq::GemmParams probe{};
             probe.M = (int)M, probe.N = (int)N, probe.K = (int)K, probe.O = kNumOutliers;
             probe.splitk_ws = scratch;
+            probe.B = W;      // (a registered weight image widens the skinny kernel's range: the probe must see the same pointer the launch will)
             probe.a_frag = 1; // ("if the quantiser writes the fragment-major image, does the skinny kernel take the problem?")
             frag = mixq::gemm_takes_skinny(probe, mixq::EPI_DEQUANT) ? 1 : 0;
         }
