@@ -698,9 +698,17 @@ bool gemm_takes_skinny(const GemmParams& p, int epi)
                                           (img && p.M <= 48 && p.N >= 1024 && p.N <= c16 && p.K <= 12288));
     const bool xsplit_wins = epi != EPI_INT32 && p.splitk_ws != nullptr && p.K >= 8192 && gemm_xsplit_factor(p.M, p.N, p.K) != 0 &&
                              !skinny_on_image;
+    // 33..64 rows (fragment-major qA image only), round 4 on COLD weights (profiles/r04_decode_batch_k4096_probe.txt, operator us, tiles vs
+    // skinny / skinny on a registered weight image): 12288 x 4096 at 48 rows 22.7 vs 25.1 / 21.7, 11008 x 4096 22.4 / 24.4 / 20.6,
+    // 8192 x 4096 19.1 / 18.6 / 16.0, 6144 x 4096 at 64 rows 19.1 / 20.7 / 18.5, 5120 x 5120 (32 features per workgroup) at 48 rows
+    // 22.0 / 23.5 / 19.7, at 64 rows 22.2 / 26.0 / 23.0, 4096 x 4096 at 64 rows 17.9 / 14.4 / 13.2.  (Round 3 had fitted this warm:
+    // 48 rows up to N = 12288, 64 rows up to 6144 whatever the weight's layout.)
+    const bool one_tile = skinny_feature_tiles(p.M, p.N, p.K) == 1;
+    const bool rows_33_64 = frag && (img ? ((p.M <= 48 && p.N <= 12288) || (p.M <= 64 && p.N <= 6144 && one_tile))
+                                         : ((p.M <= 48 && p.N <= 8192 && one_tile) || (p.M <= 64 && p.N <= 4096)));
     return gemm_variant() != 1 && !xsplit_wins && gemm_skinny_supported(p) &&
-           (p.M <= 16 || (p.M <= 32 && (p.N <= 12288 || g_skinny_wide.load() != 0)) ||
-            (frag && ((p.M <= 48 && p.N <= 12288) || (p.M <= 64 && p.N <= 6144))) || (p.M <= 64 && g_skinny_wide.load() == 2));
+           (p.M <= 16 || (p.M <= 32 && (p.N <= 12288 || g_skinny_wide.load() != 0)) || rows_33_64 ||
+            (p.M <= 64 && g_skinny_wide.load() == 2));
     // (33..64 rows, fragment-major image only, operator us, tiles vs skinny: 4096 x 4096 at 40 / 48 / 64 rows 13.4 / 13.5 / 13.5 vs
     //  10.3 / 10.3 / 11.9; 3584 x 3584 at 64 12.7 / 11.1; 8192 x 4096 at 48 15.9 / 14.5; 12288 x 4096 at 48 19.2 / 18.7, at 64 19.9 / 22.4)
     // (17..32 rows, round 3 with the fragment-major qA image, operator us, tiles vs skinny: N = 8192 15.9 / 12.8, 11008 17.6 / 16.0,

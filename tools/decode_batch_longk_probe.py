@@ -24,12 +24,14 @@ CASES = [(1024, 28672), (1280, 8192), (3584, 18944), (3584, 8192), (4096, 11008)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--Ms", default="8,16,32,48,64")
+    ap.add_argument("--cases", default="", help='"N K;N K;..." instead of the built-in long-K list')
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.load()
     gen = torch.Generator(device=dev).manual_seed(0)
     p = lambda t: ctypes.c_void_p(t.data_ptr())
-    for N, K in CASES:
+    cases = [tuple(int(x) for x in c.split()) for c in a.cases.split(";") if c.strip()] or CASES
+    for N, K in cases:
         t = bench.synth_layer(N, K, dev, gen)
         copies = (320 << 20) // (N * K) + 2
         ws = [t["weight"]] + [t["weight"].clone() for _ in range(copies - 1)]
