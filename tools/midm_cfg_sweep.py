@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--secs", type=float, default=0.25)
     ap.add_argument("--Ms", default="96,128,192,256,384,512,1024")
     ap.add_argument("--shapes", default="12288 4096;11008 4096;4096 11008;4096 4096")
+    ap.add_argument("--cold", action="store_true", help="cycle through > 320 MiB of weight copies: every launch streams its weights from HBM")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.load()
@@ -33,6 +34,8 @@ def main():
     for shape in a.shapes.split(";"):
         N, K = (int(x) for x in shape.split())
         W = torch.randint(-127, 128, (N, K), dtype=torch.int8, device=dev, generator=g)
+        Ws = [W] + ([W.clone() for _ in range((320 << 20) // (N * K) + 1)] if a.cold else [])
+        turn = [0]
         sW = (torch.rand(N, device=dev, generator=g) * 4e-4 + 4e-4).to(torch.float16)
         fpW = (torch.randn((N, O), device=dev, generator=g) * 0.02).to(torch.float16)
         for M in [int(x) for x in a.Ms.split(",")]:
@@ -48,8 +51,11 @@ def main():
                 nscr = int(lib.mixq_gemm_scratch_size(M, N, K))
                 if name in ("s2", "s4", "s8") and nscr == 0:
                     continue
-                fn = lambda: lib.mixq_gemm_mixed_scratch(p(qA), p(W), p(sA), p(sW), p(fpA), p(fpW), p(out), M, N, K, O,
-                                                         p(scr) if nscr else None, nscr, st)
+                def fn():
+                    w = Ws[turn[0] % len(Ws)]
+                    turn[0] += 1
+                    return lib.mixq_gemm_mixed_scratch(p(qA), p(w), p(sA), p(sW), p(fpA), p(fpW), p(out), M, N, K, O,
+                                                       p(scr) if nscr else None, nscr, st)
                 out.zero_()
                 if fn() != 0:
                     continue
