@@ -927,8 +927,8 @@ void set_splitk_force(int v) { g_splitk_force.store(v); }
 // Automatic choice, from tools/splitk_select_sweep.py on MI355X.
 //  * tiles <= CUs / 2 (one partial wave of tiles): with the tiles on (1/4, 1/2] of the CUs two workgroups per tile
 //    always pay; on at most 1/4 of the CUs four pay once K is long enough to amortise the exchange (3 x 64 KiB per
-//    workgroup each way) and there are enough tiles for the small-tile kernels to be L2-bound; rows that fill less
-//    than one 256-row tile are better served by the small-tile kernels.
+//    workgroup each way) and there are enough tiles for the small-tile kernels to be L2-bound; 129..255 rows take the
+//    4- and 8-way forms of one 256-row tile row (cold weights: see below), up to 128 rows the small-tile kernels.
 //  * tiles > CUs (whole waves + a partial one): the whole waves run one workgroup per tile ("solo"), the tiles of the
 //    last wave are split if they cover at most half of the CUs -- instead of a last wave that takes a full tile time
 //    on a fraction of the chip.
@@ -943,7 +943,7 @@ SplitPlan gemm_splitk_plan(int M, int N, int K)
     const int cus = num_cus() & ~7;
     if (tiles > cus) { // hybrid
         const int tail = tiles % cus, rounds = tiles / cus;
-        if (tail == 0 || 2 * tail > cus || (force < 0 && M < 256)) return none; // (mixq_workspace_size reserves from 256 rows)
+        if (tail == 0 || 2 * tail > cus || (force < 0 && M < 256)) return none; // (under 256 rows: N > 65536, not measured)
         // Round 4: re-fitted in STEADY STATE (tools/splitk_select_sweep.py --hybrid --secs 0.35, profiles/r04_hybrid_sweep.txt: the
         // power-capped clock a prefill runs at; round 1's 100-launch cells read the boost clock of an idle chip and over-sold the
         // split).  What a split tail saves shrinks with the number of whole rounds before it -- by then the CUs are out of step
@@ -969,15 +969,30 @@ SplitPlan gemm_splitk_plan(int M, int N, int K)
     if (force == 8) return 8 * tiles <= cus && nk >= 32 ? SplitPlan{8, 0} : none;
     if (force == 4) return 4 * tiles <= cus && nk >= 16 ? SplitPlan{4, 0} : none;
     if (force == 2) return 2 * tiles <= cus && nk >= 8 ? SplitPlan{2, 0} : none;
-    if (M < 256 || 2 * tiles > cus) return none;
-    if (4 * tiles > cus) return nk >= 16 ? SplitPlan{2, 0} : none;
+    if (2 * tiles > cus) return none;
+    // Round 4, re-fitted on COLD weights (tools/midm_cfg_sweep.py --cold --only auto,s2,s4,s8, profiles/r04_splitk_cold_fit.txt: the
+    // weights cycle through > 320 MiB of copies -- no layer of a model finds its weights cache-resident -- where the small-tile forms,
+    // whose workgroups re-read the weights from L2, lose more than the 256 x 256 tiles do):
+    //  * 129..255 rows take the plan of one 256-row tile row for the 4- and 8-way forms (us, small tiles vs split, 192 rows:
+    //    3584 x 18944 57.7 / 42.8, 4096 x 16384 48.6 / 37.5, 8192 x 28672 111 / 73, 6144 x 12288 49.4 / 39.0, 5120 x 13824 44.3 / 38.9;
+    //    ties within 2 % at 4096 x 11008, 8192 x 8192, 10240 x 8192; at 224 rows 10240 x 8192 56.2 / 38.2);
+    //  * 8 ways with exactly 1/8 of the CUs from K = 11008 (4096 x 11008 at 512 rows 4 / 8 ways 45.3 / 42.5, 4096 x 16384 54.7 / 48.7;
+    //    warm the 4-way form is ahead there), with 20..31 tiles from K = 8192 unless the 64 x 64 tiles still fit one wave of the chip
+    //    (5120 x 8192 at 256 rows 39.0 -> 29.4, 2560 x 8192 at 512 rows 36.5 -> 30.0, 3584 x 8192 at 512 37.1 -> 33.6; with one wave of
+    //    64 x 64 tiles 2560 x 8192 at 384 rows 27.5 vs 30.4, 5120 x 8192 at 192 rows 28.4 vs 29.1: then from K = 12800).
+    const bool tall = M >= 256; // (the 2-way forms were fitted from 256 rows on only)
+    if (4 * tiles > cus) return tall && nk >= 16 ? SplitPlan{2, 0} : none;
     if (8 * tiles <= cus) { // at most 1/8 of the CUs: 8 ways once K amortises 7 x 32 KiB each way per workgroup
-        const bool pays = 8 * tiles == cus ? nk >= 192 : 64 * tiles >= 3 * cus ? nk >= 86 : 32 * tiles >= cus && nk >= 160;
+        const int64_t wg64 = (int64_t)((M + 63) / 64) * ((N + 63) / 64);
+        const bool pays = 8 * tiles == cus        ? nk >= 86
+                          : 64 * tiles >= 5 * cus ? nk >= (wg64 <= cus ? 100 : 64)
+                          : 64 * tiles >= 3 * cus ? nk >= 86
+                                                  : 32 * tiles >= cus && nk >= 160;
         if (pays) return SplitPlan{8, 0};
     }
     if (nk >= 64 && 8 * tiles >= cus) return SplitPlan{4, 0};
     if (nk >= 96 && 64 * tiles >= 5 * cus) return SplitPlan{4, 0}; // 20..31 tiles pay with K >= 12288 (-7..-27 %)
-    if (nk >= 40 && 16 * tiles >= 3 * cus) return SplitPlan{2, 0};
+    if (tall && nk >= 40 && 16 * tiles >= 3 * cus) return SplitPlan{2, 0};
     return none;
 }
 

@@ -288,12 +288,12 @@ static size_t qa_region_bytes(int64_t M, int64_t K)
 }
 
 // Exchange scratch ONE mixq_enqueue call with exactly M rows carves behind fpA (the K splits over workgroups of
-// gemm_pp_kernels.hip / gemm_kernels.hip): the 256x256 form's from 256 rows on, the small-tile form's below that.
+// gemm_pp_kernels.hip / gemm_kernels.hip): the 256x256 form's from 129 rows on where its plan applies, else the small-tile form's.
 // enqueue_impl and the workspace bound below both go through this function, so they cannot disagree.
 static size_t enqueue_scratch_bytes(int64_t M, int64_t N, int64_t K)
 {
     if (M <= 4 || N <= 0 || K <= 0 || M > INT32_MAX || N > INT32_MAX || K > INT32_MAX) return 0;
-    if (M >= 256) {
+    if (M > 128) {
         const size_t a = mixq::gemm_splitk_workspace_size((int)M, (int)N, (int)K);
         if (a) return a;
     }

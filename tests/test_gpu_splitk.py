@@ -41,7 +41,8 @@ def operands(M, N, K, O, seed):
 SHAPES = [(300, 528, 2064),     # ragged M and N, partial last K slice, 2 x 3 tiles
           (512, 1024, 2048),    # whole tiles, 16 slices (4 per workgroup in the 4-way form)
           (257, 272, 4224),     # one row / 16 columns into the second tile, odd slice count
-          (1100, 1536, 2176)]   # 5 x 6 tiles: 8 groups of XCDs unevenly filled
+          (1100, 1536, 2176),   # 5 x 6 tiles: 8 groups of XCDs unevenly filled
+          (200, 784, 2304)]     # fewer rows than one 256-row tile (129..255 rows take the 4- / 8-way plan since round 4)
 
 
 @pytest.mark.parametrize("factor", [2, 4, 8])
@@ -148,6 +149,38 @@ def test_split_form_through_enqueue_matches_the_oracle(oracle, lib, factor):
     got = run_enqueue(A, pk)
     assert np.array_equal(bits(got), bits(plain))
     assert_prefill_parity(oracle, got, A, pk, f"K split {factor} ways through enqueue")
+
+
+@pytest.mark.parametrize("M,N,K,ways", [(192, 3584, 18944, 8),    # Qwen2-7B down projection, decode batch of 192: 14 tiles, 148 slices
+                                        (144, 8192, 8192, 4),     # 32 tiles = 1/8 of the CUs, K = 8192: 4 ways
+                                        (224, 5120, 8192, 8),     # 20 tiles, 4 x 80 tiles of 64 x 64 = more than one wave: 8 ways
+                                        (192, 5120, 8192, 0),     # ... 3 x 80 fit one wave: the small tiles keep it
+                                        (192, 12288, 4096, 0),    # short K: never
+                                        (128, 3584, 18944, 0)])   # up to 128 rows: the small-tile forms
+def test_rows_129_to_255_take_the_plan_of_one_tile_row(oracle, lib, M, N, K, ways):
+    """Round 4 (cold-weight fit, profiles/r04_splitk_cold_fit.txt): a decode batch of 129..255 rows on a long-K linear runs the 256 x 256
+    tiles with K split 4 / 8 ways, bit-identical to the one-workgroup-per-tile forms, and through mixq_enqueue equal to the oracle."""
+    from test_gpu_parity import bits, run_enqueue
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    if cus != 256:
+        pytest.skip("plan thresholds are written for 256 CUs")
+    lib.mixq_debug_set_gemm_variant(79)
+    tiles = (N + 255) // 256
+    n = lib.mixq_gemm_scratch_size(M, N, K)
+    if ways:
+        assert n == 16384 + tiles * ways * 262144
+        assert lib.mixq_enqueue_scratch_size(M, N, K) == n
+    else:
+        assert n < 16384 + tiles * 2 * 262144     # nothing, or the small-tile form's 16-KiB slots
+    A, W, act = make_layer(M, N, K, seed=M + N)
+    pk = oracle.pack_linear_weights(W, act)
+    got = run_enqueue(A, pk)
+    kern = lib.mixq_debug_last_gemm_kernel().decode()
+    assert ("SPLITK" in kern) == bool(ways), kern
+    lib.mixq_debug_set_gemm_variant(70)
+    plain = run_enqueue(A, pk)
+    assert np.array_equal(bits(got), bits(plain))
+    assert_prefill_parity(oracle, got, A, pk, f"{M} rows on {N} x {K}")
 
 
 def test_automatic_choice_and_graph_replay(lib):
