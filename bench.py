@@ -528,6 +528,7 @@ def main():
                          "is, a run on N > 1 GPUs also reports the north-star layout (tp = N) in the `tp` object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode-step", action="store_true", help="skip the decode_step object (profiling runs: 3 graphs of 96 calls)")
+    ap.add_argument("--no-small-m", action="store_true", help="skip the small_m object (counter passes: thousands of short launches)")
     ap.add_argument("--no-sweeps", action="store_true", help="skip the chunk_sweep and configs objects (profiling runs)")
     ap.add_argument("--mid-m", action="store_true",
                     help="add the informational 1024 / 2048-token prefill points (K split over workgroups) to the JSON line")
@@ -763,7 +764,8 @@ def main():
                 max(elapsed - gemm_ms / 1e3, 1e-9) / n_launch),
         }
         try:  # informational small-M points (HBM-bound end of the operator); never part of `value`
-            res["small_m"] = small_m_points(lib, TensorDesc, dev, gen, st_ptr)
+            if not args.no_small_m:
+                res["small_m"] = small_m_points(lib, TensorDesc, dev, gen, st_ptr)
         except Exception as e:  # noqa: BLE001
             res["small_m"] = {"error": repr(e)}
         if world == 1 and not args.no_decode_step:

@@ -498,18 +498,6 @@ static hipError_t launch_epi(const GemmParams& p, hipStream_t st)
     case 21: return launch_cfg<64, 128, 2, 4, EPI, 2, 2>(p, st);
     case 22: return launch_cfg<32, 64, 1, 2, EPI, 2, 4, true>(p, st);
     case 23: return launch_cfg<64, 64, 2, 2, EPI, 2, 4, true>(p, st);
-    case 24: case 25: case 26: case 27: { // EXPERIMENT (R4.13): K split over workgroups on larger tiles; factor = the forced xsplit knob
-        const int f = g_xsplit_force.load();
-        if (EPI == EPI_INT32 || f < 2 || p.splitk_ws == nullptr) return hipErrorInvalidValue;
-        GemmParams q = p;
-        q.xsplit = f;
-        switch (g_force_cfg.load()) {
-        case 24: return launch_cfg<128, 128, 2, 4, EPI, 2, 1, true, true>(q, st);
-        case 25: return launch_cfg<128, 128, 2, 4, EPI, 2, 2, false, true>(q, st);
-        case 26: return launch_cfg<128, 64, 4, 2, EPI, 2, 2, true, true>(q, st);
-        default: return launch_cfg<64, 128, 2, 4, EPI, 2, 2, true, true>(q, st);
-        }
-    }
     default: break;
     }
     // Measured choice (tools/cfg_sweep.sh, M = 32..1024 on 12288x4096, 4096x11008, 4096x4096): small problems are

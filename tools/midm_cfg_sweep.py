@@ -32,11 +32,8 @@ def main():
     scr = torch.zeros(int(lib.mixq_gemm_scratch_bound()) + (1 << 20), dtype=torch.uint8, device=dev)
     variants = [("auto", [0, 79, 69])] + [(f"c{i}", [70, 60, 10 + i]) for i in range(24)] + \
                [("pp128", [70, 60, 5]), ("pp256", [70, 60, 2]), ("s2", [0, 72]), ("s4", [0, 74]), ("s8", [0, 78])]
-    # experiment R4.13: larger tiles with K split over f workgroups (x<cfg>_<f>): 24 = 128x128, 25 = 128x128 + 2 K groups, 26 = 128x64, 27 = 64x128
-    xknob = {2: 62, 4: 64, 8: 68, 16: 66}
-    variants += [(f"x{c}_{f}", [70, xknob[f], 10 + c]) for c in (24, 25, 26, 27) for f in (2, 4, 8)]
     if a.only:
-        variants = [v for v in variants + [("plain", [0, 70])] if v[0] in a.only.split(",") or (v[0][0] == "x" and "x" in a.only.split(","))]   # plain = automatic with the 256 x 256 K split off
+        variants = [v for v in variants + [("plain", [0, 70])] if v[0] in a.only.split(",")]   # plain = automatic with the 256 x 256 K split off
     for shape in a.shapes.split(";"):
         N, K = (int(x) for x in shape.split())
         W = torch.randint(-127, 128, (N, K), dtype=torch.int8, device=dev, generator=g)
@@ -57,13 +54,6 @@ def main():
                 nscr = int(lib.mixq_gemm_scratch_size(M, N, K))
                 if name in ("s2", "s4", "s8") and nscr == 0:
                     continue
-                if name.startswith("x"):   # experimental forms: the whole scratch (the library's own size query does not know them)
-                    c, f = (int(t) for t in name[1:].split("_"))
-                    bm, bn = {24: (128, 128), 25: (128, 128), 26: (128, 64), 27: (64, 128)}[c]
-                    tiles = ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
-                    if tiles * f > 512 or tiles > 4096 or 16384 + tiles * f * bm * bn * 4 > scr.numel():
-                        continue
-                    nscr = scr.numel()
                 def fn():
                     w = Ws[turn[0] % len(Ws)]
                     turn[0] += 1

@@ -5,8 +5,12 @@ set -u
 OUT="$PWD/gpurun_out/pmc_bench"; rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/$c" -o p -- \
-      python "$OLDPWD/bench.py" --tokens 65536 --steps 1 --warmup 0 --no-cpu-baseline --no-decode-step --no-sweeps ) > "$OUT/$c.log" 2>&1
+  for attempt in 1 2; do   # (a counter pass now and then dies at start-up with HSA_STATUS_ERROR_INVALID_PACKET_FORMAT: once more)
+    rm -rf "$OUT/$c"
+    ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/$c" -o p -- \
+        python "$OLDPWD/bench.py" --tokens 65536 --steps 1 --warmup 0 --no-cpu-baseline --no-decode-step --no-sweeps --no-small-m ) > "$OUT/$c.log" 2>&1
+    find "$OUT/$c" -name "*counter_collection.csv" 2>/dev/null | grep -q . && break
+  done
 done
 python - "$OUT" <<'PY' | tee "$OUT/summary.txt"
 import csv, glob, sys, collections
