@@ -4,7 +4,7 @@
 alternative the table chose between (forced through mixq_debug_set_gemm_variant), device-paced (HIP graph of 50 calls).
 
   table (file)                                      alternatives timed
-  gemm_splitk_plan   (csrc/gemm_pp_kernels.hip)     K split over workgroups off (70) | 2 (72) | 4 (74) | 8 (78) | automatic (79)
+  gemm_splitk_plan   (csrc/gemm_pp_kernels.hip)     K split over workgroups off (70) | 2 (72) | 4 (74) | 8 (78) | automatic (79); six more probes on COLD weights
   gemm_pp128_wins    (csrc/gemm_kernels.hip)        128 x 256 tiles (5) | 256 x 256 tiles (2) | automatic (0)
   wo_skinny_pick     (csrc/w8a16_gemm_kernels.hip)  fpA_intB skinny form automatic (850) | off (851); decode 856 | 857 | 858
   wo_wide_plan       (csrc/w8a16_gemm_kernels.hip)  wide-form tile heights 831..834, K split 86..89 | automatic (80, 85)
@@ -74,16 +74,21 @@ class Int8Problem:
         self.out = torch.empty((M, N), dtype=torch.float16, device=DEV)
         self.scr = torch.zeros(int(LIB.mixq_gemm_scratch_bound()), dtype=torch.uint8, device=DEV)
 
-    def time(self, *ks):
+    def time(self, *ks, cold=False):
         knobs(*ks)
         p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
         M, N, K = self.M, self.N, self.K
+        if cold and not hasattr(self, "Ws"):   # > 320 MiB of copies, one per call in turn: every call streams its weights from HBM
+            self.Ws = [self.W] + [self.W.clone() for _ in range((320 << 20) // (N * K) + 1)]
+        turn = [0]
 
         def run(st):
-            rc = LIB.mixq_gemm_mixed_scratch(p(self.qA), p(self.W), p(self.sA), p(self.sW), p(self.fpA), p(self.fpW),
+            w = self.Ws[turn[0] % len(self.Ws)] if cold else self.W
+            turn[0] += 1
+            rc = LIB.mixq_gemm_mixed_scratch(p(self.qA), p(w), p(self.sA), p(self.sW), p(self.fpA), p(self.fpW),
                                              p(self.out), M, N, K, 128, p(self.scr), self.scr.numel(), st)
             assert rc == 0
-        t = graph_us(run)
+        t = graph_us(run, calls=max(50, len(self.Ws) if cold else 0))
         return t, LIB.mixq_debug_last_gemm_kernel().decode()
 
 
@@ -142,6 +147,17 @@ def main():
             alts[name] = t
         auto, kern = pr.time(79, 69, 0)
         report("gemm_splitk_plan", f"{M}x{N}x{K}", auto, alts)
+        knobs(79, 69, 0)
+        del pr
+    # ---- 1b. the same plan where it was fitted on COLD weights (round 4, notebook R4.13: 129..255 rows, 20..31 tiles from K = 8192) ----
+    splitk_cold = [(192, 3584, 18944), (224, 5120, 8192), (512, 2560, 8192), (192, 6144, 12288), (192, 5120, 8192), (384, 2560, 8192)]
+    for M, N, K in (splitk_cold[::2] if a.quick else splitk_cold):
+        pr = Int8Problem(M, N, K)
+        alts = {}
+        for name, k in (("off", 70), ("s4", 74), ("s8", 78)):
+            alts[name], _ = pr.time(79, 69, 0, k, cold=True)
+        auto, kern = pr.time(79, 69, 0, cold=True)
+        report("splitk_plan (cold)", f"{M}x{N}x{K}", auto, alts)
         knobs(79, 69, 0)
         del pr
     # ---- 2. gemm_pp128_wins -----------------------------------------------------------------------------------------------
