@@ -976,9 +976,11 @@ SplitPlan gemm_splitk_plan(int M, int N, int K)
     //  * 129..255 rows take the plan of one 256-row tile row for the 4- and 8-way forms (us, small tiles vs split, 192 rows:
     //    3584 x 18944 57.7 / 42.8, 4096 x 16384 48.6 / 37.5, 8192 x 28672 111 / 73, 6144 x 12288 49.4 / 39.0, 5120 x 13824 44.3 / 38.9;
     //    ties within 2 % at 4096 x 11008, 8192 x 8192, 10240 x 8192; at 224 rows 10240 x 8192 56.2 / 38.2);
-    //  * 8 ways with 20..31 tiles from K = 8192 unless the 64 x 64 tiles still fit one wave of the chip (5120 x 8192 at 256 rows 39.0 ->
-    //    29.4, 2560 x 8192 at 512 rows 36.5 -> 30.0, 3584 x 8192 at 512 37.1 -> 33.6; with one wave of 64 x 64 tiles 2560 x 8192 at 384
-    //    rows 27.5 vs 30.4, 5120 x 8192 at 192 rows 28.4 vs 29.1: then from K = 12800);
+    //  * 8 ways with 20..24 tiles (at most 3/4 of the CUs busy; 25..31 tiles: from K = 11008 as before, 4 ways below that -- 3584 x 8192 at
+    //    384 / 512 rows = 28 tiles x 8 = 224 workgroups read 32.8 / 33.6 us on one box and 35.4 / 38.6 on another, 4 ways 33.4..34.2 on both,
+    //    no split 34.0 / 37.1) from K = 8192 unless the 64 x 64 tiles still fit one wave of the chip (5120 x 8192 at 256 rows 39.0 -> 29.4,
+    //    2560 x 8192 at 512 rows 36.5 -> 30.0; with one wave of 64 x 64 tiles 2560 x 8192 at 384 rows 27.5 vs 30.4, 5120 x 8192 at 192 rows
+    //    28.4 vs 29.1: then from K = 12800);
     //  * 8 ways on exactly 1/8 of the CUs (8 x 32 = every CU holds one workgroup) from K = 16384 (4096 x 16384 at 384 / 512 rows 4 / 8
     //    ways 53.6 / 48.9, 54.9 / 50.3).  NOT from K = 11008: that launch measured 41.4, 43.6 and 49.8 us on three boxes of the pool
     //    (4 ways: 43.1..43.5 on all of them) -- a launch that needs every CU at once is at the mercy of the slowest one.
@@ -987,13 +989,14 @@ SplitPlan gemm_splitk_plan(int M, int N, int K)
     if (8 * tiles <= cus) { // at most 1/8 of the CUs: 8 ways once K amortises 7 x 32 KiB each way per workgroup
         const int64_t wg64 = (int64_t)((M + 63) / 64) * ((N + 63) / 64);
         const bool pays = 8 * tiles == cus        ? nk >= 128
-                          : 64 * tiles >= 5 * cus ? nk >= (wg64 <= cus ? 100 : 64)
+                          : 64 * tiles >= 5 * cus ? (32 * tiles <= 3 * cus ? nk >= (wg64 <= cus ? 100 : 64) : nk >= 86)
                           : 64 * tiles >= 3 * cus ? nk >= 86
                                                   : 32 * tiles >= cus && nk >= 160;
         if (pays) return SplitPlan{8, 0};
     }
     if (nk >= 64 && 8 * tiles >= cus) return SplitPlan{4, 0};
     if (nk >= 96 && 64 * tiles >= 5 * cus) return SplitPlan{4, 0}; // 20..31 tiles pay with K >= 12288 (-7..-27 %)
+    if (nk >= 64 && 32 * tiles > 3 * cus && (int64_t)((M + 63) / 64) * ((N + 63) / 64) > cus) return SplitPlan{4, 0}; // 25..31 tiles, K = 8192 (above)
     if (tall && nk >= 40 && 16 * tiles >= 3 * cus) return SplitPlan{2, 0};
     return none;
 }
