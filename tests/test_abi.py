@@ -146,6 +146,27 @@ def test_workspace_sized_once_covers_every_smaller_m(lib, N, K, maxM):
     lib.mixq_destroy(h)
 
 
+def test_workspace_bound_on_random_shapes_up_to_512_rows(lib):
+    """Round 4: decode batches of 129..255 rows take the K split of the 256 x 256 tiles too; the plan sees M through ceil(M / 64 | 128 | 256)
+    and, inside gemm_pp128_wins, through M itself -- 120 seeded random (N, K, maxM): the workspace sized once covers every smaller M."""
+    import random
+    rng = random.Random(5)
+    h = lib.mixq_create(0, 0, 0)
+
+    def up(v, a=128):
+        return (v + a - 1) // a * a
+
+    for _ in range(120):
+        N, K = rng.randrange(16, 2000) * 16, rng.randrange(8, 1900) * 16
+        maxM = rng.choice([130, 160, 191, 192, 200, 255, 256, 300, 384, 512])
+        ws = lib.mixq_workspace_size(h, maxM, N, K)
+        for m in range(5, maxM + 1):
+            qa = max(m * K, up(m, 16) * up(K, 64)) if m <= 64 else m * K
+            carve = 127 + up(qa) + up(2 * m) + up(2 * 128 * m) + lib.mixq_enqueue_scratch_size(m, N, K)
+            assert carve <= ws, (N, K, maxM, m)
+    lib.mixq_destroy(h)
+
+
 def test_scratch_plan_is_not_monotone_in_m(lib):
     """The shapes ADVICE r2 named: M = 257 needs a K-split scratch that M = 1024 / 2048 does not."""
     assert lib.mixq_enqueue_scratch_size(257, 7168, 7168) > 0 == lib.mixq_enqueue_scratch_size(1024, 7168, 7168) or \
