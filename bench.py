@@ -925,11 +925,19 @@ def main():
         wd.cancel()
     if rank == 0 and tp_obj is not None:
         res["tp"] = tp_obj
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
     if rank == 0:
-        emit(res)
+        emit(res)   # the line first: a teardown that hangs (a rank that died inside the tp = N leg) must not cost it
+    if world > 1:
+        import threading
+        td = threading.Timer(60.0, lambda: os._exit(0))
+        td.daemon = True
+        td.start()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception:  # noqa: BLE001 -- nothing left to report
+            pass
+        td.cancel()
 
 
 if __name__ == "__main__":
