@@ -871,6 +871,9 @@ def main():
         wd = threading.Timer(300.0, bail)   # (a healthy leg takes well under a minute; a hung collective must not cost the line)
         wd.daemon = True
         wd.start()
+        if rank == 0:   # ... and neither must a leg that takes the process down (a GPU memory fault ends in abort()): the library writes this line then
+            lib.mixq_debug_arm_crash_line(json_fd, (json.dumps(dict(res, tp={
+                "tp": world, "error": "the process received SIGABRT / SIGSEGV / SIGBUS inside the tp = N leg"})) + "\n").encode())
         try:
             acts = model.acts
             model.close()
@@ -923,6 +926,8 @@ def main():
         except Exception as e:  # noqa: BLE001 -- the main measurement must survive
             tp_obj = {"tp": world, "error": repr(e)}
         wd.cancel()
+        if rank == 0:
+            lib.mixq_debug_arm_crash_line(-1, None)
     if rank == 0 and tp_obj is not None:
         res["tp"] = tp_obj
     if rank == 0:

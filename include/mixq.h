@@ -401,6 +401,10 @@ MIXQ_API int mixq_unprocess_weights_int8(int8_t* row_major, const uint8_t* prepr
  * mixq_debug_knobs_enabled() says which kind of process this is.  mixq_debug_reset() and the reporting entries always work. */
 MIXQ_API int mixq_debug_knobs_enabled(void);
 MIXQ_API void mixq_debug_reset(void);
+/* Measurement harness support (bench.py, the tp = N leg on a node nobody has run it on yet): keep a copy of `line` (at most 1 MiB) and, should
+ * the process receive SIGABRT / SIGSEGV / SIGBUS (a GPU memory fault ends in the runtime's abort()), write it to `fd` and _exit(0) instead
+ * of dying silent.  line == NULL disarms (default handlers back).  Returns 0, or -1 if the line does not fit.  Touches no operator state. */
+MIXQ_API int mixq_debug_arm_crash_line(int fd, const char* line);
 /* Test / measurement knob: main-loop schedule of the fused GEMM.  0 = auto (default), 1 = 2-barrier double-buffered
  * kernel only, 2 = 256x256 ping-pong kernel for every M > 4.  Results are identical bit for bit in all modes. */
 MIXQ_API void mixq_debug_set_gemm_variant(int variant);

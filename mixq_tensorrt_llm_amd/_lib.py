@@ -144,6 +144,7 @@ SIGNATURES = {
     "mixq_debug_set_gemm_variant": (None, [_i]),
     "mixq_debug_reset": (None, []),
     "mixq_debug_knobs_enabled": (_i, []),
+    "mixq_debug_arm_crash_line": (_i, [_i, ctypes.c_char_p]),
     "mixq_debug_set_stamp_buffer": (None, [_vp]),
     "mixq_debug_set_quant_stamp_buffer": (None, [_vp]),
     "mixq_debug_last_gemm_kernel": (ctypes.c_char_p, []),

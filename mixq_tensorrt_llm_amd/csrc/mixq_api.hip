@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <csignal>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -13,6 +14,7 @@
 #include <string>
 #include <unordered_set>
 #include <vector>
+#include <unistd.h>
 
 #include "mixq_launch.h"
 
@@ -144,6 +146,36 @@ void mixq_debug_reset(void)
                   80 /* fpA_intB forms automatic */, 85, 840, 843, 848 /* non-temporal loads of large weights on */, 850, 858, 891 /* fragment-major qA on */, 893 /* skinny range: the rule */,
                   894 /* feature tiles automatic */, 880 /* skinny-GEMM weight image off */})
         mixq::set_gemm_variant(v);
+}
+
+// ---- measurement harness support: a last line for a process that is about to die on a signal (include/mixq.h) ----------------------
+static char g_crash_line[1 << 20];
+static volatile size_t g_crash_len = 0;
+static volatile int g_crash_fd = -1;
+static void crash_line_handler(int)
+{
+    if (g_crash_fd >= 0 && g_crash_len) {
+        ssize_t r = write(g_crash_fd, g_crash_line, g_crash_len); // (async-signal-safe)
+        (void)r;
+    }
+    _exit(0);
+}
+int mixq_debug_arm_crash_line(int fd, const char* line)
+{
+    struct sigaction sa;
+    memset(&sa, 0, sizeof(sa));
+    if (line == nullptr) {
+        g_crash_len = 0, g_crash_fd = -1;
+        sa.sa_handler = SIG_DFL;
+    } else {
+        const size_t n = strlen(line);
+        if (n >= sizeof(g_crash_line)) return -1;
+        memcpy(g_crash_line, line, n);
+        g_crash_len = n, g_crash_fd = fd;
+        sa.sa_handler = crash_line_handler;
+    }
+    for (int sig : {SIGABRT, SIGSEGV, SIGBUS}) sigaction(sig, &sa, nullptr);
+    return 0;
 }
 
 const char* mixq_debug_last_gemm_kernel(void) { return mixq::last_gemm_kernel(); }

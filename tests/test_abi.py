@@ -167,6 +167,19 @@ def test_workspace_bound_on_random_shapes_up_to_512_rows(lib):
     lib.mixq_destroy(h)
 
 
+def test_crash_line_is_written_when_the_process_aborts():
+    """bench.py arms this before the tp = N leg: a process that dies on SIGABRT (a GPU memory fault ends in abort()) still prints its line."""
+    import subprocess
+    import sys
+    code = ("import os\nfrom mixq_tensorrt_llm_amd import _lib\nlib = _lib.load()\n"
+            "assert lib.mixq_debug_arm_crash_line(1, b'{\"ok\": 1}\\n') == 0\nos.abort()\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=120)
+    assert r.returncode == 0 and r.stdout == b'{"ok": 1}\n', (r.returncode, r.stdout, r.stderr[-300:])
+    code2 = code.replace("os.abort()", "assert lib.mixq_debug_arm_crash_line(-1, None) == 0\nos.abort()")
+    r = subprocess.run([sys.executable, "-c", code2], capture_output=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=120)
+    assert r.returncode != 0 and r.stdout == b""   # disarmed: the default action again
+
+
 def test_scratch_plan_is_not_monotone_in_m(lib):
     """The shapes ADVICE r2 named: M = 257 needs a K-split scratch that M = 1024 / 2048 does not."""
     assert lib.mixq_enqueue_scratch_size(257, 7168, 7168) > 0 == lib.mixq_enqueue_scratch_size(1024, 7168, 7168) or \
