@@ -68,6 +68,31 @@ class Hip:
         return ms.value
 
 
+class LineGuard:
+    """Keeps the JSON line safe while a leg runs that may take the process down: a child process reads a copy of the line from a
+    pipe and, if the pipe closes WITHOUT the disarm byte (this process died), writes it to `fd`.  The harness owns this -- the
+    operator library installs no signal handlers -- and the dying process keeps its own exit status."""
+    _CHILD = ("import os, sys\nfd = int(sys.argv[1])\ndata = sys.stdin.buffer.read()\n"
+              "if not data.endswith(b'\\0'):\n    os.write(fd, data)\n")
+
+    def __init__(self, fd, line: bytes):
+        import subprocess
+        self.p = subprocess.Popen([sys.executable, "-c", self._CHILD, str(fd)], stdin=subprocess.PIPE, pass_fds=[fd])
+        self.p.stdin.write(line)
+        self.p.stdin.flush()
+
+    def disarm(self):
+        if self.p is None:
+            return
+        try:
+            self.p.stdin.write(b"\0")
+            self.p.stdin.close()
+            self.p.wait(timeout=30)
+        except Exception:  # noqa: BLE001
+            pass
+        self.p = None
+
+
 def synth_layer(N, K, dev, gen, n0=0, n1=None):
     """Random-init packed tensors of one MixQ linear, generated on device in the operator's own contract:
     int8 W ~ round(N(0, 32^2)) clipped (a gaussian weight row quantised with max|w|/127), outlier columns zero."""
@@ -236,14 +261,17 @@ def small_m_points(lib, TensorDesc, dev, gen, st_ptr, iters=300):
     return out
 
 
-def decode_step_points(lib, TensorDesc, model, dev, gen, batches=(1, 4, 32)):
+def decode_step_points(lib, TensorDesc, model, dev, gen, batches=(1, 4, 32, 64, 128, 256, 512)):
     """Informational (never part of `value`): ONE decode step's worth of the path -- all 96 MixQ linears of Llama-2-7B, each with
-    ITS OWN weights (4.5 GB of int8 `weight` / `qweight`: cold by construction, no cache serves a layer twice), at batch 1, 4
-    and 32, captured as one HIP graph of 96 mixq_enqueue calls.  The regime of the reference's published numbers (README of
-    the reference: tokens/s at bs 32..512); linears only -- attention, norms and sampling are outside the path."""
+    ITS OWN weights (4.5 GB of int8 `weight` / `qweight`: cold by construction, no cache serves a layer twice), captured as one
+    HIP graph of 96 mixq_enqueue calls, at batch 1 / 4 and at the batch sizes the reference publishes its tokens/s for
+    (bs 32 / 64 / 128 / 256 / 512: MixQ/src/benchflops.py:311-315).  Each point: time per step, the GEMM kernel
+    family the library chose per linear shape, and the fraction of the BINDING roofline -- algorithmic bytes (weights + fp16
+    activations in + fp16 outputs) at 8 TB/s below the ridge, 2 bs N (K + 128) ops at the dense int8 MFMA peak above it.
+    Linears only -- attention, norms and sampling are outside the path."""
     out = {}
     for bs in batches:
-        calls, max_ws, wbytes = [], 16, 0
+        calls, max_ws, wbytes, abytes, ops = [], 16, 0, 0, 0.0
         acts, outs = {}, {}
         for (t, ins) in model.keep:
             N, K = t["weight"].shape[0], ins[0].shape[1]
@@ -260,6 +288,8 @@ def decode_step_points(lib, TensorDesc, model, dev, gen, batches=(1, 4, 32)):
             max_ws = max(max_ws, lib.mixq_workspace_size(h, bs, N, K))
             calls.append((h, in_desc, out_desc, in_ptrs, out_ptrs))
             wbytes += N * K
+            abytes += 2 * bs * (K + N) + 2 * N * (1 + NUM_OUTLIERS)   # A in, Out, sW, fp_weight
+            ops += 2.0 * bs * N * (K + (NUM_OUTLIERS if bs > 4 else 0))
         ws = torch.empty(max_ws, dtype=torch.uint8, device=dev)
         turn = [0]
 
@@ -268,14 +298,26 @@ def decode_step_points(lib, TensorDesc, model, dev, gen, batches=(1, 4, 32)):
             turn[0] += 1
             assert lib.mixq_enqueue(h, in_desc, ctypes.byref(out_desc), in_ptrs, out_ptrs, ctypes.c_void_p(ws.data_ptr()), st) == 0
 
+        kernels = {}
+        st0 = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        for i in range(len(model.spec["linears"])):   # (one eager call per shape: which kernel family serves it)
+            turn[0] = i
+            run(st0)
+            name = model.spec["linears"][i][0]
+            kernels[name] = lib.mixq_debug_last_gemm_kernel().decode().split(" ")[0] if bs > 4 else "w8a16 (fpA_intB on qweight)"
+        torch.cuda.synchronize(dev)
         turn[0] = -1   # (graph_time_us makes one call outside the capture: the captured 96 then start at linear 0)
         us = graph_time_us(run, dev, calls=len(calls), reps=10) * len(calls)
+        t_hbm, t_mfma = (wbytes + abytes) / 8e12, ops / (INT8_MFMA_PEAK_TOPS * 1e12)
         out[f"bs{bs}"] = {"us_per_step": us, "linears": len(calls), "weight_GB": wbytes / 1e9, "weight_GBps": wbytes / us / 1e3,
-                          "hbm_frac": wbytes / (us * 1e-6) / 8e12, "tokens_per_s_bound_by_these_linears": bs / (us * 1e-6)}
-        if bs > 4:   # the same step with a registered weight image per layer (mixq_weight_image_*: + N K bytes per layer, same bits)
+                          "hbm_frac": wbytes / (us * 1e-6) / 8e12, "tokens_per_s_bound_by_these_linears": bs / (us * 1e-6),
+                          "kernels": kernels,
+                          "roofline": {"bound": "hbm" if t_hbm >= t_mfma else "mfma", "frac": max(t_hbm, t_mfma) / (us * 1e-6),
+                                       "algorithmic_GB": (wbytes + abytes) / 1e9, "int8_TOP": ops / 1e12,
+                                       "hbm_floor_us": t_hbm * 1e6, "mfma_floor_us": t_mfma * 1e6}}
+        if 4 < bs <= 64:   # the same step with a weight image per layer (mixq_weight_image_*: + N K bytes per layer, same bits)
             try:
                 imgs = []
-                st0 = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
                 for (t, ins) in model.keep:
                     N, K = t["weight"].shape[0], ins[0].shape[1]
                     im = torch.empty(N * K, dtype=torch.int8, device=dev)
@@ -286,6 +328,7 @@ def decode_step_points(lib, TensorDesc, model, dev, gen, batches=(1, 4, 32)):
                 us_i = graph_time_us(run, dev, calls=len(calls), reps=10) * len(calls)
                 out[f"bs{bs}"]["with_weight_images"] = {
                     "us_per_step": us_i, "weight_GBps": wbytes / us_i / 1e3, "hbm_frac": wbytes / (us_i * 1e-6) / 8e12,
+                    "roofline_frac": max(t_hbm, t_mfma) / (us_i * 1e-6),
                     "tokens_per_s_bound_by_these_linears": bs / (us_i * 1e-6), "extra_HBM_GB": wbytes / 1e9,
                     "what": "every layer's `weight` registered with mixq_weight_image_register (a fragment-major copy the decode-batch "
                             "GEMM streams with contiguous reads; the calls are the same mixq_enqueue calls, bit-identical outputs)"}
@@ -297,8 +340,61 @@ def decode_step_points(lib, TensorDesc, model, dev, gen, batches=(1, 4, 32)):
                 imgs = None
         for c in calls:
             lib.mixq_destroy(c[0])
+        del ws, acts, outs
     out["what"] = ("one decode step of the 96 MixQ linears of Llama-2-7B (qkv, gate, proj x 32 layers), every layer its own weights, "
-                   "one HIP graph of 96 mixq_enqueue calls; M <= 4: the W8A16 path on qweight, M = 32: quantise + fused int8 GEMM")
+                   "one HIP graph of 96 mixq_enqueue calls; M <= 4: the W8A16 path on qweight, M > 4: quantise + fused int8 GEMM; "
+                   "bs 32..512 = the batch sizes of the reference's published tokens/s (benchflops.py:311-315)")
+    return out
+
+
+def int4_points(lib, model, dev, gen, decode_step, batches=(1, 32)):
+    """Informational (never part of `value`): the 4-bit (W4A4) flavour of the same 96 linears in decode (MixLinear_GEMM bit = 4,
+    MixQ/src/mixquant/modules/linear.py:121-143, cult.cu:2005-2060): every layer its own PACKED weights (2.25 GB), one HIP graph
+    per step.  `gemm_only`: mixq_int4_fused_dequantize alone -- ONE launch per linear that streams the packed weight and widens
+    it in registers (csrc/int4_gemm_kernels.hip); what a linear costs when the fused RMSNorm in front has already quantised the row
+    (mixq_rmsnorm_extract_quant4, the P-flavour's decode route).  `two_launches`: mixq_int4quant + the GEMM.  Against the int8
+    flavour's decode_step at the same batch (bs 1: the W8A16 GEMV on qweight; bs 32: quantise + int8 skinny GEMM)."""
+    out = {}
+    p = lambda x: ctypes.c_void_p(x.data_ptr())  # noqa: E731
+    shapes = [(t["weight"].shape[0], ins[0].shape[1]) for (t, ins) in model.keep]
+    ws4 = [torch.randint(0, 256, (N, K // 2), dtype=torch.uint8, device=dev, generator=gen) for (N, K) in shapes]
+    sws = [t["weights_scaling_factor"] for (t, _) in model.keep]
+    wbytes = sum(w.numel() for w in ws4)
+    for bs in batches:
+        acts = {K: torch.randn((bs, K), device=dev, generator=gen).to(torch.float16) for K in {k for _, k in shapes}}
+        q4 = {K: torch.empty((bs, K // 2), dtype=torch.uint8, device=dev) for K in acts}
+        sa = {K: torch.empty(bs, dtype=torch.float16, device=dev) for K in acts}
+        outs = {N: torch.empty((bs, N), dtype=torch.float16, device=dev) for N in {n for n, _ in shapes}}
+        st0 = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        for K in acts:
+            assert lib.mixq_int4quant(bs, K, p(acts[K]), p(q4[K]), p(sa[K]), st0) == 0
+        turn = [0]
+
+        def gemm_only(st):
+            i = turn[0] % len(shapes)
+            turn[0] += 1
+            N, K = shapes[i]
+            assert lib.mixq_int4_fused_dequantize(p(q4[K]), p(ws4[i]), p(sa[K]), p(sws[i]), None, p(outs[N]), bs, N, K // 2, None, st) == 0
+
+        def two_launches(st):
+            N, K = shapes[turn[0] % len(shapes)]
+            assert lib.mixq_int4quant(bs, K, p(acts[K]), p(q4[K]), p(sa[K]), st) == 0
+            gemm_only(st)
+
+        pt = {}
+        for name, fn in (("gemm_only", gemm_only), ("two_launches", two_launches)):
+            turn[0] = -1
+            us = graph_time_us(fn, dev, calls=len(shapes), reps=10) * len(shapes)
+            pt[name] = {"us_per_step": us, "weight_GBps": wbytes / us / 1e3, "hbm_frac": wbytes / (us * 1e-6) / 8e12}
+        ref = (decode_step or {}).get(f"bs{bs}", {}).get("us_per_step")
+        pt["int8_step_us"] = ref
+        if ref:
+            pt["speedup_vs_int8_step"] = {k: ref / pt[k]["us_per_step"] for k in ("gemm_only", "two_launches")}
+        pt["kernel"] = lib.mixq_debug_last_gemm_kernel().decode()
+        out[f"bs{bs}"] = pt
+    out["weight_GB"] = wbytes / 1e9
+    out["what"] = ("decode step of the 96 Llama-2-7B linears with 4-bit weights AND activations (W4A4, MixLinear_GEMM bit = 4): the packed "
+                   "weight (N K / 2 bytes) is streamed once per call and widened to int8 in registers -- no unpack pass, no workspace")
     return out
 
 
@@ -745,7 +841,9 @@ def main():
             "config": {"workload": "Llama-2-7B W8A8O16 (int8_mix) prefill, bs=512 seq=2048: all 96 MixQ linears "
                                    "(qkv 12288x4096, gate 11008x4096, proj 4096x11008; 32 layers), 128 outlier cols",
                        "tokens_per_step_per_replica": args.tokens, "m_chunk": chunk,
-                       "parallelism": f"dp{dp}" + (f"xtp{tp}" if tp > 1 else ""),
+                       "parallelism": f"dp{dp}" + (f"xtp{tp}" if tp > 1 else "") + (
+                           " (`value` = independent DP replicas, weak scaling; the tp = N row-sharded layout is `tp_tokens_per_s`)"
+                           if world > 1 and tp == 1 else ""),
                        "int8_gop_per_token": int8_gop_per_token},
             "gemm_tops_end_to_end": value * int8_gop_per_token / 1e3 / world,
             "roofline": {"bound": "mfma", "achieved": achieved_tops, "peak": INT8_MFMA_PEAK_TOPS, "unit": "TOP/s",
@@ -773,6 +871,11 @@ def main():
                 res["decode_step"] = decode_step_points(lib, TensorDesc, model, dev, gen)
             except Exception as e:  # noqa: BLE001
                 res["decode_step"] = {"error": repr(e)}
+        if world == 1 and not args.no_decode_step:
+            try:
+                res["int4"] = int4_points(lib, model, dev, gen, res.get("decode_step"))
+            except Exception as e:  # noqa: BLE001
+                res["int4"] = {"error": repr(e)}
         if args.mid_m:  # informational mid-M points (short prefill: tiles do not fill the chip); never part of `value`.
             # Opt-in: its launches of the ping-pong kernel would otherwise dilute that kernel's average in a
             # rocprofv3 --stats summary of this command, which has to agree with roofline.avg_launch_ms.
@@ -858,9 +961,12 @@ def main():
         import threading
 
         partial = {}   # what the leg has measured so far (the watchdog emits it instead of nothing)
+        guard = None
 
         def bail():
             if rank == 0:
+                if guard is not None:
+                    guard.disarm()
                 if partial.get("tp"):
                     res["tp"] = dict(partial["tp"], watchdog="the comparison of transports did not finish in time")
                 else:
@@ -871,9 +977,11 @@ def main():
         wd = threading.Timer(300.0, bail)   # (a healthy leg takes well under a minute; a hung collective must not cost the line)
         wd.daemon = True
         wd.start()
-        if rank == 0:   # ... and neither must a leg that takes the process down (a GPU memory fault ends in abort()): the library writes this line then
-            lib.mixq_debug_arm_crash_line(json_fd, (json.dumps(dict(res, tp={
-                "tp": world, "error": "the process received SIGABRT / SIGSEGV / SIGBUS inside the tp = N leg"})) + "\n").encode())
+        if rank == 0:   # ... and neither must a leg that takes the process down (a GPU memory fault ends in the runtime's abort()): a child
+            # process holds a copy of the line and writes it if this process disappears; the process itself still dies with its signal
+            # (non-zero status: the driver sees that the leg crashed)
+            guard = LineGuard(json_fd, (json.dumps(dict(res, tp={
+                "tp": world, "error": "the benchmark process died inside the tp = N leg (see its exit status)"})) + "\n").encode())
         try:
             acts = model.acts
             model.close()
@@ -926,10 +1034,17 @@ def main():
         except Exception as e:  # noqa: BLE001 -- the main measurement must survive
             tp_obj = {"tp": world, "error": repr(e)}
         wd.cancel()
-        if rank == 0:
-            lib.mixq_debug_arm_crash_line(-1, None)
+        if guard is not None:
+            guard.disarm()
     if rank == 0 and tp_obj is not None:
         res["tp"] = tp_obj
+    if rank == 0 and world > 1:
+        # `value` is what config.parallelism says; the north-star layout (rows of W sharded over all N GPUs + one all-gather of
+        # the fp16 output) is reported next to it at the top level, so that a scaling curve can be read for EITHER layout
+        res["tp_tokens_per_s"] = (tp_obj or {}).get("value")
+        res["value_layout"] = (f"{dp} data-parallel replica(s)" + (f" x tp{tp}" if tp > 1 else "") +
+                               " -- no data-path collective at tp = 1; `tp_tokens_per_s` = the row-sharded layout (tp = N, "
+                               "strong scaling: the same tokens, W sharded N ways, one all-gather per linear)")
     if rank == 0:
         emit(res)   # the line first: a teardown that hangs (a rank that died inside the tp = N leg) must not cost it
     if world > 1:

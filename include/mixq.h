@@ -299,9 +299,14 @@ MIXQ_API int mixq_int4quant(int rows, int cols, const void* src_f16, uint8_t* ds
                             void* stream);
 /* int4FusedDequantize[Silu] (cult.cu:2005-2060, 2119-2181): D = fp16(float(A.B^T) * (scale_col[n]*scale_row[m]) + y)
  * with A uint8 [M, k_packed], B uint8 [N, k_packed] packed int4, K = 2 * k_packed (the reference also takes the packed
- * count).  gfx950 has no int4 MFMA: both operands are sign-extended to int8 in `workspace`
- * (mixq_int4_fused_workspace_size bytes, caller-owned, 16-byte aligned) and the int8 MFMA kernels run on them; the
- * int32 accumulators are identical.  k_packed % 16 == 0, N % 16 == 0.  y may be NULL (no addend). */
+ * count).  gfx950 has no int4 MFMA; the int32 accumulators are nevertheless the reference's, bit for bit:
+ *   M <= 64 (decode batches): ONE launch that streams the PACKED weight -- N * k_packed bytes, the HBM saving 4-bit weights are
+ *     for -- and widens the nibbles in registers on their way into the int8 MFMA (csrc/int4_gemm_kernels.hip); `workspace` is not
+ *     used and may be NULL;
+ *   M > 64: both operands are sign-extended to int8 in `workspace` (mixq_int4_fused_workspace_size bytes, caller-owned, 16-byte
+ *     aligned) and the int8 MFMA kernels run on them.  A caller that can spare N * K bytes per layer widens the weight ONCE at
+ *     load time (mixq_unpack_int4_to_int8) and calls mixq_int4_fused_dequantize_w8 instead: per call only A is widened.
+ * k_packed % 16 == 0, N % 16 == 0.  y may be NULL (no addend). */
 MIXQ_API size_t mixq_int4_fused_workspace_size(int M, int N, int k_packed);
 MIXQ_API int mixq_int4_fused_dequantize(const uint8_t* A, const uint8_t* B, const void* scale_row, const void* scale_col,
                                         const void* y, void* D, int M, int N, int k_packed, char* workspace,
@@ -309,6 +314,11 @@ MIXQ_API int mixq_int4_fused_dequantize(const uint8_t* A, const uint8_t* B, cons
 MIXQ_API int mixq_int4_fused_dequantize_silu(const uint8_t* A, const uint8_t* B, const void* scale_row,
                                              const void* scale_col, const void* y, void* D, int M, int N, int k_packed,
                                              char* workspace, void* stream);
+/* MI355X extension: A packed int4 [M, k_packed], B_int8 = the weight widened to int8 [N, 2 * k_packed] once at load time;
+ * epilogue 0 = dequant, 1 = dequant + SiLU; workspace >= mixq_int4_fused_workspace_size(M, 0, k_packed) bytes (A only). */
+MIXQ_API int mixq_int4_fused_dequantize_w8(const uint8_t* A, const int8_t* B_int8, const void* scale_row, const void* scale_col,
+                                           const void* y, void* D, int M, int N, int k_packed, int epilogue, char* workspace,
+                                           void* stream);
 /* layernorm_forward_cuda_extract_outliers_int4 (layernorm/layernorm.cu:201-290, 379-414): the fused RMSNorm producer
  * with 4-bit rows: out fp16 [M,K] (normalised, outlier columns zeroed), outliers fp16 [M,len], q_packed uint8 [M,K/2]
  * (scale = fp16(amax/7)), scale fp16 [M].  Same constraints as mixq_rmsnorm_extract_quant. */
@@ -359,6 +369,27 @@ MIXQ_API int mixq_tp_push_columns(const void* src, void* const* dst_bases, void*
 MIXQ_API int mixq_tp_wait(const void* flags, int nprod, int word0, int nwords, uint32_t seq, void* status_dev,
                           int trap_on_timeout, uint32_t patience_ms, void* stream);
 
+/* CAPTURABLE form of the stand-alone gather (round 5).  The reference's collectives are plugins INSIDE the engine, on the engine's
+ * stream (tensorrt_llm/functional.py:3834-3880, called from plugin.py:155-156), so a TP step replays as one graph; the calls
+ * above cannot be captured -- `seq` and the buffer parity are host state baked into the launch.  Here nothing of a call is host
+ * state: `seq_word` (ONE zeroed device word per rank and gather object) holds the number of the last finished call, every launch
+ * of call s reads s = *seq_word + 1 on the device, and mixq_tp_wait_seq stores s back.  Every rank owns ONE [M, N] destination
+ * buffer (no parity), whose reuse is acknowledged explicitly.  A gather = three launches on `stream`, in this order:
+ *   mixq_tp_arrive            this rank has reached call s (whatever read call s - 1's tensor is earlier in the stream): writes s
+ *                             into peer_ack_words[r] (rank r's acknowledge word for THIS consumer: MIXQ_TP_FLAG_WORDS-strided block
+ *                             of r, one word per consumer) for every r < npeer, then waits until own_ack_words[c * MIXQ_TP_FLAG_WORDS]
+ *                             == s for every consumer c < npeer of OUR push
+ *   mixq_tp_push_columns_seq  as mixq_tp_push_columns with seq = s, one flag word
+ *   mixq_tp_wait_seq          waits for flags[r * MIXQ_TP_FLAG_WORDS] == s for every producer r < nprod, then *seq_word = s
+ * The three may be captured in a HIP graph, replayed any number of times and mixed with eager calls on the same objects.
+ * Time-outs as mixq_tp_wait (sticky status word; optional trap). */
+MIXQ_API int mixq_tp_arrive(void* const* peer_ack_words, const void* own_ack_words, int npeer, const void* seq_word,
+                            void* status_dev, int trap_on_timeout, uint32_t patience_ms, void* stream);
+MIXQ_API int mixq_tp_push_columns_seq(const void* src, void* const* dst_bases, void* const* dst_flags, int ndst, int M,
+                                      int n_local, int N, int col0, const void* seq_word, void* done_counter, void* stream);
+MIXQ_API int mixq_tp_wait_seq(const void* flags, int nprod, void* seq_word, void* status_dev, int trap_on_timeout,
+                              uint32_t patience_ms, void* stream);
+
 /* The same all-gather FUSED INTO THE OPERATOR (round 3): mixq_enqueue's prefill path with the GEMM's store path writing
  * every finished block straight into this rank's column block [col0, col0 + N_local) of all ndst destination buffers
  * ([M, n_total] fp16, own rank included) -- no [M, N_local] output, no push launch, no second read of the block; the
@@ -401,10 +432,6 @@ MIXQ_API int mixq_unprocess_weights_int8(int8_t* row_major, const uint8_t* prepr
  * mixq_debug_knobs_enabled() says which kind of process this is.  mixq_debug_reset() and the reporting entries always work. */
 MIXQ_API int mixq_debug_knobs_enabled(void);
 MIXQ_API void mixq_debug_reset(void);
-/* Measurement harness support (bench.py, the tp = N leg on a node nobody has run it on yet): keep a copy of `line` (at most 1 MiB) and, should
- * the process receive SIGABRT / SIGSEGV / SIGBUS (a GPU memory fault ends in the runtime's abort()), write it to `fd` and _exit(0) instead
- * of dying silent.  line == NULL disarms (default handlers back).  Returns 0, or -1 if the line does not fit.  Touches no operator state. */
-MIXQ_API int mixq_debug_arm_crash_line(int fd, const char* line);
 /* Test / measurement knob: main-loop schedule of the fused GEMM.  0 = auto (default), 1 = 2-barrier double-buffered
  * kernel only, 2 = 256x256 ping-pong kernel for every M > 4.  Results are identical bit for bit in all modes. */
 MIXQ_API void mixq_debug_set_gemm_variant(int variant);

@@ -98,6 +98,7 @@ SIGNATURES = {
     "mixq_int4_fused_workspace_size": (ctypes.c_size_t, [_i, _i, _i]),
     "mixq_int4_fused_dequantize": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "mixq_int4_fused_dequantize_silu": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "mixq_int4_fused_dequantize_w8": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "mixq_unpack_int4_to_fp16": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "mixq_unpack_int4_to_int8": (_i, [_vp, _vp, ctypes.c_size_t, _vp]),
     "mixq_find_outliers_workspace_size": (ctypes.c_size_t, [_i]),
@@ -136,6 +137,9 @@ SIGNATURES = {
     "mixq_tp_push_columns": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i, _i, _i, _i, _i, ctypes.c_uint32, _i,
                                   _vp, _vp]),
     "mixq_tp_wait": (_i, [_vp, _i, _i, _i, ctypes.c_uint32, _vp, _i, ctypes.c_uint32, _vp]),
+    "mixq_tp_arrive": (_i, [ctypes.POINTER(_vp), _vp, _i, _vp, _vp, _i, ctypes.c_uint32, _vp]),
+    "mixq_tp_push_columns_seq": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "mixq_tp_wait_seq": (_i, [_vp, _i, _vp, _vp, _i, ctypes.c_uint32, _vp]),
     "mixq_tp_fused_supported": (_i, [_i64, _i64, _i64]),
     "mixq_tp_flag_words": (_i, [_i64]),
     "mixq_enqueue_tp": (_i, [_vp, ctypes.POINTER(TensorDesc), ctypes.POINTER(_vp), _vp, ctypes.POINTER(TpEpilogue), _vp]),
@@ -144,7 +148,6 @@ SIGNATURES = {
     "mixq_debug_set_gemm_variant": (None, [_i]),
     "mixq_debug_reset": (None, []),
     "mixq_debug_knobs_enabled": (_i, []),
-    "mixq_debug_arm_crash_line": (_i, [_i, ctypes.c_char_p]),
     "mixq_debug_set_stamp_buffer": (None, [_vp]),
     "mixq_debug_set_quant_stamp_buffer": (None, [_vp]),
     "mixq_debug_last_gemm_kernel": (ctypes.c_char_p, []),

@@ -6,7 +6,6 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
-#include <csignal>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -14,7 +13,6 @@
 #include <string>
 #include <unordered_set>
 #include <vector>
-#include <unistd.h>
 
 #include "mixq_launch.h"
 
@@ -132,9 +130,15 @@ void mixq_debug_set_quant_stamp_buffer(void* device_u64_8_per_block)
     if (debug_knobs_enabled() || device_u64_8_per_block == nullptr) mixq::set_quant_stamp_buffer(device_u64_8_per_block);
 }
 
+static void set_int4_stream(int on);
 void mixq_debug_set_gemm_variant(int variant)
 {
-    if (debug_knobs_enabled()) mixq::set_gemm_variant(variant < 0 ? 0 : variant);
+    if (!debug_knobs_enabled()) return;
+    if (variant == 870 || variant == 871) { // packed-int4 weight stream for decode batches: 870 on (default), 871 off (unpack route)
+        set_int4_stream(variant == 870);
+        return;
+    }
+    mixq::set_gemm_variant(variant < 0 ? 0 : variant);
 }
 
 void mixq_debug_reset(void)
@@ -146,36 +150,7 @@ void mixq_debug_reset(void)
                   80 /* fpA_intB forms automatic */, 85, 840, 843, 848 /* non-temporal loads of large weights on */, 850, 858, 891 /* fragment-major qA on */, 893 /* skinny range: the rule */,
                   894 /* feature tiles automatic */, 880 /* skinny-GEMM weight image off */})
         mixq::set_gemm_variant(v);
-}
-
-// ---- measurement harness support: a last line for a process that is about to die on a signal (include/mixq.h) ----------------------
-static char g_crash_line[1 << 20];
-static volatile size_t g_crash_len = 0;
-static volatile int g_crash_fd = -1;
-static void crash_line_handler(int)
-{
-    if (g_crash_fd >= 0 && g_crash_len) {
-        ssize_t r = write(g_crash_fd, g_crash_line, g_crash_len); // (async-signal-safe)
-        (void)r;
-    }
-    _exit(0);
-}
-int mixq_debug_arm_crash_line(int fd, const char* line)
-{
-    struct sigaction sa;
-    memset(&sa, 0, sizeof(sa));
-    if (line == nullptr) {
-        g_crash_len = 0, g_crash_fd = -1;
-        sa.sa_handler = SIG_DFL;
-    } else {
-        const size_t n = strlen(line);
-        if (n >= sizeof(g_crash_line)) return -1;
-        memcpy(g_crash_line, line, n);
-        g_crash_len = n, g_crash_fd = fd;
-        sa.sa_handler = crash_line_handler;
-    }
-    for (int sig : {SIGABRT, SIGSEGV, SIGBUS}) sigaction(sig, &sa, nullptr);
-    return 0;
+    set_int4_stream(1);
 }
 
 const char* mixq_debug_last_gemm_kernel(void) { return mixq::last_gemm_kernel(); }
@@ -528,6 +503,9 @@ int mixq_int4quant(int rows, int cols, const void* src, uint8_t* dst, void* scal
 }
 
 static size_t align16_up(size_t v) { return (v + 15) & ~static_cast<size_t>(15); }
+static std::atomic<int> g_int4_stream{1};
+static void set_int4_stream(int on) { g_int4_stream.store(on); }
+// ^ test / measurement knob 870 (default: on) / 871: decode batches through the unpack route
 
 size_t mixq_int4_fused_workspace_size(int M, int N, int k_packed)
 {
@@ -535,21 +513,47 @@ size_t mixq_int4_fused_workspace_size(int M, int N, int k_packed)
     return align16_up((size_t)M * 2 * k_packed) + align16_up((size_t)N * 2 * k_packed);
 }
 
+// b8 != nullptr: the weight already widened to int8 [N, 2 k_packed] (once, at load time); only A is unpacked per call
 static int int4_fused_impl(const uint8_t* A, const uint8_t* B, const void* scale_row, const void* scale_col,
-                           const void* y, void* D, int M, int N, int k_packed, char* workspace, int epi, void* stream)
+                           const void* y, void* D, int M, int N, int k_packed, char* workspace, int epi, void* stream,
+                           const int8_t* b8 = nullptr)
 {
     if (M < 0 || N < 0 || k_packed <= 0) return MIXQ_E_BADARG;
     if (M == 0 || N == 0) return MIXQ_OK;
-    if (!A || !B || !workspace) return MIXQ_E_BADARG;
+    if (!A || (!B && !b8)) return MIXQ_E_BADARG;
     if (k_packed % 16) return MIXQ_E_SHAPE;
-    if (!aligned16(A) || !aligned16(B) || !aligned16(workspace)) return MIXQ_E_ALIGN;
+    if (!aligned16(A) || (B && !aligned16(B)) || (b8 && !aligned16(b8))) return MIXQ_E_ALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // decode batches: the packed weight stream (int4_gemm_kernels.hip) -- ONE launch, no workspace, N K / 2 weight bytes
+    if (B && g_int4_stream.load(std::memory_order_relaxed) && mixq::gemm_skinny_s4_supported(M, N, k_packed)) {
+        if (!scale_row || !scale_col || !D) return MIXQ_E_BADARG;
+        if (!aligned16(D) || !aligned16(scale_col) || (y && !aligned16(y))) return MIXQ_E_ALIGN;
+        mixq::GemmParams p{};
+        p.A = reinterpret_cast<const int8_t*>(A), p.B = reinterpret_cast<const int8_t*>(B);
+        p.sA = static_cast<const uint16_t*>(scale_row), p.sW = static_cast<const uint16_t*>(scale_col);
+        p.Y = static_cast<const uint16_t*>(y), p.D = D;
+        p.M = M, p.N = N, p.K = k_packed, p.O = 0;
+        return hip_rc(mixq::launch_gemm_skinny_s4(p, epi, st));
+    }
+    if (!workspace) return MIXQ_E_WORKSPACE;
+    if (!aligned16(workspace)) return MIXQ_E_ALIGN;
     int8_t* a8 = reinterpret_cast<int8_t*>(workspace);
-    int8_t* b8 = a8 + align16_up((size_t)M * 2 * k_packed);
     hipError_t e = mixq::launch_unpack_s4(A, a8, (size_t)M * k_packed, st);
-    if (e == hipSuccess) e = mixq::launch_unpack_s4(B, b8, (size_t)N * k_packed, st);
+    if (e == hipSuccess && !b8) {
+        int8_t* w8 = a8 + align16_up((size_t)M * 2 * k_packed);
+        e = mixq::launch_unpack_s4(B, w8, (size_t)N * k_packed, st);
+        b8 = w8;
+    }
     if (e != hipSuccess) return hip_rc(e);
     return fused_dequant_impl(a8, b8, scale_row, scale_col, y, D, M, N, 2 * k_packed, epi, stream);
+}
+
+int mixq_int4_fused_dequantize_w8(const uint8_t* A, const int8_t* B_int8, const void* scale_row, const void* scale_col,
+                                  const void* y, void* D, int M, int N, int k_packed, int epilogue, char* workspace, void* stream)
+{
+    if (epilogue != mixq::EPI_DEQUANT && epilogue != mixq::EPI_DEQUANT_SILU) return MIXQ_E_BADARG;
+    if (!B_int8) return MIXQ_E_BADARG;
+    return int4_fused_impl(A, nullptr, scale_row, scale_col, y, D, M, N, k_packed, workspace, epilogue, stream, B_int8);
 }
 
 int mixq_int4_fused_dequantize(const uint8_t* A, const uint8_t* B, const void* scale_row, const void* scale_col,
@@ -1078,6 +1082,49 @@ int mixq_tp_wait(const void* flags, int nprod, int word0, int nwords, uint32_t s
     return hip_rc(mixq::launch_tp_wait(static_cast<const unsigned*>(flags), nprod, word0, nwords, seq,
                                        static_cast<unsigned*>(status_dev), trap_on_timeout, patience_ms,
                                        static_cast<hipStream_t>(stream)));
+}
+
+// Capturable form of the same gather (tp_kernels.hip): the call number lives in `seq_word` (one zeroed device word of this rank,
+// bumped by mixq_tp_wait_seq), every rank has ONE destination buffer, and its reuse is acknowledged explicitly.
+int mixq_tp_arrive(void* const* peer_ack_words, const void* own_ack_words, int npeer, const void* seq_word, void* status_dev,
+                   int trap_on_timeout, uint32_t patience_ms, void* stream)
+{
+    if (!peer_ack_words || !own_ack_words || !seq_word || !status_dev || npeer < 1 || npeer > 8) return MIXQ_E_BADARG;
+    unsigned* acks[8];
+    for (int r = 0; r < npeer; ++r) {
+        if (!peer_ack_words[r]) return MIXQ_E_BADARG;
+        acks[r] = static_cast<unsigned*>(peer_ack_words[r]);
+    }
+    return hip_rc(mixq::launch_tp_arrive(acks, static_cast<const unsigned*>(own_ack_words), npeer,
+                                         static_cast<const unsigned*>(seq_word), static_cast<unsigned*>(status_dev),
+                                         trap_on_timeout, patience_ms, static_cast<hipStream_t>(stream)));
+}
+
+int mixq_tp_push_columns_seq(const void* src, void* const* dst_bases, void* const* dst_flags, int ndst, int M, int n_local,
+                             int N, int col0, const void* seq_word, void* done_counter, void* stream)
+{
+    if (!dst_bases || !dst_flags || !done_counter || !seq_word || ndst < 1 || ndst > 8 || M < 0 || n_local <= 0 || N <= 0 ||
+        col0 < 0 || col0 + n_local > N || (M > 0 && !src))
+        return MIXQ_E_BADARG;
+    if (n_local % 8 || N % 8 || col0 % 8) return MIXQ_E_SHAPE;
+    if (M > 0 && !aligned16(src)) return MIXQ_E_ALIGN;
+    unsigned* flags[8];
+    for (int r = 0; r < ndst; ++r) {
+        if (!dst_bases[r] || !dst_flags[r] || !aligned16(dst_bases[r])) return MIXQ_E_BADARG;
+        flags[r] = static_cast<unsigned*>(dst_flags[r]);
+    }
+    return hip_rc(mixq::launch_tp_push(src, dst_bases, flags, ndst, M, n_local, N, col0, 0u, 1,
+                                       static_cast<unsigned*>(done_counter), static_cast<hipStream_t>(stream),
+                                       static_cast<const unsigned*>(seq_word)));
+}
+
+int mixq_tp_wait_seq(const void* flags, int nprod, void* seq_word, void* status_dev, int trap_on_timeout, uint32_t patience_ms,
+                     void* stream)
+{
+    if (!flags || !status_dev || !seq_word || nprod < 1 || nprod > 8) return MIXQ_E_BADARG;
+    return hip_rc(mixq::launch_tp_wait(static_cast<const unsigned*>(flags), nprod, 0, 1, 0u, static_cast<unsigned*>(status_dev),
+                                       trap_on_timeout, patience_ms, static_cast<hipStream_t>(stream),
+                                       static_cast<unsigned*>(seq_word)));
 }
 
 // ------------------------------------------------------------------------------------- host helpers ----

@@ -164,6 +164,9 @@ hipError_t launch_dequant_columns(const int8_t* W, const void* sW, const int32_t
                                   hipStream_t st);
 hipError_t launch_quant4_rows(const void* A, uint8_t* q, void* sA, int M, int K, hipStream_t st);
 hipError_t launch_unpack_s4(const uint8_t* src, int8_t* dst, size_t packed_bytes, hipStream_t st);
+// packed-int4 weight stream (int4_gemm_kernels.hip): p.A / p.B packed int4 [M, K] / [N, K], p.K = PACKED bytes per row, p.Y addend or null
+bool gemm_skinny_s4_supported(int M, int N, int k_packed);
+hipError_t launch_gemm_skinny_s4(const GemmParams& p, int epi, hipStream_t st);
 hipError_t launch_unpack_s4_columns(const uint8_t* weight, const int32_t* ind, int rows, int cols_packed, int n,
                                     void* out, hipStream_t st);
 hipError_t launch_w8a16(const void* A, const uint8_t* Wq, const void* scale, void* Out, int M, int N, int K,
@@ -171,10 +174,14 @@ hipError_t launch_w8a16(const void* A, const uint8_t* Wq, const void* scale, voi
 
 void note_gemm_kernel(const char* name);
 // TP all-gather of the output columns as one-sided peer writes + flags (tp_kernels.hip)
+// seq_word != null (capturable form): the call number is *seq_word + 1, read on the device; launch_tp_wait stores it back
 hipError_t launch_tp_push(const void* src, void* const* dst_bases, unsigned* const* dst_flags, int ndst, int M, int n_loc,
-                          int N, int col0, unsigned seq, int nflags, unsigned* done_counter, hipStream_t st);
+                          int N, int col0, unsigned seq, int nflags, unsigned* done_counter, hipStream_t st,
+                          const unsigned* seq_word = nullptr);
 hipError_t launch_tp_wait(const unsigned* flags, int nprod, int word0, int nwords, unsigned seq, unsigned* status, int trap,
-                          unsigned patience_ms, hipStream_t st);
+                          unsigned patience_ms, hipStream_t st, unsigned* seq_word = nullptr);
+hipError_t launch_tp_arrive(unsigned* const* peer_acks, const unsigned* own_acks, int npeer, const unsigned* seq_word,
+                            unsigned* status, int trap, unsigned patience_ms, hipStream_t st);
 // fpA_intB GEMM (M > 4) on the interleaved qweight (w8a16_gemm_kernels.hip); scratch may be null (no K split)
 size_t w8a16_gemm_workspace_size(int M, int N, int K);
 hipError_t launch_w8a16_gemm(const void* A, const uint8_t* Wq, const void* scale, void* Out, int M, int N, int K,

@@ -19,6 +19,11 @@
 // that gives up (lost peer) is STICKY: it raises a word in host-mapped memory that the host side checks on every later
 // call without synchronising (parallel.PeerGather), later waits return at once instead of spinning again, and in
 // production mode (`trap`) the kernel traps, so that nothing queued behind it ever consumes a stale tensor.
+// CAPTURABLE FORM (round 5): the host-baked sequence number / buffer parity made a gather impossible to capture in a HIP graph
+// (a replay would find the captured call's flags already set).  With a device word holding the number of the last finished call
+// and ONE destination buffer whose reuse is acknowledged explicitly (tp_arrive_kernel), nothing of a call is host state: the
+// three launches replay as they are, mixed freely with eager calls (the reference's all-gather is a plugin inside the engine and
+// replays with it: tensorrt_llm/functional.py:3834-3880).
 // Flag words: kTpFlagWords per (parity, producer); the stand-alone push below publishes word 0, the push fused into the
 // GEMM epilogue (gemm_pp_kernels.hip, TpEpilogue) publishes one word per M chunk as the chunk's last tile retires.
 #include "mixq_launch.h"
@@ -36,8 +41,10 @@ struct TpDest {
 __global__ __launch_bounds__(256) void tp_push_columns_kernel(const uint4* __restrict__ src, TpDest d, int ndst, int M,
                                                                int vec_per_row /* n_loc / 8 */, int64_t dst_row_vecs
                                                                /* N / 8 */, int col0_vec, unsigned seq, int nflags,
-                                                               unsigned* __restrict__ done_counter)
+                                                               unsigned* __restrict__ done_counter,
+                                                               const unsigned* __restrict__ seq_word)
 {
+    if (seq_word != nullptr) seq = *seq_word + 1u; // capturable form: the call's number lives on the device (tp_wait bumps it)
     const int64_t total = (int64_t)M * vec_per_row;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t m = i / vec_per_row;
@@ -69,8 +76,10 @@ __global__ __launch_bounds__(256) void tp_push_columns_kernel(const uint4* __res
 // wait return at once; `trap` != 0 kills the queue instead of letting consumers behind it run on a stale tensor.
 __global__ __launch_bounds__(256) void tp_wait_flags_kernel(const unsigned* __restrict__ flags, int nprod, int word0,
                                                              int nwords, unsigned seq, unsigned* __restrict__ status,
-                                                             int trap, unsigned long long patience)
+                                                             int trap, unsigned long long patience,
+                                                             unsigned* __restrict__ seq_word)
 {
+    if (seq_word != nullptr) seq = *seq_word + 1u;
     __shared__ unsigned failed;
     if (threadIdx.x == 0) failed = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __syncthreads();
@@ -92,10 +101,46 @@ __global__ __launch_bounds__(256) void tp_wait_flags_kernel(const unsigned* __re
     __threadfence_system(); // acquire at system scope: what the producers wrote before their flags is visible from here on
     __syncthreads();
     if (trap && failed) __builtin_trap();
+    if (seq_word != nullptr && threadIdx.x == 0) *seq_word = seq; // (every thread read the old value before the barrier above)
+}
+
+// Capturable form, step 1 of 3 (tp_arrive -> tp_push_columns -> tp_wait, all reading the call number s = *seq_word + 1):
+// this rank has reached call s on its stream -- whatever read the gathered tensor of call s - 1 is earlier in the stream and
+// done -- so its ONE destination buffer may be overwritten: publish s in every producer's acknowledge words, then wait until
+// every destination of OUR push has acknowledged s.  One workgroup; bounded like tp_wait_flags_kernel.
+struct TpAck {
+    unsigned* peer[kTpMaxPeers]; // rank r's acknowledge word for THIS consumer
+};
+__global__ __launch_bounds__(64) void tp_arrive_kernel(TpAck a, const unsigned* __restrict__ own_acks, int npeer,
+                                                        const unsigned* __restrict__ seq_word, unsigned* __restrict__ status,
+                                                        int trap, unsigned long long patience)
+{
+    const unsigned seq = *seq_word + 1u;
+    __shared__ unsigned failed;
+    if (threadIdx.x == 0) failed = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();
+    if (failed == 0 && (int)threadIdx.x < npeer) {
+        __hip_atomic_store(a.peer[threadIdx.x], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned* p = own_acks + (size_t)threadIdx.x * kTpFlagWords;
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+            __builtin_amdgcn_s_sleep(16);
+            if (wall_clock64() - t0 > patience) {
+                __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(status + 1, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                failed = 1;
+                break;
+            }
+        }
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (trap && failed) __builtin_trap();
 }
 
 hipError_t launch_tp_push(const void* src, void* const* dst_bases, unsigned* const* dst_flags, int ndst, int M, int n_loc,
-                          int N, int col0, unsigned seq, int nflags, unsigned* done_counter, hipStream_t st)
+                          int N, int col0, unsigned seq, int nflags, unsigned* done_counter, hipStream_t st,
+                          const unsigned* seq_word)
 {
     if (ndst < 1 || ndst > kTpMaxPeers || n_loc % 8 || N % 8 || col0 % 8 || nflags < 1 || nflags > kTpFlagWords || M < 0 ||
         n_loc <= 0)
@@ -108,18 +153,29 @@ hipError_t launch_tp_push(const void* src, void* const* dst_bases, unsigned* con
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1; // M == 0: one workgroup that only publishes the flags
     hipLaunchKernelGGL(tp_push_columns_kernel, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const uint4*>(src), d,
-                       ndst, M, n_loc / 8, (int64_t)(N / 8), col0 / 8, seq, nflags, done_counter);
+                       ndst, M, n_loc / 8, (int64_t)(N / 8), col0 / 8, seq, nflags, done_counter, seq_word);
     return hipGetLastError();
 }
 
 hipError_t launch_tp_wait(const unsigned* flags, int nprod, int word0, int nwords, unsigned seq, unsigned* status,
-                          int trap, unsigned patience_ms, hipStream_t st)
+                          int trap, unsigned patience_ms, hipStream_t st, unsigned* seq_word)
 {
     if (nprod < 1 || nprod > kTpMaxPeers || word0 < 0 || nwords < 1 || word0 + nwords > kTpFlagWords)
         return hipErrorInvalidValue;
     const unsigned long long ticks = (unsigned long long)(patience_ms ? patience_ms : 2000u) * 100000ull; // 100 MHz
     hipLaunchKernelGGL(tp_wait_flags_kernel, dim3(1), dim3(256), 0, st, flags, nprod, word0, nwords, seq, status, trap,
-                       ticks);
+                       ticks, seq_word);
+    return hipGetLastError();
+}
+
+hipError_t launch_tp_arrive(unsigned* const* peer_acks, const unsigned* own_acks, int npeer, const unsigned* seq_word,
+                            unsigned* status, int trap, unsigned patience_ms, hipStream_t st)
+{
+    if (npeer < 1 || npeer > kTpMaxPeers) return hipErrorInvalidValue;
+    TpAck a{};
+    for (int r = 0; r < npeer; ++r) a.peer[r] = peer_acks[r];
+    const unsigned long long ticks = (unsigned long long)(patience_ms ? patience_ms : 2000u) * 100000ull; // 100 MHz
+    hipLaunchKernelGGL(tp_arrive_kernel, dim3(1), dim3(64), 0, st, a, own_acks, npeer, seq_word, status, trap, ticks);
     return hipGetLastError();
 }
 

@@ -15,7 +15,7 @@ __all__ = ["FindRowScale", "ExtractOutliersAndSetToZeros", "int8FusedDequantize"
            "dequantizeInt8", "Int8quantize", "FindRowScaleFusedExtracOutliers", "layernorm_forward_cuda",
            "layernorm_forward_cuda_extract_outliers", "int_to_half", "int_matrix_to_half",
            "int8_matrix_to_half", "w8_a16_gemm", "preprocess_weights", "mixq_linear", "int4FusedDequantize",
-           "int4FusedDequantizeSilu", "unpack_int4_to_fp16", "int8FusedDequantizeSiluMul",
+           "int4FusedDequantizeSilu", "unpack_int4_to_fp16", "unpack_int4_to_int8", "int8FusedDequantizeSiluMul",
            "layernorm_forward_cuda_extract_outliers_int4", "ExtractOutliers", "dequantizeInt8Silu", "mixlinear_forward",
            "qa_layout", "qa_to_row_major", "QA_ROW_MAJOR", "QA_FRAGMENT_MAJOR", "WeightImage"]
 
@@ -208,27 +208,47 @@ def int8FusedDequantizeSilu(A, B, scale_row, scale_col, y, M, N, K, qa_layout=0)
     return _fused("mixq_int8_fused_dequantize_silu", A, B, scale_row, scale_col, y, M, N, K, qa_layout, 1)
 
 
-def _fused4(name, A, B, scale_row, scale_col, y, M, N, K):
+def _fused4(name, A, B, scale_row, scale_col, y, M, N, K, B_int8=None):
     _dev(*(t for t in (A, B, scale_row, scale_col, y) if t is not None))
     lib = _lib.load()
     D = torch.empty((M, N), dtype=torch.float16, device=A.device)
-    ws = torch.empty(max(16, lib.mixq_int4_fused_workspace_size(M, N, K)), dtype=torch.uint8, device=A.device)
+    if M <= 64:      # decode batches: ONE launch streams the packed weight (csrc/int4_gemm_kernels.hip); no workspace
+        ws = None
+    elif B_int8 is not None:   # prefill size with the weight widened once at load: only A is widened per call
+        ws = torch.empty(max(16, lib.mixq_int4_fused_workspace_size(M, 0, K)), dtype=torch.uint8, device=A.device)
+        _lib.check(lib.mixq_int4_fused_dequantize_w8(_p(A), _p(B_int8), _p(scale_row), _p(scale_col), _p(y), _p(D), M, N, K,
+                                                     1 if name.endswith("_silu") else 0, _p(ws), _st(A)), name + "_w8")
+        return D
+    else:
+        ws = torch.empty(max(16, lib.mixq_int4_fused_workspace_size(M, N, K)), dtype=torch.uint8, device=A.device)
     _lib.check(getattr(lib, name)(_p(A), _p(B), _p(scale_row), _p(scale_col), _p(y), _p(D), M, N, K, _p(ws), _st(A)),
                name)
     return D
 
 
 @_on_tensor_device
-def int4FusedDequantize(A, B, scale_row, scale_col, y, M, N, K):
+def int4FusedDequantize(A, B, scale_row, scale_col, y, M, N, K, B_int8=None):
     """cult.cu:2005-2060: packed-int4 A [M,K] / B [N,K] (K = packed bytes per row = in_features // 2, as the reference
-    passes it).  No int4 MFMA on gfx950: operands are sign-extended to int8 and run on the int8 kernels (same int32)."""
-    return _fused4("mixq_int4_fused_dequantize", A, B, scale_row, scale_col, y, M, N, K)
+    passes it).  No int4 MFMA on gfx950, same int32 all the same: up to 64 rows the packed weight is streamed once and widened in
+    registers (one launch); above, the operands are sign-extended to int8 for the int8 kernels -- ``B_int8`` (MI355X extension):
+    the weight already widened at load time (``unpack_int4_to_int8``), then only A is widened per call."""
+    return _fused4("mixq_int4_fused_dequantize", A, B, scale_row, scale_col, y, M, N, K, B_int8)
 
 
 @_on_tensor_device
-def int4FusedDequantizeSilu(A, B, scale_row, scale_col, y, M, N, K):
+def int4FusedDequantizeSilu(A, B, scale_row, scale_col, y, M, N, K, B_int8=None):
     """cult.cu:2119-2181."""
-    return _fused4("mixq_int4_fused_dequantize_silu", A, B, scale_row, scale_col, y, M, N, K)
+    return _fused4("mixq_int4_fused_dequantize_silu", A, B, scale_row, scale_col, y, M, N, K, B_int8)
+
+
+@_on_tensor_device
+def unpack_int4_to_int8(packed):
+    """Sign-extending unpack of a packed int4 tensor [rows, cols / 2] -> int8 [rows, cols] (``mixq_unpack_int4_to_int8``)."""
+    _dev(packed)
+    assert packed.dtype == torch.uint8 and packed.is_contiguous() and packed.numel() % 16 == 0
+    out = torch.empty(packed.shape[:-1] + (packed.shape[-1] * 2,), dtype=torch.int8, device=packed.device)
+    _lib.check(_lib.load().mixq_unpack_int4_to_int8(_p(packed), _p(out), packed.numel(), _st(packed)), "unpack_int4_to_int8")
+    return out
 
 
 @_on_tensor_device

@@ -170,6 +170,16 @@ class MixLinear_GEMM:
             self.weight_image = mixlib.WeightImage(self.q_weight)
         return self
 
+    def prepare_prefill(self, enable=True):
+        """MI355X extension (bit = 4): keep the packed weight ALSO widened to int8 (+ N * K bytes) so that prefill-size calls
+        (more than 64 rows: MFMA-bound, the int8 kernels) widen only the activation per call instead of both operands; decode
+        batches stream the packed ``q_weight`` either way.  Call after the weights are final; ``enable=False`` drops the copy."""
+        self.q_weight_i8 = mixlib.unpack_int4_to_int8(self.q_weight) if (enable and self.bit == 4 and not self.weight_only) else None
+        return self
+
+    def _q_weight_i8(self, M):
+        return getattr(self, "q_weight_i8", None) if M > 64 else None
+
     def FindOutliers(self, activation):
         """linear.py:155-161."""
         return find_outliers(activation, float(self.sigma[0, 0]))
@@ -242,7 +252,7 @@ class MixLinear_GEMM:
                                             self.out_features, self.in_features, lay)
         else:
             y1 = mixlib.int4FusedDequantize(cache.q_xcache, self.q_weight, cache.x_scale, self.scale_col, y, M,
-                                            self.out_features, self.in_features // 2)
+                                            self.out_features, self.in_features // 2, self._q_weight_i8(M))
         if self.bias is not None:
             y1 += self.bias
         return y1.reshape(cache.shape)
@@ -297,7 +307,7 @@ class MixLinear_GEMM:
             if y is None:
                 raise RuntimeError("int4 mod should have outliers !")  # :364
             y1 = mixlib.int4FusedDequantizeSilu(cache.q_xcache, self.q_weight, cache.x_scale, self.scale_col, y, M,
-                                                self.out_features, self.in_features // 2)
+                                                self.out_features, self.in_features // 2, self._q_weight_i8(M))
         if self.bias is not None:
             y1 += self.bias
         if mul is not None and not fused_mul:

@@ -54,16 +54,18 @@ def _is_gloo(group) -> bool:
         return False
 
 
-def all_gather_columns(x_local: torch.Tensor, group=None, tp_size: int = None) -> torch.Tensor:
+def all_gather_columns(x_local: torch.Tensor, group=None, tp_size: int = None, run_trivial: bool = False) -> torch.Tensor:
     """[.., N/tp] per rank -> [.., N] on every rank with ONE collective (ncclAllGather under RCCL).
 
     RCCL moves contiguous buffers, so the gather lands rank-major ([tp, M, N/tp]); one strided copy puts the column
     blocks side by side (csrc/tp_kernels.hip's peer writes -- parallel.PeerGather -- avoid that pass where the ranks can
     map each other's output buffers).  Message per rank per call = M * N/tp * 2 bytes to each of the tp-1 peers.
-    A gloo group (CPU tests, and the 2-ranks-on-one-GPU test) is served through host staging."""
+    A gloo group (CPU tests, and the 2-ranks-on-one-GPU test) is served through host staging.
+    Capturable in a HIP graph on an RCCL group (the collective is enqueued on the current stream, like the reference's allgather
+    plugin inside a TensorRT engine: tensorrt_llm/functional.py:3834-3880)."""
     if tp_size is None:
         tp_size = dist.get_world_size(group)
-    if tp_size == 1:
+    if tp_size == 1 and not run_trivial:   # (run_trivial: issue the collective on a one-rank group too -- the RCCL pre-flight test)
         return x_local
     lead = x_local.shape[:-1]
     n_loc = x_local.shape[-1]
@@ -108,9 +110,17 @@ class PeerGather:
     it needs the slow rank's flag of call i + 1 before its own call i + 2 is pushed, and the slow rank publishes that
     flag only after its readers of call i, which are earlier in its stream).
 
-    NOT capturable in a HIP graph: the sequence number and the buffer parity are host-side state baked into the kernel
-    arguments, so a replay would find the flags of the captured call already set and read a half-written buffer.
-    ``gather`` refuses a capturing stream.
+    In this (default) form a call is NOT capturable in a HIP graph: the sequence number and the buffer parity are host-side
+    state baked into the kernel arguments, so a replay would find the flags of the captured call already set and read a
+    half-written buffer; ``gather`` refuses a capturing stream.
+
+    ``capturable=True`` (every rank of the group must agree) selects the form whose calls CAN be captured and replayed, as the
+    reference's all-gather plugin replays inside its engine (tensorrt_llm/functional.py:3834-3880): the call number lives in a
+    device word that the wait kernel bumps, every rank has ONE destination buffer (fixed address: what a graph needs), and its
+    reuse is acknowledged explicitly -- ``mixq_tp_arrive`` + ``mixq_tp_push_columns_seq`` + ``mixq_tp_wait_seq``, three launches
+    per gather instead of two, no host state per call.  Captured and eager calls mix freely on one object; the contract is the
+    same (readers of call i are on the stream before call i + 1).  The GEMM-fused transport (``enqueue_gather``) is not offered in
+    this form (it returns None: operator + ``gather``).
 
     Failure: a wait gives up after ``patience_ms`` (lost / hung peer) and raises a STICKY status word in host-mapped
     memory; every later ``gather`` (and ``check()``) raises ``PeerGatherTimeout`` without synchronising the device, and
@@ -123,7 +133,7 @@ class PeerGather:
     FLAG_WORDS = 64   # per (parity, producer): include/mixq.h MIXQ_TP_FLAG_WORDS
 
     def __init__(self, max_m: int, n_total: int, tp_size: int, rank: int, device, group=None, trap_on_timeout=False,
-                 patience_ms: int = 2000):
+                 patience_ms: int = 2000, capturable: bool = False):
         import os
         from . import _lib
         assert n_total % tp_size == 0 and (n_total // tp_size) % 8 == 0 and 1 < tp_size <= 8
@@ -137,6 +147,7 @@ class PeerGather:
         self.data_bytes = (self.M * self.N * 2 + 255) // 256 * 256
         self.flag_bytes = 2 * 8 * self.FLAG_WORDS * 4          # [parity][producer][FLAG_WORDS] uint32
         self.seq = 0
+        self.capturable = bool(capturable)
         self.own, handles = [], []
 
         def alloc(nbytes, kind):
@@ -171,7 +182,7 @@ class PeerGather:
                     self.peer[r][which] = ptr.value
                     self._opened.append(ptr.value)
         self.views = [torch.as_tensor(_RawDeviceBuffer(p, self.data_bytes), device=self.dev) for p in self.own[:2]]
-        self.small = torch.zeros(self.FLAG_WORDS + 1, dtype=torch.int32, device=self.dev)   # [0] push counter, [1..] chunk counters
+        self.small = torch.zeros(self.FLAG_WORDS + 2, dtype=torch.int32, device=self.dev)   # [0] push counter, [1..64] chunk counters, [65] call number (capturable form)
         dist.barrier(group=group)  # every rank has every buffer mapped before the first push
 
     # flag words of producer `prod` in rank r's block of parity `par`
@@ -209,6 +220,26 @@ class PeerGather:
     def _view(self, par: int, m: int) -> torch.Tensor:
         return self.views[par][: m * self.N * 2].view(torch.float16).view(m, self.N)
 
+    def _gather_capturable(self, x_local: torch.Tensor, m: int) -> torch.Tensor:
+        """arrive -> push -> wait with the call number on the device: nothing here depends on how often it has been called."""
+        from . import _lib
+        self.check()      # (host-mapped status word; harmless during capture)
+        st = ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+        seq_word = ctypes.c_void_p(self.small.data_ptr() + 4 * (self.FLAG_WORDS + 1))
+        # data flags: parity block 0, one word per producer; acknowledge words: parity block 1, one word per consumer
+        bases = (ctypes.c_void_p * self.tp)(*[self.peer[r][0] for r in range(self.tp)])
+        flags = (ctypes.c_void_p * self.tp)(*[self._flag_ptr(r, 0, self.rank) for r in range(self.tp)])
+        acks = (ctypes.c_void_p * self.tp)(*[self._flag_ptr(r, 1, self.rank) for r in range(self.tp)])
+        with torch.cuda.device(self.dev):
+            _lib.check(self.lib.mixq_tp_arrive(acks, self._flag_ptr(self.rank, 1, 0), self.tp, seq_word, self._status_dev,
+                                               self.trap, self.patience_ms, st), "mixq_tp_arrive")
+            _lib.check(self.lib.mixq_tp_push_columns_seq(x_local.data_ptr() if m else None, bases, flags, self.tp, m, self.n_loc,
+                                                         self.N, self.rank * self.n_loc, seq_word, self.small.data_ptr(), st),
+                       "mixq_tp_push_columns_seq")
+            _lib.check(self.lib.mixq_tp_wait_seq(self._flag_ptr(self.rank, 0, 0), self.tp, seq_word, self._status_dev,
+                                                 self.trap, self.patience_ms, st), "mixq_tp_wait_seq")
+        return self._view(0, m)
+
     def gather(self, x_local: torch.Tensor) -> torch.Tensor:
         """x_local fp16 [m, N/tp] (m <= max_m, contiguous) -> fp16 [m, N] view of this rank's buffer of the call's parity,
         valid on the current stream once the returned tensor's producer kernels (push + wait) have run."""
@@ -216,6 +247,9 @@ class PeerGather:
         m = x_local.numel() // self.n_loc
         assert x_local.shape[-1] == self.n_loc
         from . import _lib
+        if self.capturable:
+            assert m <= self.M
+            return self._gather_capturable(x_local, m)
         par = self._begin(m)
         st = ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
         bases, flags = self.destinations(par)
@@ -237,7 +271,7 @@ class PeerGather:
         K = A.shape[-1]
         m = A.numel() // K
         assert inputs[1].shape[0] == self.n_loc and A.is_cuda and A.is_contiguous()
-        if not self.lib.mixq_tp_fused_supported(m, self.n_loc, K):
+        if self.capturable or not self.lib.mixq_tp_fused_supported(m, self.n_loc, K):
             return None
         in_desc = (_lib.TensorDesc * 7)(*[_lib.TensorDesc.make(t.shape) for t in inputs])
         in_ptrs = (ctypes.c_void_p * 7)(*[t.data_ptr() for t in inputs])
@@ -248,6 +282,7 @@ class PeerGather:
     def enqueue_gather_raw(self, handle, in_desc, in_ptrs, ws_ptr, m: int, K: int):
         """``enqueue_gather`` on prepared ctypes blocks (bench.py); the shape must be ``mixq_tp_fused_supported``."""
         from . import _lib
+        assert not self.capturable, "the GEMM-fused transport carries a host-side sequence number"
         par = self._begin(m)
         st = ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
         tp = _lib.TpEpilogue()

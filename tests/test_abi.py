@@ -167,17 +167,22 @@ def test_workspace_bound_on_random_shapes_up_to_512_rows(lib):
     lib.mixq_destroy(h)
 
 
-def test_crash_line_is_written_when_the_process_aborts():
-    """bench.py arms this before the tp = N leg: a process that dies on SIGABRT (a GPU memory fault ends in abort()) still prints its line."""
+def test_bench_line_guard_writes_the_line_when_the_process_aborts_and_keeps_its_status():
+    """bench.py guards its JSON line with a CHILD PROCESS during the tp = N leg (the operator library installs no
+    signal handlers): a process that dies on SIGABRT (a GPU memory fault ends in the runtime's abort()) still gets its line out,
+    and -- unlike the handler the library used to carry -- dies with its signal, so the driver sees a failed run."""
+    import signal
     import subprocess
     import sys
-    code = ("import os\nfrom mixq_tensorrt_llm_amd import _lib\nlib = _lib.load()\n"
-            "assert lib.mixq_debug_arm_crash_line(1, b'{\"ok\": 1}\\n') == 0\nos.abort()\n")
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=120)
-    assert r.returncode == 0 and r.stdout == b'{"ok": 1}\n', (r.returncode, r.stdout, r.stderr[-300:])
-    code2 = code.replace("os.abort()", "assert lib.mixq_debug_arm_crash_line(-1, None) == 0\nos.abort()")
-    r = subprocess.run([sys.executable, "-c", code2], capture_output=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=120)
-    assert r.returncode != 0 and r.stdout == b""   # disarmed: the default action again
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys\nsys.argv = ['bench.py']\nimport bench\n"
+            "g = bench.LineGuard(1, b'{\"ok\": 1}\\n')\nDISARM\nos.abort()\n")
+    r = subprocess.run([sys.executable, "-c", code.replace("DISARM", "")], capture_output=True, cwd=root, timeout=300)
+    assert r.returncode == -signal.SIGABRT and r.stdout == b'{"ok": 1}\n', (r.returncode, r.stdout, r.stderr[-300:])
+    r = subprocess.run([sys.executable, "-c", code.replace("DISARM", "g.disarm()")], capture_output=True, cwd=root, timeout=300)
+    assert r.returncode == -signal.SIGABRT and r.stdout == b""   # disarmed: nothing is written
+    from mixq_tensorrt_llm_amd import _lib
+    assert not hasattr(_lib.load(), "mixq_debug_arm_crash_line")
 
 
 def test_scratch_plan_is_not_monotone_in_m(lib):
@@ -251,7 +256,10 @@ def test_argument_validation_returns_codes_and_never_touches_the_device():
     # 4-bit flavour and outlier helpers
     assert lib.mixq_int4quant(4, 60, p16, p16, p16, None) == SHAPE
     assert lib.mixq_int4_fused_dequantize(p16, p16, p16, p16, None, p16, 8, 64, 24, p16, None) == SHAPE
-    assert lib.mixq_int4_fused_dequantize(p16, p16, p16, p16, None, p16, 8, 64, 32, None, None) == BADARG  # no workspace
+    assert lib.mixq_int4_fused_dequantize(p16, p16, p16, p16, None, p16, 80, 64, 32, None, None) == 5  # M > 64 needs the workspace (MIXQ_E_WORKSPACE)
+    assert lib.mixq_int4_fused_dequantize(p16, p16, None, p16, None, p16, 8, 64, 32, None, None) == BADARG  # decode batch: no scales
+    assert lib.mixq_int4_fused_dequantize_w8(p16, None, p16, p16, None, p16, 80, 64, 32, 0, p16, None) == BADARG
+    assert lib.mixq_int4_fused_dequantize_w8(p16, p16, p16, p16, None, p16, 80, 64, 32, 2, p16, None) == BADARG  # epilogue 0 | 1
     assert lib.mixq_find_outliers(p16, 4, 60, ctypes.c_float(6.0), p16, p16, p16, 8, None) == SHAPE
     assert lib.mixq_find_outliers(p16, 4, 64, ctypes.c_float(6.0), None, p16, p16, 8, None) == BADARG
     assert lib.mixq_find_outliers_workspace_size(4096) == 512 and lib.mixq_int4_fused_workspace_size(32, 64, 16) == 32 * 32 + 64 * 32

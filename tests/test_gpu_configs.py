@@ -13,6 +13,12 @@ torch = pytest.importorskip("torch")
 REL_TOL = 1e-3
 
 
+@pytest.fixture
+def lib():
+    from mixq_tensorrt_llm_amd import _lib
+    return _lib.load()
+
+
 def rel_err(got, want):
     g, w = got.astype(np.float64), want.astype(np.float64)
     return np.abs(g - w).max() / max(np.abs(w).max(), 1e-30)
@@ -117,22 +123,30 @@ def test_config4_llama2_70b_tp8_shard_shapes(oracle, name, N, K):
     assert_elementwise(got2, want2, w8a16_slack(A[:2], q_un, p["weights_scaling_factor"]), f"config 4 decode {name}")
 
 
-@pytest.mark.parametrize("name,N,K", [("qkv", 12288, 4096), ("proj", 4096, 11008)])
-def test_bench_configuration_at_full_size_on_sampled_rows(oracle, name, N, K):
-    """The BENCH configuration itself (configs[2]: 65536-token chunks of Llama-2-7B; VERDICT r2: only property-checked so
-    far): ONE mixq_enqueue at 65536 x N x K on bench.py's own synthetic data -- whole rounds of 256 x 256 tiles, the XCD
-    remap over 12288 / 4096 tiles -- against the oracle on 64 sampled rows (rows are independent: TsinghuaMixQPlugin.cpp:
-    518-532 never mixes tokens).  On those rows: qA, sA and the int32 accumulators of the full-size GEMM bit-exact, the fp16
-    output within the element-wise bound and the north-star 1e-3."""
+# every (N, K) BASELINE.json's configs name: Llama-2-7B, Qwen2-7B-Instruct, one GPU's row shard of Llama-2-70B at TP = 8
+BASELINE_SHAPES = [("llama2-7b qkv", 12288, 4096), ("llama2-7b gate", 11008, 4096), ("llama2-7b proj", 4096, 11008),
+                   ("qwen2-7b qkv", 4608, 3584), ("qwen2-7b gate", 18944, 3584), ("qwen2-7b proj", 3584, 18944),
+                   ("llama2-70b/8 qkv", 1280, 8192), ("llama2-70b/8 gate", 3584, 8192), ("llama2-70b/8 proj", 1024, 28672)]
+
+
+@pytest.mark.parametrize("M", [65536, 16384, 4096])
+@pytest.mark.parametrize("name,N,K", BASELINE_SHAPES)
+def test_bench_configuration_at_full_size_on_sampled_rows(oracle, lib, name, N, K, M):
+    """The BENCH configuration itself (configs[2]: 65536-token chunks of Llama-2-7B) and every other (N, K) of BASELINE.json's
+    configs at prefill size (Qwen2-7B and the Llama-2-70B shards met the oracle only at M = 48-64): ONE
+    mixq_enqueue at M x N x K on bench.py's own synthetic data -- whole rounds of 256 x 256 tiles and the XCD remap at 65536
+    rows; at 16384 / 4096 rows the narrow shards take the 256 x 256 tiles with K split over workgroups (`pp_kernel<SPLITK>`) --
+    against the oracle on 64 sampled rows (rows are independent: TsinghuaMixQPlugin.cpp:518-532 never mixes tokens).  On
+    those rows: qA, sA and the int32 accumulators of the full-size GEMM bit-exact, the fp16 output within the element-wise
+    bound and the north-star 1e-3."""
     import bench
     from mixq_tensorrt_llm_amd import mixlib, plugin
-    M = 65536
     dev = torch.device("cuda:0")
-    gen = torch.Generator(device=dev).manual_seed(99 + N)
+    gen = torch.Generator(device=dev).manual_seed(99 + N + (M >> 10))
     t = bench.synth_layer(N, K, dev, gen)
     A = bench.synth_activation(M, K, t["ind_i32"], dev, gen)
-    rng = np.random.default_rng(N)
-    rows = np.unique(np.concatenate([[0, 1, 255, 256, 257, 32767, 32768, 65279, 65280, 65534, 65535],
+    rng = np.random.default_rng(N + M)
+    rows = np.unique(np.concatenate([[0, 1, 255, 256, 257, M // 2 - 1, M // 2, M - 257, M - 256, M - 2, M - 1],
                                      rng.integers(0, M, 53)]))[:64]
     ridx = torch.from_numpy(rows).to(dev)
     # the operator through the plugin object (same call as bench.py: mixq_enqueue on a 65536-row chunk)
@@ -140,6 +154,14 @@ def test_bench_configuration_at_full_size_on_sampled_rows(oracle, name, N, K):
     out = plug.enqueue([A, t["weight"], t["weights_scaling_factor"], t["fp_weight"], t["fp_ind"], t["qweight"],
                         t["weights_scaling_factor"]])
     torch.cuda.synchronize()
+    kernel = lib.mixq_debug_last_gemm_kernel().decode()
+    # the forms this test is there to cover: the plain 256 x 256 ping-pong kernel at the bench's chunk, and the same tiles with K
+    # split over workgroups wherever the plugin carves exchange scratch for the call (16384 rows: Qwen2-7B proj, the 70B qkv shard;
+    # 4096 rows: every narrow shard)
+    if M == 65536 and N >= 3584 and torch.cuda.get_device_properties(0).multi_processor_count == 256:
+        assert kernel.startswith("gemm_w8a8o16_pp_kernel (256x256"), kernel
+    if M > 128 and lib.mixq_gemm_scratch_size(M, N, K) > 0:
+        assert lib.mixq_enqueue_scratch_size(M, N, K) > 0 and "SPLITK" in kernel, kernel
     got = out[ridx].cpu().numpy()
     W8 = t["weight"].view(torch.int8).reshape(N, K)
     # oracle on the sampled rows
@@ -149,7 +171,7 @@ def test_bench_configuration_at_full_size_on_sampled_rows(oracle, name, N, K):
     assert rel_err(got, want) < REL_TOL
     assert_elementwise(got, want, prefill_slack(parts, A_s, dict(fp_ind=t["ind_i32"].cpu().numpy().astype(np.int64),
                                                                  fp_weight=t["fp_weight"].cpu().numpy())),
-                       f"bench configuration {name}")
+                       f"{name} at {M} rows ({kernel})")
     h = ulp_histogram(got, want)
     assert h["<=1"] > 0.995, h
     # integer half of the path at full size: quantiser rows and the int32 accumulators of the 65536-row GEMM, bit for bit
@@ -157,7 +179,7 @@ def test_bench_configuration_at_full_size_on_sampled_rows(oracle, name, N, K):
     qA = mixlib.FindRowScale(A, sA, M, K, 8)
     assert np.array_equal(qA[ridx].cpu().numpy(), parts["qA"])
     assert np.array_equal(sA[ridx].cpu().numpy().view(np.uint16), parts["sA"].view(np.uint16))
-    acc = mixlib.gemm(qA, W8, M, N, K)          # int32 [65536, N]: the same ping-pong main loop, raw accumulators
+    acc = mixlib.gemm(qA, W8, M, N, K)          # int32 [M, N]: the same ping-pong main loop, raw accumulators
     torch.cuda.synchronize()
     assert np.array_equal(acc[ridx].cpu().numpy(), parts["acc"])
     del acc, out
