@@ -46,7 +46,14 @@ constexpr int GROUP_M = 4;
 // sums and runs the epilogue, the others are gone by then -- nobody ever waits, so there is nothing to dead-lock.
 // Hand-over accesses are relaxed agent-scope atomics as in gemm_pp_kernels.hip (no fences); the counter of a tile lives
 // in the first kSplitkWordsBytes of the scratch and is left zero.  Same int32 sums, same bits.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int NSTAGE = 2, int KG = 1, bool PREO = false, bool XSP = false>
+// ADMA (round 5): the slice copies are issued in ASM form (glds16_vaddr: not counted by the compiler's s_waitcnt insertion), so that
+// NSTAGE - 1 slices really are in flight behind the explicit `s_waitcnt vmcnt(n)` of the loop -- with the builtin copies hipcc
+// drains everything in front of every barrier and the loop runs ONE slice ahead whatever NSTAGE says (notebook R3.16: no effect
+// where 2-5 workgroups share a CU and cover each other's round trips).  It is the regime with ONE workgroup per CU that needs it:
+// mid-M problems (129..512 rows) whose 128 x 128 tiles, split over K, put exactly one workgroup on every CU -- there a slice's
+// ~1 us L2 / HBM round trip, not its ~0.3 us of MFMA work, set the pace of the two-slice loop.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int NSTAGE = 2, int KG = 1, bool PREO = false, bool XSP = false,
+          bool ADMA = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N* KG * 64) void gemm_w8a8o16_kernel(const GemmParams p)
 {
     const int XS = XSP ? p.xsplit : 1; // workgroups per tile (2 / 4 / 8 / 16: index arithmetic only, so a run-time value)
@@ -154,6 +161,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KG * 64) void gemm_w8a8o16_kernel
     };
     if (PREO && has_outliers) stage_outliers(); // older than every slice copy: retired by the loop's first wait
 
+    const unsigned lds_group0 = (unsigned)(size_t)(MIXQ_LDS_PTR(smem)); // LDS byte address of this group's stages (ADMA)
     auto stage = [&](int buf, int kt) {
         char* xb = smem + buf * STAGE_BYTES;
         char* yb = xb + X_BYTES;
@@ -163,13 +171,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KG * 64) void gemm_w8a8o16_kernel
         for (int i = 0; i < XL; ++i) {
             const char* s = xsrc[i] + kbyte;
             if (last_partial && (kbyte + xkoff >= K)) s = static_cast<const char*>(p.zeros);
-            glds16(s, xb + (i * T + wave * 64) * 16);
+            if (ADMA) glds16_vaddr(s, lds_group0 + buf * STAGE_BYTES + (i * T + wave * 64) * 16);
+            else glds16(s, xb + (i * T + wave * 64) * 16);
         }
 #pragma unroll
         for (int i = 0; i < YL; ++i) {
             const char* s = ysrc[i] + kbyte;
             if (last_partial && (kbyte + ykoff >= K)) s = static_cast<const char*>(p.zeros);
-            glds16(s, yb + (i * T + wave * 64) * 16);
+            if (ADMA) glds16_vaddr(s, lds_group0 + buf * STAGE_BYTES + X_BYTES + (i * T + wave * 64) * 16);
+            else glds16(s, yb + (i * T + wave * 64) * 16);
         }
     };
 
@@ -398,13 +408,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KG * 64) void gemm_w8a8o16_kernel
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int NSTAGE = 2, int KG = 1, bool PREO = false, bool XSP = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int NSTAGE = 2, int KG = 1, bool PREO = false, bool XSP = false,
+          bool ADMA = false>
 static hipError_t launch_cfg(const GemmParams& p, hipStream_t st)
 {
     constexpr int T = WAVES_M * WAVES_N * KG * 64;
     constexpr size_t lds = (size_t)KG * NSTAGE * (size_t)(BM + BN) * KSLICE + (PREO ? (size_t)(BM + BN) * OSLICE : 0);
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = gemm_w8a8o16_kernel<BM, BN, WAVES_M, WAVES_N, EPI, NSTAGE, KG, PREO, XSP>;
+    auto kern = gemm_w8a8o16_kernel<BM, BN, WAVES_M, WAVES_N, EPI, NSTAGE, KG, PREO, XSP, ADMA>;
     static DeviceOnce once;
     if (hipError_t e = ensure_dynamic_lds(kern, lds, once); e != hipSuccess) return e;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
@@ -467,6 +478,97 @@ size_t gemm_xsplit_workspace_size(int M, int N, int K)
 }
 
 size_t gemm_xsplit_workspace_bound() { return kSplitkWordsBytes + (size_t)256 * 64 * 64 * 4; } // <= 256 workgroups x 16 KiB
+
+// ---- mid-M "deep" form (round 5): 128 x 128 tiles, 4 LDS stages really in flight (ADMA), K split over XS workgroups per tile ----
+// 129..512 rows are the band furthest below either roofline: the 256 x 256 / 128 x 256 ping-pong tiles cover a
+// quarter to a half of the CUs there, and the small two-barrier tiles run their slices one memory round trip at a time.  This form
+// puts (about) one workgroup of a 128 x 128 tile on every CU -- the tiles alone where there are enough of them, 2 / 4 / 8 workgroups
+// per tile along K otherwise -- and keeps three slices in flight behind the one being multiplied.  Same int32 sums, same epilogue.
+struct DeepPlan;
+static std::atomic<int> g_deep_force{-1}; // -1 automatic, 0 off, 1 / 2 / 4 / 8: forced workgroups per tile (knobs 1240 / 1241 + xs); + 10: the 8-wave build
+struct DeepPlan {
+    int xs;    // 0 = not used; workgroups per 128 x 128 tile otherwise
+    int tiles;
+    int waves8; // build: 0 = 4 waves x 64 x 64, 1 = 8 waves x 64 x 32 (4 stages), 2 = 8 waves, 5 stages
+};
+// The automatic rule: a table over (128 x 128 tiles, K slices), read off a sweep of every build x split against the selection as it
+// was, on COLD weights (a model's layer never finds its weights cache-resident), profiles/r05_deep_form_sweep_cold.txt -- 110 cells
+// over the ten (N, K) of BASELINE.json's configs, 80..1024 rows.  The form wins 8..35 % exactly where it puts 140..256 workgroups
+// on the chip and the alternatives leave CUs idle or take their slices one round trip at a time:
+//   tiles 140..256, K <= 5120           -> the tiles alone            (12288 x 4096 at 129..256 rows: 35.0 -> 28.3 us)  [and > 512 tiles of 64 x 64]
+//   tiles  70..128, K 5120..12800       -> 2 workgroups per tile      (4096 x 11008 at 320..512 rows: 42.8 -> 36.1 us)
+//   tiles  36..64,  K 8192..20480       -> 4                          (4096 x 11008 at 129..256 rows: 35.4 -> 30.9 us)
+//   tiles  20..32,  K >= 25600          -> 8                          (1024 x 28672 at 257..512 rows: 46.1 -> 34.1 us)
+// Everywhere else it is level or behind (the ping-pong tiles multiply a slice in less than half the time per CU; warm weights:
+// level) and is not used.  8 waves x (64 x 32) beat 4 waves x (64 x 64) in every cell; a fifth LDS stage changed nothing.
+static DeepPlan deep_plan_auto(int M, int N, int K, int tiles, int nk)
+{
+    (void)N, (void)K;
+    const int cus = num_cus();
+    if (cus != 256) return DeepPlan{0, 0, 0}; // (the table counts workgroups against the 256 CUs it was measured on)
+    // (first row: only where the 64 x 64 tiles are past their forms with K split inside the workgroup -- more than 512 of them;
+    //  below that those are ahead: 448 x 4608 x 3584 19.5 vs 23.7 us, 288 x 6144 x 4096 21.6 vs 26.0, validation sweep of the table)
+    const int64_t wg64 = (int64_t)((M + 63) / 64) * ((N + 63) / 64);
+    if (tiles >= 140 && tiles <= 256 && nk <= 40 && wg64 > 512) return DeepPlan{1, tiles, 1};
+    if (M <= 128) return DeepPlan{0, 0, 0};
+    if (tiles >= 70 && tiles <= 128 && nk >= 40 && nk <= 100) return DeepPlan{2, tiles, 1};
+    if (tiles >= 36 && tiles <= 64 && nk >= 64 && nk <= 160) return DeepPlan{4, tiles, 1};
+    if (M > 256 && tiles >= 20 && tiles <= 32 && nk >= 200) return DeepPlan{8, tiles, 1};
+    return DeepPlan{0, 0, 0};
+}
+static DeepPlan deep_plan(int M, int N, int K)
+{
+    DeepPlan none{0, 0, 0};
+    const int force = g_deep_force.load();
+    if (force == 0 || M <= 64) return none;
+    const int64_t tiles = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
+    const int nk = (K + KSLICE - 1) / KSLICE;
+    if (tiles > 4096) return none;
+    if (force > 0) {
+        const int xs = force % 10;
+        if (xs > 1 && tiles * xs > 768) return none; // (the parked tiles must fit the scratch bound: 64 KiB per workgroup)
+        return (xs == 1 || xs == 2 || xs == 4 || xs == 8) && nk >= 4 * xs ? DeepPlan{xs, (int)tiles, force / 10} : none;
+    }
+    return deep_plan_auto(M, N, K, (int)tiles, nk);
+}
+bool gemm_deep_takes(int M, int N, int K, bool have_scratch)
+{
+    const DeepPlan pl = deep_plan(M, N, K);
+    return pl.xs == 1 || (pl.xs > 1 && have_scratch);
+}
+size_t gemm_deep_workspace_size(int M, int N, int K)
+{
+    const DeepPlan pl = deep_plan(M, N, K);
+    return pl.xs > 1 ? kSplitkWordsBytes + (size_t)pl.tiles * pl.xs * (size_t)(128 * 128 * 4) : 0;
+}
+void set_deep_force(int v) { g_deep_force.store(v); }
+
+template <int EPI>
+static hipError_t launch_deep_epi(const GemmParams& p, hipStream_t st)
+{
+    const DeepPlan pl = deep_plan(p.M, p.N, p.K);
+    GemmParams q = p;
+    q.xsplit = pl.xs;
+    if (pl.waves8 == 2) { // five stages = the whole 160 KiB of LDS: four slices in flight
+        if (pl.xs > 1) return launch_cfg<128, 128, 2, 4, EPI, 5, 1, false, true, true>(q, st);
+        return launch_cfg<128, 128, 2, 4, EPI, 5, 1, false, false, true>(q, st);
+    }
+    if (pl.waves8) {
+        if (pl.xs > 1) return launch_cfg<128, 128, 2, 4, EPI, 4, 1, false, true, true>(q, st);
+        return launch_cfg<128, 128, 2, 4, EPI, 4, 1, false, false, true>(q, st);
+    }
+    if (pl.xs > 1) return launch_cfg<128, 128, 2, 2, EPI, 4, 1, false, true, true>(q, st);
+    return launch_cfg<128, 128, 2, 2, EPI, 4, 1, false, false, true>(q, st);
+}
+hipError_t launch_gemm_deep(const GemmParams& p, int epi, hipStream_t st)
+{
+    switch (epi) {
+    case EPI_DEQUANT: return launch_deep_epi<EPI_DEQUANT>(p, st);
+    case EPI_DEQUANT_SILU: return launch_deep_epi<EPI_DEQUANT_SILU>(p, st);
+    case EPI_DEQUANT_SILU_MUL: return launch_deep_epi<EPI_DEQUANT_SILU_MUL>(p, st);
+    default: return hipErrorInvalidValue;
+    }
+}
 
 static std::atomic<int> g_force_cfg{-1}; // measurement knob (variant 10 + i): force tile configuration i
 
@@ -533,6 +635,10 @@ bool qa_frag_enabled() { return g_qa_frag.load() != 0; }
 
 void set_gemm_variant(int v)
 {
+    if (v >= 1240 && v <= 1269) { // mid-M deep form: 1240 automatic, 1241 off, 1241 + xs (1242 / 1243 / 1245 / 1249) forced, + 10 the 8-wave build
+        set_deep_force(v == 1240 ? -1 : v - 1241);
+        return;
+    }
     if (v >= 880 && v <= 883) { // registered weight images in the decode-batch GEMM: 880 automatic, 881 plain loads, 882 non-temporal loads, 883 ignored
         set_skinny_wfrag(v - 880);
         return;
@@ -673,7 +779,7 @@ void note_gemm_kernel(const char* name) { g_last_kernel.store(name, std::memory_
 bool gemm_tp_fused_supported(int M, int N, int K, int O)
 {
     if (M <= 128 || N <= 0 || K <= 0 || O < 0 || O > 128 || gemm_variant() != 0) return false;
-    if (gemm_pp128_wins(M, N, K) || gemm_splitk_factor(M, N, K) != 0) return false;
+    if (gemm_deep_takes(M, N, K, true) || gemm_pp128_wins(M, N, K) || gemm_splitk_factor(M, N, K) != 0) return false;
     const int64_t tiles256 = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
     const int64_t wg64 = (int64_t)((M + 63) / 64) * ((N + 63) / 64);
     return tiles256 >= 96 && wg64 > 768;
@@ -730,6 +836,10 @@ hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st)
     if (gemm_takes_skinny(p, epi)) {
         chose("gemm_skinny_kernel");
         return launch_gemm_skinny(p, epi, st);
+    }
+    if (variant == 0 && epi != EPI_INT32 && p.a_frag == 0 && gemm_deep_takes(p.M, p.N, p.K, p.splitk_ws != nullptr)) {
+        chose("gemm_w8a8o16_kernel<DEEP> (128x128 tiles, 4 stages in flight, K split over workgroups)");
+        return launch_gemm_deep(p, epi, st);
     }
     const int64_t tiles256 = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256);
     if (variant >= 100) return launch_gemm_pp_ablate(p, variant - 100, st); // measurement-only ablations

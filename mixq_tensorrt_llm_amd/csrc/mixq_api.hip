@@ -148,7 +148,7 @@ void mixq_debug_reset(void)
     mixq::set_quant_stamp_buffer(nullptr);
     for (int v : {-1 /* schedule (back to the MIXQ_GEMM_VARIANT default), tile configuration, skinny K width */, 79 /* K splits over workgroups automatic */, 69, 65, 91,
                   80 /* fpA_intB forms automatic */, 85, 840, 843, 848 /* non-temporal loads of large weights on */, 850, 858, 891 /* fragment-major qA on */, 893 /* skinny range: the rule */,
-                  894 /* feature tiles automatic */, 880 /* skinny-GEMM weight image off */})
+                  894 /* feature tiles automatic */, 880 /* skinny-GEMM weight image off */, 1240 /* mid-M deep form automatic */})
         mixq::set_gemm_variant(v);
     set_int4_stream(1);
 }
@@ -300,11 +300,12 @@ static size_t qa_region_bytes(int64_t M, int64_t K)
 static size_t enqueue_scratch_bytes(int64_t M, int64_t N, int64_t K)
 {
     if (M <= 4 || N <= 0 || K <= 0 || M > INT32_MAX || N > INT32_MAX || K > INT32_MAX) return 0;
-    if (M > 128) {
-        const size_t a = mixq::gemm_splitk_workspace_size((int)M, (int)N, (int)K);
-        if (a) return a;
-    }
-    return mixq::gemm_xsplit_workspace_size((int)M, (int)N, (int)K);
+    // (the mid-M deep form is chosen first where its table says so; the scratch also covers whichever form a forced schedule would
+    //  fall back to on the same shape)
+    const size_t d = mixq::gemm_deep_takes((int)M, (int)N, (int)K, true) ? mixq::gemm_deep_workspace_size((int)M, (int)N, (int)K) : 0;
+    size_t a = M > 128 ? mixq::gemm_splitk_workspace_size((int)M, (int)N, (int)K) : 0;
+    if (!a) a = mixq::gemm_xsplit_workspace_size((int)M, (int)N, (int)K);
+    return d > a ? d : a;
 }
 // Largest exchange scratch mixq_enqueue can carve with these N, K and ANY M <= maxM.  The plans (gemm_splitk_plan incl. its
 // gemm_pp128_wins gate, xsplit_plan) see M only through ceil(M / 32 | 64 | 128 | 256) and the thresholds 4 / 16 / 32 / 128 /
@@ -596,8 +597,10 @@ int mixq_int8_fused_dequantize_silu_mul(const int8_t* A, const int8_t* B, const 
 // scratch of whichever cross-workgroup K split launch_gemm would pick for this shape (at most one applies)
 static size_t gemm_scratch_bytes(int M, int N, int K)
 {
-    const size_t a = mixq::gemm_splitk_workspace_size(M, N, K);
-    return a ? a : mixq::gemm_xsplit_workspace_size(M, N, K);
+    const size_t d = mixq::gemm_deep_takes(M, N, K, true) ? mixq::gemm_deep_workspace_size(M, N, K) : 0;
+    size_t a = mixq::gemm_splitk_workspace_size(M, N, K);
+    if (!a) a = mixq::gemm_xsplit_workspace_size(M, N, K);
+    return d > a ? d : a;
 }
 
 size_t mixq_gemm_scratch_size(int M, int N, int K) { return gemm_scratch_bytes(M, N, K); }

@@ -113,6 +113,11 @@ int gemm_xsplit_factor(int M, int N, int K);              // 0 / 2 / 4 / 8 / 16
 size_t gemm_xsplit_workspace_size(int M, int N, int K);
 size_t gemm_xsplit_workspace_bound();
 void set_xsplit_force(int v); // -1 automatic (default), 0 off, 2 / 4 / 8 / 16 forced
+// mid-M deep form (gemm_kernels.hip): 128 x 128 tiles, 4 stages in flight, K split over 1 / 2 / 4 / 8 workgroups per tile
+bool gemm_deep_takes(int M, int N, int K, bool have_scratch);
+size_t gemm_deep_workspace_size(int M, int N, int K); // 0: the form is not used for this shape, or needs no scratch
+void set_deep_force(int v);
+hipError_t launch_gemm_deep(const GemmParams& p, int epi, hipStream_t st);
 bool gemm_skinny_supported(const GemmParams& p);
 hipError_t launch_gemm_skinny(const GemmParams& p, int epi, hipStream_t st); // M <= 64: GEMV-like, HBM-bound on W
 hipError_t launch_gemm_pp_ablate(const GemmParams& p, int abl, hipStream_t st);  // timing experiments only
