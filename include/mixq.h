@@ -32,6 +32,7 @@ enum {
     MIXQ_E_ALIGN = 3,     /* a device pointer is not 16-byte aligned */
     MIXQ_E_HIP = 4,       /* a HIP launch failed; hipGetLastError() has the detail */
     MIXQ_E_WORKSPACE = 5, /* workspace pointer is null where one is needed */
+    MIXQ_E_STALE = 6,     /* mixq_weight_image_verify: the bytes behind a registered weight pointer are not the registered weight's */
 };
 
 /* ---- tensor descriptor ------------------------------------------------------------------------ */
@@ -195,14 +196,28 @@ MIXQ_API int mixq_gemm_mixed_scratch(const int8_t* qA, const int8_t* W, const vo
  * operator time at 32 rows -10..-15 % (profiles/r04_weight_image_probe.txt).  Every other kernel keeps reading `weight` itself,
  * which must stay valid and unchanged.
  *   mixq_weight_image_bytes(N, K)        bytes the image needs (N * K), or 0 if the shape has no image (N % 16 or K % 64 != 0)
- *   mixq_weight_image_register(...)      builds the image of `weight` into caller-owned device memory `image` (one launch on
- *                                        `stream`) and registers it under the pointer `weight`; registering again replaces it
- *   mixq_weight_image_unregister(weight) forgets it -- REQUIRED before `weight` or `image` is freed or rewritten: the registry is
- *                                        keyed by address and cannot see a reallocation (a shape that no longer matches is ignored)
- * Process-global, thread-safe (readers share a lock; with nothing registered a lookup is one atomic load). */
+ *   mixq_weight_image_register(...)      builds the image of `weight` into caller-owned device memory `image` and registers it under the
+ *                                        pointer `weight` together with a 64-bit CONTENT TAG of the weight; registering again replaces it.
+ *                                        Set-up work: two passes over the weight on `stream`, which it SYNCHRONISES (the only entries of
+ *                                        this header that do, with _verify and the first use below)
+ *   mixq_weight_image_unregister(weight) forgets it -- REQUIRED before `weight` or `image` is freed or rewritten
+ *   mixq_weight_image_verify(weight, s)  MIXQ_OK if the bytes behind `weight` still carry the registered tag, MIXQ_E_STALE if not (the
+ *                                        entry is dropped: calls go back to reading `weight`), MIXQ_E_BADARG if nothing is registered;
+ *                                        synchronises `s`
+ * An address says nothing about what lives there: a weight freed and re-allocated at the same address with the same shape must not be
+ * served the old tensor's image.  The image of a registration is therefore NOT TRUSTED until the bytes behind the pointer have been
+ * compared with the tag on its FIRST USE (one pass over the weight + one synchronisation of the call's stream, once per registration;
+ * a first use inside a stream capture cannot verify and reads `weight` itself -- run a call eagerly before capturing, as any graph
+ * warm-up does); a mismatch drops the entry and counts in mixq_weight_image_stale_count().  After the first use the contract is the
+ * usual one for a pointer held by a library: unregister before the memory changes hands (a captured graph holds the image pointer
+ * like any other argument: keep image and registration alive as long as the graph).
+ * Process-global, thread-safe (readers share a lock; with nothing registered a lookup is one atomic load); every call looks its
+ * weight up ONCE. */
 MIXQ_API size_t mixq_weight_image_bytes(int64_t N, int64_t K);
 MIXQ_API int mixq_weight_image_register(const int8_t* weight, int64_t N, int64_t K, void* image, void* stream);
 MIXQ_API int mixq_weight_image_unregister(const int8_t* weight);
+MIXQ_API int mixq_weight_image_verify(const int8_t* weight, void* stream);
+MIXQ_API int mixq_weight_image_stale_count(void);
 
 /* ---- qA layouts (MI355X extension; decode batches) --------------------------------------------------------------------------
  * The int8 activation image between a producer (quantiser, fused norm) and the fused GEMM is the library's own intermediate,

@@ -87,6 +87,8 @@ SIGNATURES = {
     "mixq_weight_image_bytes": (_sz, [_i64, _i64]),
     "mixq_weight_image_register": (_i, [_vp, _i64, _i64, _vp, _vp]),
     "mixq_weight_image_unregister": (_i, [_vp]),
+    "mixq_weight_image_verify": (_i, [_vp, _vp]),
+    "mixq_weight_image_stale_count": (_i, []),
     "mixq_enqueue_profiled": (_i, [_vp, ctypes.POINTER(TensorDesc), ctypes.POINTER(TensorDesc), ctypes.POINTER(_vp),
                                    ctypes.POINTER(_vp), _vp, _vp, _vp, _vp]),
     "mixq_int8quant": (_i, [_i, _i, _vp, _vp, _vp, _vp]),

@@ -104,7 +104,8 @@ def load_checkpoint(ckpt_dir: str, rank: int = 0) -> (dict, Dict[str, Dict[str, 
 def load_linear(layer, tensors: Dict[str, torch.Tensor]):
     """Install one module's carrier tensors into a plugin.MixQLinear (names match plugin.py:99-123)."""
     dev = layer.weight.device
-    if getattr(layer, "weight_image", None) is not None:   # (a registered streaming copy belongs to the tensor being replaced)
+    had_image = getattr(layer, "weight_image", None) is not None
+    if had_image:   # (a registered streaming copy belongs to the tensor being replaced; rebuilt for the new one below, as MixQLinear.load does)
         layer.prepare_decode_batches(False)
     for name in MIXQ_TENSORS:
         want = tuple(getattr(layer, name).shape)
@@ -115,6 +116,8 @@ def load_linear(layer, tensors: Dict[str, torch.Tensor]):
         want, got = tuple(layer.bias.shape), tuple(tensors["bias"].shape)
         assert want == got, f"bias: checkpoint {got} vs module {want} (row-sharded layers hold their [N/tp] slice)"
         layer.bias = tensors["bias"].to(dev)
+    if had_image:
+        layer.prepare_decode_batches(True)
     return layer
 
 

@@ -495,7 +495,7 @@ struct DeepPlan {
 // was, on COLD weights (a model's layer never finds its weights cache-resident), profiles/r05_deep_form_sweep_cold.txt -- 110 cells
 // over the ten (N, K) of BASELINE.json's configs, 80..1024 rows.  The form wins 8..35 % exactly where it puts 140..256 workgroups
 // on the chip and the alternatives leave CUs idle or take their slices one round trip at a time:
-//   tiles 140..256, K <= 5120           -> the tiles alone            (12288 x 4096 at 129..256 rows: 35.0 -> 28.3 us)  [and > 512 tiles of 64 x 64]
+//   tiles 140..256, K 3072..5120        -> the tiles alone            (12288 x 4096 at 129..256 rows: 35.0 -> 28.3 us)  [and > 512 tiles of 64 x 64]
 //   tiles  70..128, K 5120..12800       -> 2 workgroups per tile      (4096 x 11008 at 320..512 rows: 42.8 -> 36.1 us)
 //   tiles  36..64,  K 8192..20480       -> 4                          (4096 x 11008 at 129..256 rows: 35.4 -> 30.9 us)
 //   tiles  20..32,  K >= 25600          -> 8                          (1024 x 28672 at 257..512 rows: 46.1 -> 34.1 us)
@@ -509,7 +509,7 @@ static DeepPlan deep_plan_auto(int M, int N, int K, int tiles, int nk)
     // (first row: only where the 64 x 64 tiles are past their forms with K split inside the workgroup -- more than 512 of them;
     //  below that those are ahead: 448 x 4608 x 3584 19.5 vs 23.7 us, 288 x 6144 x 4096 21.6 vs 26.0, validation sweep of the table)
     const int64_t wg64 = (int64_t)((M + 63) / 64) * ((N + 63) / 64);
-    if (tiles >= 140 && tiles <= 256 && nk <= 40 && wg64 > 512) return DeepPlan{1, tiles, 1};
+    if (tiles >= 140 && tiles <= 256 && nk >= 24 && nk <= 40 && wg64 > 512) return DeepPlan{1, tiles, 1}; // (measured at K = 3584 .. 5120 only)
     if (M <= 128) return DeepPlan{0, 0, 0};
     if (tiles >= 70 && tiles <= 128 && nk >= 40 && nk <= 100) return DeepPlan{2, tiles, 1};
     if (tiles >= 36 && tiles <= 64 && nk >= 64 && nk <= 160) return DeepPlan{4, tiles, 1};
@@ -797,7 +797,7 @@ bool gemm_takes_skinny(const GemmParams& p, int epi)
     //  35.0, 8192 x 16384 41.2 / 47.5, 3584 x 18944 29.8 / 39.7, 1024 x 28672 27.9 / 52.1) -- UNLESS the weight has a registered image
     //  (gemm_skinny_kernels.hip), which the skinny kernel streams 15-20 % faster: 5120 x 13824 27.8, 8192 x 16384 37.2, 4096 x 16384 29.2
     //  -> 24.1, 2560 x 12288 21.6 -> 18.2, 512 x 8192 15.8 -> 12.5; at 48 rows 3584 x 8192 19.7 -> 17.0, 1280 x 8192 16.7 -> 16.0.)
-    const bool img = frag && p.B != nullptr && find_weight_image(p.B, p.N, p.K) != nullptr;
+    const bool img = frag && p.b_image != nullptr;
     const int c16 = 16 * num_cus();
     const bool skinny_on_image = frag && ((p.N >= c16 && p.K <= 12288) || (p.M <= 32 && p.N >= 1024 && p.K <= 8192) ||
                                           (img && p.M <= 32 && p.N >= 512 && p.K <= 16384) ||
@@ -810,8 +810,10 @@ bool gemm_takes_skinny(const GemmParams& p, int epi)
     // 22.0 / 23.5 / 19.7, at 64 rows 22.2 / 26.0 / 23.0, 4096 x 4096 at 64 rows 17.9 / 14.4 / 13.2.  (Round 3 had fitted this warm:
     // 48 rows up to N = 12288, 64 rows up to 6144 whatever the weight's layout.)
     const bool one_tile = skinny_feature_tiles(p.M, p.N, p.K) == 1;
-    const bool rows_33_64 = frag && (img ? ((p.M <= 48 && p.N <= 12288) || (p.M <= 64 && p.N <= 6144 && one_tile))
-                                         : ((p.M <= 48 && p.N <= 8192 && one_tile) || (p.M <= 64 && p.N <= 4096)));
+    // (the rule with an image is a SUPERSET of the rule without: a producer that probed without the weight pointer -- mixq_qa_layout --
+    //  and wrote the fragment-major image must find the consumer agreeing whatever the registry holds)
+    const bool rows_plain = (p.M <= 48 && p.N <= 8192 && one_tile) || (p.M <= 64 && p.N <= 4096);
+    const bool rows_33_64 = frag && (rows_plain || (img && ((p.M <= 48 && p.N <= 12288) || (p.M <= 64 && p.N <= 6144 && one_tile))));
     return gemm_variant() != 1 && !xsplit_wins && gemm_skinny_supported(p) &&
            (p.M <= 16 || (p.M <= 32 && (p.N <= 12288 || g_skinny_wide.load() != 0)) || rows_33_64 ||
             (p.M <= 64 && g_skinny_wide.load() == 2));

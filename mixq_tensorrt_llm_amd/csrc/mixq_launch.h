@@ -75,7 +75,8 @@ struct GemmParams {
     int a_frag;           // layout of A: 0 row-major | 1 the skinny GEMM's fragment-major image (only valid when gemm_takes_skinny) |
                           // 2 K-slice-major [K/128][M][128 B] (read by the plain 256 x 256 ping-pong kernel only; no producer ships:
                           // measured a net loss, docs/LAB_NOTEBOOK.md R3.10); 1 is written by mixq_enqueue's quantiser (FRAG)
-    int b_frag;           // (set by the skinny launcher from the weight-image registry, a_frag == 1 only) layout of B: 0 row-major [N,K] | 1 fragment-major image
+    const void* b_image;  // the registered fragment-major image of B this call may stream (resolved once per call by the API layer), or null
+    int b_frag;           // (set by the skinny launcher from b_image, a_frag == 1 only) layout of B: 0 row-major [N,K] | 1 fragment-major image
                           // (1-KiB blocks [16-feature tile][64-byte k-step], lane l = feature % 16 + 16 * (k / 16 % 4) at l * 16) | 2 the same, non-temporal loads
     void* dbg;            // measurement only: 8 x uint64 s_memtime stamps per block (ping-pong kernel), else null
     int xsplit;           // (set by launch_epi) workgroups per tile of the small-tile kernels' K split, else 0
@@ -140,10 +141,12 @@ void set_skinny_nt(int nt);
 void set_skinny_wfrag(int mode); // knob 880 automatic | 881 weight images with plain loads | 882 with non-temporal loads | 883 images ignored
 // weight images (gemm_skinny_kernels.hip): a fragment-major copy of an int8 [N, K] weight, registered under the weight's pointer
 hipError_t launch_weight_image(const int8_t* W, int8_t* img, int N, int K, hipStream_t st);
-void register_weight_image(const void* weight, const void* image, int N, int K);
+hipError_t register_weight_image(const void* weight, const void* image, int N, int K, hipStream_t st); // records the weight's content tag; synchronises st
 bool unregister_weight_image(const void* weight);
-const void* find_weight_image(const void* weight, int N, int K); // measurement knob 894 / 895 / 896: feature tiles per workgroup of the fragment-major form auto / 1 / 2
-int skinny_feature_tiles(int M, int N, int K);
+const void* resolve_weight_image(const void* weight, int N, int K, hipStream_t st); // once per call; verifies the content tag on first use
+int verify_weight_image(const void* weight, hipStream_t st);  // 1 current | 0 stale (dropped) | -1 nothing registered; synchronises st
+int weight_image_stale_count();
+int skinny_feature_tiles(int M, int N, int K); // measurement knob 894 / 895 / 896: feature tiles per workgroup of the fragment-major form auto / 1 / 2
 hipError_t launch_gemm_fp16(const void* fpA, const void* fpW, void* Out, int M, int N, int O, hipStream_t st);
 hipError_t launch_dequantization(void* out, const int32_t* x, const void* sRow, const void* sCol, int M, int N,
                                  hipStream_t st);

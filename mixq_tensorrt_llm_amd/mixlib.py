@@ -43,7 +43,10 @@ class WeightImage:
     """A registered fragment-major copy of an int8 weight [N, K] (include/mixq.h ``mixq_weight_image_*``, MI355X extension): while it
     is alive, every decode-batch call (5 .. 64 rows) of the library on that weight POINTER streams the copy -- one contiguous 1-KiB
     read per load instead of 64 bytes of 16 rows -- with bit-identical results (-10..-15 % operator time at 32 rows).  Costs N * K
-    bytes.  ``close()`` (or garbage collection) unregisters it; the weight tensor must not be freed or rewritten before that."""
+    bytes.  ``close()`` (or garbage collection) unregisters it; the weight tensor must not be freed or rewritten before that.  The
+    library records a content tag of the weight at registration and compares the bytes behind the pointer with it on the image's first
+    use (``verify()`` re-checks on demand): a tensor that was replaced behind the same address is served from its own bytes, not from
+    the stale image.  A captured HIP graph holds the image pointer: keep this object alive as long as the graph."""
 
     def __init__(self, weight_int8):
         assert weight_int8.is_cuda and weight_int8.is_contiguous() and weight_int8.element_size() == 1 and weight_int8.dim() == 2
@@ -56,6 +59,13 @@ class WeightImage:
         self.image = torch.empty(nbytes, dtype=torch.int8, device=weight_int8.device)
         with torch.cuda.device(weight_int8.device):
             _lib.check(lib.mixq_weight_image_register(_p(weight_int8), n, k, _p(self.image), _st(weight_int8)), "weight_image_register")
+
+    def verify(self) -> bool:
+        """True if the weight still has the registered content (synchronises the weight's stream); False drops the registration."""
+        if self._weight is None:
+            return False
+        with torch.cuda.device(self._weight.device):
+            return _lib.load().mixq_weight_image_verify(_p(self._weight), _st(self._weight)) == 0
 
     def close(self):
         if self._weight is not None:

@@ -111,3 +111,64 @@ def test_graph_replay_and_the_mixlib_flavour(oracle):
     torch.cuda.synchronize()
     assert torch.equal(y0, y1)
     lin.prepare_decode_batches(False)
+
+
+def test_a_weight_replaced_behind_the_same_address_is_not_served_the_old_image(oracle):
+    """the registry is keyed by address.  The library records a content tag at registration and compares the bytes
+    behind the pointer with it on the image's FIRST USE: a tensor whose content was replaced in place (= freed and re-allocated at the
+    same address) without unregistering gets results from its OWN bytes, the entry is dropped, the stale counter moves; the same after
+    a first use is what `verify` is for."""
+    from mixq_tensorrt_llm_amd import _lib, mixlib, plugin
+    lib = _lib.load()
+    N, K, M = 4096, 4096, 32
+    A, W1, act = make_layer(M, N, K, seed=1)
+    _, W2, _ = make_layer(M, N, K, seed=2)
+    p1, p2 = oracle.pack_linear_weights(W1, act), oracle.pack_linear_weights(W2, act)
+    layer = plugin.MixQLinear(K, N, device="cuda:0").load(p1)
+    x = torch.from_numpy(A).to("cuda:0")
+    stale0 = lib.mixq_weight_image_stale_count()
+    img = mixlib.WeightImage(layer.weight.view(torch.int8))                 # registered, not used yet
+    layer.weight.view(torch.int8).copy_(torch.from_numpy(p2["weight"]))     # ... the memory changes hands behind the library's back
+    layer.fp_weight.copy_(torch.from_numpy(p2["fp_weight"]).view(torch.float16).reshape(layer.fp_weight.shape))
+    layer.weights_scaling_factor.copy_(torch.from_numpy(p2["weights_scaling_factor"]))
+    got = layer(x).cpu().numpy()                                            # first use: tag mismatch -> reads `weight` itself
+    assert lib.mixq_weight_image_stale_count() == stale0 + 1
+    assert_prefill_parity(oracle, got, A, dict(p2, fp_ind=p1["fp_ind"]), "replaced weight, stale image dropped")
+    assert not img.verify()                                                 # nothing registered any more
+    img.close()
+    # after a verified first use: verify() tells a later replacement, and drops the entry
+    img = mixlib.WeightImage(layer.weight.view(torch.int8))
+    got2 = layer(x).cpu().numpy()
+    assert np.array_equal(got2, got) and img.verify()
+    layer.weight.view(torch.int8).copy_(torch.from_numpy(p1["weight"]))
+    assert not img.verify() and lib.mixq_weight_image_stale_count() == stale0 + 2
+    img.close()
+
+
+def test_first_use_inside_a_capture_reads_the_weight_itself(oracle):
+    """An image that has never been used cannot be verified while its stream is being captured (verification synchronises): the captured
+    call reads `weight`; after one eager call the image is trusted and a later capture streams it.  Same bits either way."""
+    from mixq_tensorrt_llm_amd import _lib
+    lib = _lib.load()
+    A, p, layer = _layer(oracle, 4096, 4096, seed=9)
+    x = torch.from_numpy(A[:32]).to("cuda:0")
+    want = layer(x).clone()
+    torch.cuda.synchronize()
+    layer.prepare_decode_batches()
+    try:
+        outs = []
+        for eager_first in (False, True):
+            if eager_first:
+                assert torch.equal(layer(x), want)
+            g = torch.cuda.CUDAGraph()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                with torch.cuda.graph(g, stream=s):
+                    o = layer(x)
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(o, want)
+            outs.append((g, o))
+    finally:
+        layer.prepare_decode_batches(False)

@@ -8,6 +8,7 @@ alternative the table chose between (forced through mixq_debug_set_gemm_variant)
   gemm_pp128_wins    (csrc/gemm_kernels.hip)        128 x 256 tiles (5) | 256 x 256 tiles (2) | automatic (0)
   wo_skinny_pick     (csrc/w8a16_gemm_kernels.hip)  fpA_intB skinny form automatic (850) | off (851); decode 856 | 857 | 858
   wo_wide_plan       (csrc/w8a16_gemm_kernels.hip)  wide-form tile heights 831..834, K split 86..89 | automatic (80, 85)
+  deep_plan_auto     (csrc/gemm_kernels.hip)        mid-M deep form off (1241) | 1 / 2 / 4 / 8 workgroups per 128 x 128 tile (1252 / 1253 / 1255 / 1259), COLD weights
   gemm_takes_skinny  (csrc/gemm_kernels.hip)        decode-batch OPERATOR through mixq_enqueue (quantiser + GEMM; the fragment-major qA
                                                     image): two-barrier tiles (1) | skinny for any N up to 32 rows (892) / up to 64
                                                     rows (897) | small-tile K split off (60) | 1 / 2 feature tiles (895 / 896)
@@ -143,9 +144,9 @@ def main():
         knobs(0, 69)
         alts = {}
         for name, k in (("off", 70), ("s2", 72), ("s4", 74), ("s8", 78)):
-            t, kern = pr.time(79, 69, 0, k)
+            t, kern = pr.time(79, 69, 0, k, 1241)      # (1241: the mid-M deep form off -- this table's own alternatives)
             alts[name] = t
-        auto, kern = pr.time(79, 69, 0)
+        auto, kern = pr.time(79, 69, 0, 1240)
         report("gemm_splitk_plan", f"{M}x{N}x{K}", auto, alts)
         knobs(79, 69, 0)
         del pr
@@ -155,8 +156,8 @@ def main():
         pr = Int8Problem(M, N, K)
         alts = {}
         for name, k in (("off", 70), ("s4", 74), ("s8", 78)):
-            alts[name], _ = pr.time(79, 69, 0, k, cold=True)
-        auto, kern = pr.time(79, 69, 0, cold=True)
+            alts[name], _ = pr.time(79, 69, 0, k, 1241, cold=True)
+        auto, kern = pr.time(79, 69, 0, 1240, cold=True)
         report("splitk_plan (cold)", f"{M}x{N}x{K}", auto, alts)
         knobs(79, 69, 0)
         del pr
@@ -167,9 +168,9 @@ def main():
         pr = Int8Problem(M, N, K)
         alts = {}
         for name, k in (("128x256", 5), ("256x256", 2), ("tiles", 1)):
-            knobs(70)                      # (compare the tile shapes themselves: no K split over workgroups)
+            knobs(70, 1241)                # (compare the tile shapes themselves: no K split over workgroups, no deep form)
             alts[name], _ = pr.time(k)
-        knobs(79, 69)
+        knobs(79, 69, 1240)
         auto, kern = pr.time(0)
         alts["auto-form"] = auto
         report("gemm_pp128_wins", f"{M}x{N}x{K}", auto, alts)
@@ -201,6 +202,21 @@ def main():
         alts["narrow"] = pr.time(841, 851, 81)[0]
         auto, _ = pr.time()
         report("wo_wide_plan", f"{M}x{N}x{K}", auto, alts)
+        del pr
+    # ---- 4b. deep_plan_auto (csrc/gemm_kernels.hip): the mid-M deep form's table, COLD weights, one probe inside every row and one next to it ----
+    deep = [(256, 12288, 4096), (192, 11008, 4096), (256, 4096, 11008), (384, 4096, 11008), (384, 1024, 28672), (256, 3584, 8192),
+            (768, 4096, 4096), (448, 4608, 3584), (384, 12288, 4096), (640, 4096, 11008), (128, 12288, 4096), (256, 5120, 5120)]
+    for M, N, K in (deep[::2] if a.quick else deep):
+        pr = Int8Problem(M, N, K)
+        alts = {}
+        for name, k in (("form-off", 1241), ("x1", 1252), ("x2", 1253), ("x4", 1255), ("x8", 1259)):
+            LIB.mixq_debug_reset()
+            t, kern = pr.time(k, cold=True)
+            if name == "form-off" or "DEEP" in kern:
+                alts[name] = t
+        LIB.mixq_debug_reset()
+        auto, kern = pr.time(cold=True)
+        report("deep_plan_auto", f"{M}x{N}x{K}", auto, alts)
         del pr
     # ---- 5. gemm_takes_skinny: the decode-batch operator through mixq_enqueue ---------------------------------------------------
     from mixq_tensorrt_llm_amd._lib import TensorDesc

@@ -32,7 +32,7 @@ def steady(fn, secs):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-def mid(secs):
+def mid(secs, all_shapes=False):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from mixq_tensorrt_llm_amd import _lib
     lib = _lib.load()
@@ -42,12 +42,15 @@ def mid(secs):
     scr = torch.zeros(int(lib.mixq_gemm_scratch_bound()) + (1 << 20), dtype=torch.uint8, device=dev)
     O = 128
     print("# us per launch, steady state; vendor = torch._int_mm (int32 out, no epilogue, no outlier product); mixq = the fused GEMM")
-    for (N, K) in [(12288, 4096), (11008, 4096), (4096, 11008)]:
+    shapes = [(12288, 4096), (11008, 4096), (4096, 11008)]
+    if all_shapes:   # every (N, K) of BASELINE.json's configs: + Qwen2-7B and one GPU's shard of Llama-2-70B at TP = 8
+        shapes += [(4608, 3584), (18944, 3584), (3584, 18944), (1280, 8192), (3584, 8192), (1024, 28672)]
+    for (N, K) in shapes:
         W = torch.randint(-127, 128, (N, K), dtype=torch.int8, device=dev, generator=g)
         Ws = [W] + [W.clone() for _ in range((320 << 20) // (N * K) + 1)]
         sW = (torch.rand(N, device=dev, generator=g) * 4e-4 + 4e-4).to(torch.float16)
         fpW = (torch.randn((N, O), device=dev, generator=g) * 0.02).to(torch.float16)
-        for M in (96, 128, 256, 512, 1024):
+        for M in ((64, 96, 128, 192, 256, 384, 512, 768, 1024) if all_shapes else (96, 128, 256, 512, 1024)):
             qA = torch.randint(-127, 128, (M, K), dtype=torch.int8, device=dev, generator=g)
             sA = (torch.rand(M, device=dev, generator=g) * 0.05 + 0.01).to(torch.float16)
             fpA = torch.randn((M, O), device=dev, generator=g).to(torch.float16)
@@ -82,9 +85,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--mid", action="store_true")
     ap.add_argument("--secs", type=float, default=0.25)
+    ap.add_argument("--all", action="store_true", help="--mid on all nine BASELINE (N, K), 64..1024 rows")
     a = ap.parse_args()
     if a.mid:
-        return mid(a.secs)
+        return mid(a.secs, a.all)
     for (M, N, K) in [(8192, 12288, 4096), (8192, 11008, 4096), (8192, 4096, 11008), (65536, 12288, 4096)]:
         a_ = torch.randint(-20, 21, (M, K), dtype=torch.int8, device=dev)
         b = torch.randn((N, K), device=dev).mul_(32).round_().clamp_(-127, 127).to(torch.int8)
