@@ -216,6 +216,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KG * 64) void gemm_w8a8o16_kernel
     for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
         if (s0 * KG + group < nk) stage(s0, s0 * KG + group);
     const int nit = (nk + KG - 1) / KG;
+    const bool late_issue = ADMA && KG == 1 && NWAVES >= 8 && wave >= NWAVES / 2 && !(p.flags & 1);
     for (int it = 0; it < nit; ++it) {
         const int kt = it * KG + group;
         // copies complete in order: at most the (NSTAGE-2) younger slices may still be in flight once slice kt landed
@@ -225,7 +226,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KG * 64) void gemm_w8a8o16_kernel
         __syncthreads(); // slice kt has landed for every wave; everyone is done reading the previous slice's buffer
         // (all copies of slice it + NSTAGE - 1 at once, as early as possible: spreading them over the four k-steps -- which
         //  pays in the fpA_intB wide form -- measured +4..+8 % here on wide / long-K shapes, -3 % on 4096 x 4096: round 2)
-        if ((it + NSTAGE - 1) * KG + group < nk) stage((it + NSTAGE - 1) % NSTAGE, (it + NSTAGE - 1) * KG + group);
+        // ADMA with two waves per SIMD: the waves of the second half issue their copies AFTER their MFMAs, so that on every SIMD one
+        // wave multiplies while the other sits in the 100..200-cycle issue stall of each LDS-DMA instruction (the poor man's ping-pong;
+        // same counts per wave, so the vmcnt bookkeeping above is unchanged; the target buffer was last read one barrier ago)
+        const bool do_stage = (it + NSTAGE - 1) * KG + group < nk;
+        if (do_stage && !late_issue) stage((it + NSTAGE - 1) % NSTAGE, (it + NSTAGE - 1) * KG + group);
         if (KG > 1 && kt >= nk) continue; // (K groups past the end only keep the barrier count)
         const char* base = smem + (it % NSTAGE) * STAGE_BYTES;
 #pragma unroll
@@ -242,6 +247,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KG * 64) void gemm_w8a8o16_kernel
 #pragma unroll
                 for (int j = 0; j < TM; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xf[i], yf[j], acc[i][j], 0, 0, 0);
+        }
+        if (do_stage && late_issue) {
+            __builtin_amdgcn_sched_barrier(0); // (the copies stay behind the slice's MFMAs)
+            stage((it + NSTAGE - 1) % NSTAGE, (it + NSTAGE - 1) * KG + group);
         }
     }
 
@@ -485,6 +494,7 @@ size_t gemm_xsplit_workspace_bound() { return kSplitkWordsBytes + (size_t)256 * 
 // puts (about) one workgroup of a 128 x 128 tile on every CU -- the tiles alone where there are enough of them, 2 / 4 / 8 workgroups
 // per tile along K otherwise -- and keeps three slices in flight behind the one being multiplied.  Same int32 sums, same epilogue.
 struct DeepPlan;
+static std::atomic<int> g_deep_late{1}; // measurement knob 1238 (default) / 1239: the second half of the waves issue their copies after / before their MFMAs
 static std::atomic<int> g_deep_force{-1}; // -1 automatic, 0 off, 1 / 2 / 4 / 8: forced workgroups per tile (knobs 1240 / 1241 + xs); + 10: the 8-wave build
 struct DeepPlan {
     int xs;    // 0 = not used; workgroups per 128 x 128 tile otherwise
@@ -549,6 +559,7 @@ static hipError_t launch_deep_epi(const GemmParams& p, hipStream_t st)
     const DeepPlan pl = deep_plan(p.M, p.N, p.K);
     GemmParams q = p;
     q.xsplit = pl.xs;
+    q.flags = g_deep_late.load() ? 0 : 1;
     if (pl.waves8 == 2) { // five stages = the whole 160 KiB of LDS: four slices in flight
         if (pl.xs > 1) return launch_cfg<128, 128, 2, 4, EPI, 5, 1, false, true, true>(q, st);
         return launch_cfg<128, 128, 2, 4, EPI, 5, 1, false, false, true>(q, st);
@@ -635,6 +646,10 @@ bool qa_frag_enabled() { return g_qa_frag.load() != 0; }
 
 void set_gemm_variant(int v)
 {
+    if (v == 1238 || v == 1239) {
+        g_deep_late.store(v == 1238);
+        return;
+    }
     if (v >= 1240 && v <= 1269) { // mid-M deep form: 1240 automatic, 1241 off, 1241 + xs (1242 / 1243 / 1245 / 1249) forced, + 10 the 8-wave build
         set_deep_force(v == 1240 ? -1 : v - 1241);
         return;

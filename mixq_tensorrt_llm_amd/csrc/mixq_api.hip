@@ -148,7 +148,7 @@ void mixq_debug_reset(void)
     mixq::set_quant_stamp_buffer(nullptr);
     for (int v : {-1 /* schedule (back to the MIXQ_GEMM_VARIANT default), tile configuration, skinny K width */, 79 /* K splits over workgroups automatic */, 69, 65, 91,
                   80 /* fpA_intB forms automatic */, 85, 840, 843, 848 /* non-temporal loads of large weights on */, 850, 858, 891 /* fragment-major qA on */, 893 /* skinny range: the rule */,
-                  894 /* feature tiles automatic */, 880 /* skinny-GEMM weight image off */, 1240 /* mid-M deep form automatic */})
+                  894 /* feature tiles automatic */, 880 /* skinny-GEMM weight image off */, 1240 /* mid-M deep form automatic */, 1238})
         mixq::set_gemm_variant(v);
     set_int4_stream(1);
 }
@@ -308,10 +308,11 @@ static size_t enqueue_scratch_bytes(int64_t M, int64_t N, int64_t K)
     if (!a) a = mixq::gemm_xsplit_workspace_size((int)M, (int)N, (int)K);
     return d > a ? d : a;
 }
-// Largest exchange scratch mixq_enqueue can carve with these N, K and ANY M <= maxM.  The plans (gemm_splitk_plan incl. its
-// gemm_pp128_wins gate, xsplit_plan) see M only through ceil(M / 32 | 64 | 128 | 256) and the thresholds 4 / 16 / 32 / 128 /
-// 255, and are not monotone in M, so every 32-row step is probed at its right end (where all those ceilings are constant
-// over the step) plus the thresholds; N <= 0 or a huge maxM: the shape-independent bound.
+// Largest exchange scratch mixq_enqueue can carve with these N, K and ANY M <= maxM.  The plans (gemm_splitk_plan, xsplit_plan,
+// deep_plan_auto) see M mostly through ceil(M / 32 | 64 | 128 | 256) and the thresholds 4 / 16 / 32 / 128 / 256, and are not monotone
+// in M, so every 32-row step is probed at its right end (where those ceilings are constant over the step) plus the thresholds --
+// and, because gemm_pp128_wins weighs 129..256 rows by M itself, EVERY M of that range; N <= 0 or a huge maxM: the
+// shape-independent bound.
 static size_t enqueue_scratch_bound(int64_t maxM, int64_t N, int64_t K)
 {
     if (maxM <= 4) return 0;
@@ -328,6 +329,7 @@ static size_t enqueue_scratch_bound(int64_t maxM, int64_t N, int64_t K)
         if (b > best) best = b;
     };
     for (int64_t m : {5, 8, 16, 17}) probe(m);
+    for (int64_t m = 129; m <= 256 && m <= maxM; ++m) probe(m);
     for (int64_t t = 1; t <= steps; ++t) probe(t * 32 < maxM ? t * 32 : maxM);
     probe(maxM);
     return best;
@@ -910,7 +912,7 @@ static int enqueue_impl(const mixq_handle* h, const mixq_tensor_desc* inputDesc,
 
         // Mid-size and small problems split K over several workgroups per tile, which hand their partial sums over
         // through scratch behind fpA (gemm_pp_kernels.hip, gemm_kernels.hip).  mixq_workspace_size reserves the 256x256
-        // form's scratch from 256 rows on and the small-tile form's below that.  The hand-over words at its start are
+        // form's scratch from 129 rows on where its plan applies (the mid-M deep form's where its table does), the small-tile form's otherwise.  The hand-over words at its start are
         // cleared on every call -- the workspace is shared with whatever else the engine runs -- by the quantiser, which
         // runs one launch earlier anyway.
         hipStream_t st = static_cast<hipStream_t>(stream);

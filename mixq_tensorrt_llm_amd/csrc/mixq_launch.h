@@ -79,6 +79,7 @@ struct GemmParams {
     int b_frag;           // (set by the skinny launcher from b_image, a_frag == 1 only) layout of B: 0 row-major [N,K] | 1 fragment-major image
                           // (1-KiB blocks [16-feature tile][64-byte k-step], lane l = feature % 16 + 16 * (k / 16 % 4) at l * 16) | 2 the same, non-temporal loads
     void* dbg;            // measurement only: 8 x uint64 s_memtime stamps per block (ping-pong kernel), else null
+    int flags;            // (set by launch_gemm_deep) bit 0: measurement -- every wave issues its slice copies before its MFMAs
     int xsplit;           // (set by launch_epi) workgroups per tile of the small-tile kernels' K split, else 0
     int splitk_solo;      // (set by launch_gemm_pp_splitk) leading tiles that are not split
     unsigned splitk_patience; // (set by launch_gemm_pp_splitk) wall-clock ticks a workgroup waits for its partners before

@@ -720,7 +720,8 @@ typedef float v4f_ __attribute__((ext_vector_type(4)));
 // calls on 45-50 MB of weights -3.5..-4.4 %; 16.8 MB of weights +2.4 % cold; and +25..30 % for a loop that re-reads ONE layer (the
 // Infinity Cache serves such a loop, the hint gives that up).  Hence only for weights of wo_nt_weight_bytes() (32 MiB) and more: a
 // model with layers that large streams them from HBM once per step whatever the policy.  The int8 decode-batch GEMM measured +2 %
-// with the same hint and keeps plain loads.
+// with the same hint on the row-major weight and keeps plain loads THERE; its registered weight images of 32 MiB and more (WFRAG == 2,
+// gemm_skinny_kernels.hip) and the packed-int4 stream (int4_gemm_kernels.hip) do use non-temporal loads.
 template <int MT, int KW, int CG, bool NTW = false>
 __global__ __launch_bounds__(KW * 64) void w8a16_skinny_kernel(const uint16_t* __restrict__ A, const uint8_t* __restrict__ Wq,
                                                                 const uint16_t* __restrict__ scale,

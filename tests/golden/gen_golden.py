@@ -233,5 +233,14 @@ def pflavour_fixture():
     np.savez_compressed(os.path.join(OUT, "pflavour_small.npz"), **blob)
 
 
+def write_meta():
+    import json
+    json.dump({"torch": torch.__version__,
+               "note": "the tie ORDER of fp_ind in act_scales_llama.npz / model_walk.npz is that of this build's (unstable) torch.sort on CPU -- "
+                       "the reference's own call; tests compare the order only under the same torch version and column SETS otherwise"},
+              open(os.path.join(OUT, "META.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
+    write_meta()
     main()
