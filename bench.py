@@ -866,6 +866,29 @@ def main():
                 res["small_m"] = small_m_points(lib, TensorDesc, dev, gen, st_ptr)
         except Exception as e:  # noqa: BLE001
             res["small_m"] = {"error": repr(e)}
+        try:  # BASELINE configs[0] in one place, both routes (VERDICT r4 #1c), with the algorithmic bytes each is priced against
+            sm_ = res.get("small_m", {})
+            c0, c0n = sm_.get("config0_bs32_4096x4096"), sm_.get("config0_norm_fused")
+            if c0 and "us_per_call" in c0:
+                M0, N0, K0 = 32, 4096, 4096
+                alg = N0 * K0 + 2 * M0 * K0 + 2 * M0 * N0 + 2 * N0 * (1 + NUM_OUTLIERS)   # W + A in + Out + sW + fp_weight
+                res["config0"] = {
+                    "workload": "single 4096 x 4096 MixQ linear, bs = 32, int8_mix (BASELINE configs[0])", "algorithmic_bytes": alg,
+                    "hbm_floor_us": alg / 8e12 * 1e6,
+                    "t_flavour_two_launches": {"us_warm": c0["us_per_call"], "us_cold": (c0.get("cold") or {}).get("us_per_call"),
+                                               "hbm_frac_warm": alg / (c0["us_per_call"] * 1e-6) / 8e12,
+                                               "with_weight_image_us_warm": (c0.get("with_weight_image") or {}).get("us_per_call"),
+                                               "with_weight_image_us_cold": (c0.get("with_weight_image") or {}).get("cold_us_per_call"),
+                                               "what": "mixq_enqueue as the plugin runs it: quantise + extract (launch 1), fused GEMM (launch 2)"},
+                    "p_flavour_norm_fused": None if not c0n or "us_per_call" not in c0n else {
+                        "us_marginal": c0n["us_per_call"], "hbm_frac": alg / (c0n["us_per_call"] * 1e-6) / 8e12,
+                        "what": "the RMSNorm in front quantises in its own pass (mixq_rmsnorm_extract_quant): the linear is ONE launch"},
+                    "floor_of_two_launches": "two launches of trivial kernels of these grids cost 5.5 us here, + the quantiser's 2 us of work (row load -> "
+                                             "amax -> stores on 32 of 256 CUs) 7.2, + a 16-MB weight stream that cannot start before the second launch: "
+                                             "8-8.5 us (profiles/r03_concurrent_probe.txt, r03_small_m_timeline.txt); the one-launch builds measured 11.8-15.9 us",
+                    "cpu_reference_us": None}
+        except Exception as e:  # noqa: BLE001
+            res["config0"] = {"error": repr(e)}
         if world == 1 and not args.no_decode_step:
             try:
                 res["decode_step"] = decode_step_points(lib, TensorDesc, model, dev, gen)
@@ -946,6 +969,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline()
+                if isinstance(res.get("config0"), dict) and "error" not in res["config0"]:
+                    res["config0"]["cpu_reference_us"] = res["cpu_baseline"].get("config0_bs32_4096x4096", {}).get("us_per_call")
             except Exception as e:  # the checker failing must not hide the measurement
                 res["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {e}"}

@@ -510,7 +510,8 @@ struct DeepPlan {
 //   tiles  36..64,  K 8192..20480       -> 4                          (4096 x 11008 at 129..256 rows: 35.4 -> 30.9 us)
 //   tiles  20..32,  K >= 25600          -> 8                          (1024 x 28672 at 257..512 rows: 46.1 -> 34.1 us)
 // Everywhere else it is level or behind (the ping-pong tiles multiply a slice in less than half the time per CU; warm weights:
-// level) and is not used.  8 waves x (64 x 32) beat 4 waves x (64 x 64) in every cell; a fifth LDS stage changed nothing.
+// level) and is not used.  8 waves x (64 x 32) beat 4 waves x (64 x 64) in every cell; a fifth LDS stage changed nothing, neither did
+// 16 waves x (32 x 32); the same loop on 128 x 256 tiles is behind the ping-pong kernel of that tile (profiles/r05_deep_form_builds.txt).
 static DeepPlan deep_plan_auto(int M, int N, int K, int tiles, int nk)
 {
     (void)N, (void)K;
@@ -521,7 +522,9 @@ static DeepPlan deep_plan_auto(int M, int N, int K, int tiles, int nk)
     const int64_t wg64 = (int64_t)((M + 63) / 64) * ((N + 63) / 64);
     if (tiles >= 140 && tiles <= 256 && nk >= 24 && nk <= 40 && wg64 > 512) return DeepPlan{1, tiles, 1}; // (measured at K = 3584 .. 5120 only)
     if (M <= 128) return DeepPlan{0, 0, 0};
-    if (tiles >= 70 && tiles <= 128 && nk >= 40 && nk <= 100) return DeepPlan{2, tiles, 1};
+    // (second row at K < 8192 only past 256 tiles of 64 x 64: one workgroup per CU of those with K split four ways inside it is
+    //  ahead below -- 160 / 192 x 5120 x 5120: 20.0 / 20.9 vs 23.1 / 23.5 us, profiles/r05_int8_forms_cold.jsonl)
+    if (tiles >= 70 && tiles <= 128 && nk >= 40 && nk <= 100 && (nk >= 64 || wg64 > 256)) return DeepPlan{2, tiles, 1};
     if (tiles >= 36 && tiles <= 64 && nk >= 64 && nk <= 160) return DeepPlan{4, tiles, 1};
     if (M > 256 && tiles >= 20 && tiles <= 32 && nk >= 200) return DeepPlan{8, tiles, 1};
     return DeepPlan{0, 0, 0};

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--Ms", default="96,128,192,256,384,512,1024")
     ap.add_argument("--shapes", default="12288 4096;11008 4096;4096 11008;4096 4096")
     ap.add_argument("--only", default="", help="comma list of variant names to time (auto, plain, c0..c23, pp128, pp256, s2, s4, s8); default all but plain")
+    ap.add_argument("--dump", default="", help="append one JSON line per cell with EVERY variant's time and kernel to this file")
     ap.add_argument("--cold", action="store_true", help="cycle through > 320 MiB of weight copies: every launch streams its weights from HBM")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -33,6 +34,7 @@ def main():
     variants = [("auto", [0, 79, 69])] + [(f"c{i}", [70, 60, 10 + i]) for i in range(24)] + \
                [("pp128", [70, 60, 5]), ("pp256", [70, 60, 2]), ("s2", [0, 72]), ("s4", [0, 74]), ("s8", [0, 78])] + \
                [(f"d{x}", [0, 1241 + x]) for x in (1, 2, 4, 8)] + [(f"e{x}", [0, 1251 + x]) for x in (1, 2, 4, 8)] + [(f"f{x}", [0, 1261 + x]) for x in (1, 2, 4, 8)] + [(f"g{x}", [0, 1251 + x, 1239]) for x in (1, 2, 4, 8)]   # g = e with every wave issuing its copies before its MFMAs   # mid-M deep form (128 x 128, 4 stages in flight): 4- / 8-wave builds, x workgroups per tile
+    variants += [(f"xs{x}", [1, 70, 1241, 60 + (6 if x == 16 else x)]) for x in (2, 4, 8, 16)]   # two-barrier small tiles, K split over x workgroups
     if a.only:
         variants = [v for v in variants + [("plain", [0, 70]), ("nodeep", [0, 1241])] if v[0] in a.only.split(",")]   # nodeep = automatic with the mid-M deep form off   # plain = automatic with the 256 x 256 K split off
     for shape in a.shapes.split(";"):
@@ -54,6 +56,8 @@ def main():
                     lib.mixq_debug_set_gemm_variant(k)
                 nscr = int(lib.mixq_gemm_scratch_size(M, N, K))
                 if name in ("s2", "s4", "s8") and nscr == 0:
+                    continue
+                if name.startswith("xs") and nscr == 0:
                     continue
                 if name[0] in "defg" and name[1:].isdigit() and (nscr > scr.numel() or (nscr == 0 and name[1:] != "1")):
                     continue
@@ -83,6 +87,10 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 res[name] = (e0.elapsed_time(e1) / n * 1e3, kern)
+            if a.dump:
+                import json
+                with open(a.dump, "a") as f:
+                    f.write(json.dumps({"M": M, "N": N, "K": K, "cold": bool(a.cold), "t": {k: [round(v[0], 2), v[1]] for k, v in res.items()}}) + "\n")
             best = min(res.items(), key=lambda kv: kv[1][0])
             auto = res["auto"]
             top = sorted(res.items(), key=lambda kv: kv[1][0])[:5]
