@@ -203,6 +203,9 @@ def small_m_points(lib, TensorDesc, dev, gen, st_ptr, iters=300):
                     st0 = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
                     for wcopy, im in zip(alts, imgs):
                         assert lib.mixq_weight_image_register(ctypes.c_void_p(wcopy.data_ptr()), N, K, ctypes.c_void_p(im.data_ptr()), st0) == 0
+                        # (an image is trusted after its FIRST USE check, which cannot run inside a stream capture: verify now, or the
+                        #  captured calls on the copies that never ran eagerly would read `weight` itself)
+                        assert lib.mixq_weight_image_verify(ctypes.c_void_p(wcopy.data_ptr()), st0) == 0
                     torch.cuda.synchronize(dev)
                     tw, tcold = graph_time_us(run, dev), graph_time_us(run_cold, dev)
                     out[name]["with_weight_image"] = {"us_per_call": tw, "cold_us_per_call": tcold, "hbm_frac": N * K / (tw * 1e-6) / 8e12,
@@ -322,6 +325,7 @@ def decode_step_points(lib, TensorDesc, model, dev, gen, batches=(1, 4, 32, 64, 
                     N, K = t["weight"].shape[0], ins[0].shape[1]
                     im = torch.empty(N * K, dtype=torch.int8, device=dev)
                     assert lib.mixq_weight_image_register(ctypes.c_void_p(t["weight"].data_ptr()), N, K, ctypes.c_void_p(im.data_ptr()), st0) == 0
+                    assert lib.mixq_weight_image_verify(ctypes.c_void_p(t["weight"].data_ptr()), st0) == 0   # (before the capture: see small_m_points)
                     imgs.append(im)
                 torch.cuda.synchronize(dev)
                 turn[0] = -1

@@ -3,6 +3,9 @@
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 OUT="${HERE}/../libmixq_mi355x.so"
+# one build at a time: two concurrent runs write the same objects (seen once: a library that aborted in its first new kernel)
+exec 9>"${HERE}/.build.lock"
+flock 9
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -fno-fast-math -Wall -Wno-unused-function)
 OBJS=()

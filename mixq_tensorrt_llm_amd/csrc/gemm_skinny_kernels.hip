@@ -112,7 +112,7 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
             if (!FULL) off = min(off + lq * 16, koff_last) - lq * 16;
 #pragma unroll
             for (int c = 0; c < NT; ++c) {
-                if (WFRAG != 0) { // W from its registered fragment-major image (weight_image_kernel below): one contiguous 1-KiB read of
+                if (WFRAG == 1 || WFRAG == 2) { // W from its registered fragment-major image (weight_image_kernel below): one contiguous 1-KiB read of
                                   // whole cache lines per load instead of 64 bytes of 16 rows K bytes apart; WFRAG == 2: non-temporal
                     const int8_t* src = p.B + ((int64_t)(min((n0 >> 4) + c, (p.N >> 4) - 1) * nsteps + su) << 10) + lane * 16; // (clamped tiles are computed, never stored)
                     if (WFRAG == 2) wf[u][c] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(src));
@@ -148,11 +148,65 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
         }
     };
     dbg_stamp(p.dbg, 1); // epilogue operands requested
-    for (int s = s_begin; s < s_end; s += STEPS) {
-        const int cnt = min(STEPS, s_end - s);
-        if (cnt == STEPS && !(ktail && s + STEPS == nsteps)) do_steps(s, cnt, std::true_type{});
-        else do_steps(s, cnt, std::false_type{});
-        if (s == s_begin) dbg_stamp(p.dbg, 2); // first batch: first weight / qA data arrived and multiplied
+    if constexpr (WFRAG == 3) {
+        // ROW-MAJOR weight in whole 256-byte runs (round 5, R5.8).  The plain fragment load above takes 64 bytes of 16 rows per
+        // instruction: every 256-byte DRAM chunk of the weight is asked for in four pieces by four different instructions, and a
+        // cold stream of such pieces ran at ~3.5 TB/s against ~4.5 from a registered image (1-KiB reads) in the SAME kernel
+        // (profiles/r05_stream_form_probe.txt, timelines).  Here an instruction reads 4 rows x 256 contiguous bytes (lane l: row
+        // 4 rg + l / 16, 16-byte chunk l % 16), and the four registers of a 256-byte group (rg = 0..3) become the group's four MFMA
+        // fragments through a WAVE-PRIVATE 4-KiB LDS tile: ds_write_b128 at [row][chunk ^ row], ds_read_b128 of (row l % 16, chunk
+        // 4 s' + l / 16) -- both conflict-free (16 consecutive lanes touch 16 different 16-byte slots of the 256-byte bank row),
+        // no barrier (the LDS operations of one wave execute in order).  K % 256 == 0 (host-checked); the wave's K range is counted
+        // in 256-byte groups; a group past the range re-reads the last valid one with zeroed fragments.
+        static_assert(NT == 1 && KW == 4 && ABL == 0, "the transposing route: one feature tile, four K parts");
+        __shared__ v4i tr[KW][256];
+        constexpr int GB = MT <= 2 ? 2 : 1; // groups per batch (4 k-steps each)
+        const int ngroups = p.K >> 8;
+        const int gper = (ngroups + KW - 1) / KW;
+        const int g_begin = min(wave * gper, ngroups), g_end = min(g_begin + gper, ngroups);
+        const int lrow = lane >> 4, lch = lane & 15;
+        const int8_t* wl[4];
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) wl[rg] = p.B + (int64_t)min(n0 + 4 * rg + lrow, p.N - 1) * K + lch * 16;
+        v4i* const mytr = tr[wave];
+        for (int g0 = g_begin; g0 < g_end; g0 += GB) {
+            const int cnt = min(GB, g_end - g0);
+            v4i wr[GB][4], af[GB * 4][MT];
+#pragma unroll
+            for (int gi = 0; gi < GB; ++gi) {
+                const int gg = min(g0 + gi, g0 + cnt - 1); // (wave-uniform)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) wr[gi][rg] = *reinterpret_cast<const v4i*>(wl[rg] + gg * 256);
+#pragma unroll
+                for (int sp = 0; sp < 4; ++sp)
+#pragma unroll
+                    for (int t = 0; t < MT; ++t)
+                        af[gi * 4 + sp][t] = AFRAG ? *reinterpret_cast<const v4i*>(p.A + ((int64_t)(t * nsteps + gg * 4 + sp) << 10) + lane * 16)
+                                                   : *reinterpret_cast<const v4i*>(arow[t] + (gg * 4 + sp) * 64);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int gi = 0; gi < GB; ++gi) {
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) mytr[(4 * rg + lrow) * 16 + (lch ^ (4 * rg + lrow))] = wr[gi][rg];
+#pragma unroll
+                for (int sp = 0; sp < 4; ++sp) {
+                    v4i w = mytr[lr * 16 + ((4 * sp + lq) ^ lr)];
+                    if (gi >= cnt) w = zero4;
+#pragma unroll
+                    for (int t = 0; t < MT; ++t)
+                        acc[0][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w, af[gi * 4 + sp][t], acc[0][t], 0, 0, 0);
+                }
+            }
+            if (g0 == g_begin) dbg_stamp(p.dbg, 2);
+        }
+    } else {
+        for (int s = s_begin; s < s_end; s += STEPS) {
+            const int cnt = min(STEPS, s_end - s);
+            if (cnt == STEPS && !(ktail && s + STEPS == nsteps)) do_steps(s, cnt, std::true_type{});
+            else do_steps(s, cnt, std::false_type{});
+            if (s == s_begin) dbg_stamp(p.dbg, 2); // first batch: first weight / qA data arrived and multiplied
+        }
     }
     dbg_stamp(p.dbg, 3); // last MFMA issued
 
@@ -289,6 +343,8 @@ hipError_t launch_weight_image(const int8_t* W, int8_t* img, int N, int K, hipSt
 }
 
 static std::atomic<int> g_skinny_wfrag{0}; // knob 880 automatic | 881 images with plain loads | 882 with non-temporal loads | 883 images ignored
+static std::atomic<int> g_skinny_wrows{1}; // knob 884 / 885: row-major weights in 256-byte runs through the wave-private LDS transposition on (default) / off
+void set_skinny_wrows(int on) { g_skinny_wrows.store(on); }
 static bool g_skinny_wfrag_off() { return g_skinny_wfrag.load(std::memory_order_relaxed) == 3; }
 
 // Content tag of an int8 [N, K] tensor in EITHER layout: the image is a permutation of the weight's 16-byte chunks, so a sum over
@@ -429,6 +485,9 @@ static hipError_t launch_skinny_kw(const GemmParams& p_in, hipStream_t st)
     if (p.a_frag == 1 && p.b_image != nullptr && mode != 3 && EPI != EPI_INT32 && p.K % 64 == 0 && p.N % 16 == 0) {
         p.B = static_cast<const int8_t*>(p.b_image); // (resolved ONCE per call by the API layer: resolve_weight_image)
         p.b_frag = mode == 1 ? 1 : mode == 2 ? 2 : ((int64_t)p.N * p.K >= ((int64_t)32 << 20) ? 2 : 1);
+    } else if (KW == 4 && ABL == 0 && EPI != EPI_INT32 && p.K % 256 == 0 && g_skinny_wrows.load(std::memory_order_relaxed) != 0 &&
+               (p.a_frag == 0 || skinny_feature_tiles(p.M, p.N, p.K) == 1)) {
+        p.b_frag = 3; // row-major weight, 256-byte runs (WFRAG == 3)
     }
     return launch_skinny_kw_impl<EPI, KW, ABL>(p, st);
 }
@@ -436,6 +495,12 @@ static hipError_t launch_skinny_kw(const GemmParams& p_in, hipStream_t st)
 template <int MT, int EPI, int KW, int NT>
 static hipError_t launch_skinny_frag(const GemmParams& p, dim3 grid, dim3 block, hipStream_t st)
 {
+    if constexpr (NT == 1 && KW == 4) {
+        if (p.b_frag == 3) {
+            hipLaunchKernelGGL((gemm_skinny_kernel<MT, EPI, KW, 0, true, NT, 3>), grid, block, 0, st, p);
+            return hipGetLastError();
+        }
+    }
     if (p.b_frag == 1) hipLaunchKernelGGL((gemm_skinny_kernel<MT, EPI, KW, 0, true, NT, 1>), grid, block, 0, st, p);
     else if (p.b_frag == 2) hipLaunchKernelGGL((gemm_skinny_kernel<MT, EPI, KW, 0, true, NT, 2>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((gemm_skinny_kernel<MT, EPI, KW, 0, true, NT>), grid, block, 0, st, p);
@@ -460,6 +525,17 @@ static hipError_t launch_skinny_kw_impl(const GemmParams& p, hipStream_t st)
         }
     }
     if (p.a_frag != 0) return hipErrorInvalidValue;
+    if constexpr (KW == 4 && ABL == 0 && EPI != EPI_INT32) {
+        if (p.b_frag == 3) { // row-major qA, row-major weight in 256-byte runs
+            switch (mt) {
+            case 1: hipLaunchKernelGGL((gemm_skinny_kernel<1, EPI, KW, 0, false, 1, 3>), grid, block, 0, st, p); break;
+            case 2: hipLaunchKernelGGL((gemm_skinny_kernel<2, EPI, KW, 0, false, 1, 3>), grid, block, 0, st, p); break;
+            case 3: hipLaunchKernelGGL((gemm_skinny_kernel<3, EPI, KW, 0, false, 1, 3>), grid, block, 0, st, p); break;
+            default: hipLaunchKernelGGL((gemm_skinny_kernel<4, EPI, KW, 0, false, 1, 3>), grid, block, 0, st, p); break;
+            }
+            return hipGetLastError();
+        }
+    }
     switch (mt) {
     case 1: hipLaunchKernelGGL((gemm_skinny_kernel<1, EPI, KW, ABL>), grid, block, 0, st, p); break;
     case 2: hipLaunchKernelGGL((gemm_skinny_kernel<2, EPI, KW, ABL>), grid, block, 0, st, p); break;

@@ -22,6 +22,7 @@
 // (mixq_unpack_int4_to_int8) and passes it to mixq_int4_fused_dequantize_w8 (include/mixq.h).
 #include "mixq_device.h"
 #include "mixq_launch.h"
+#include <atomic>
 #include <type_traits>
 
 namespace mixq {
@@ -37,7 +38,12 @@ __device__ __forceinline__ void widen_s4x16(const v4i w, v4i& even, v4i& odd)
     }
 }
 
-template <int MT, int EPI, int KW, bool NTW>
+// WROWS (round 5, R5.8, the int8 twin's WFRAG == 3): the packed weight is read in whole 256-byte runs -- a load instruction takes
+// 4 rows x 256 contiguous bytes (lane l: row 4 rg + l / 16, 16-byte chunk l % 16) instead of 64 bytes of 16 rows -- and a
+// wave-private 4-KiB LDS tile ([row][chunk ^ row], conflict-free both ways, no barrier: one wave's LDS operations execute in
+// order) turns the four registers of a 256-byte group into the group's four 64-byte fragments.  A partial last group (packed row
+// length not a multiple of 256) reads clamped addresses and zeroes the fragments past the row's end.
+template <int MT, int EPI, int KW, bool NTW, bool WROWS = false>
 __global__ __launch_bounds__(KW * 64) void gemm_skinny_s4_kernel(const GemmParams p)
 {
     __shared__ v4i part[KW][MT][64]; // [K part][m tile][lane]
@@ -112,7 +118,60 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_s4_kernel(const GemmParam
             }
         }
     };
-    {
+    if constexpr (WROWS) {
+        static_assert(KW == 4, "four K parts");
+        __shared__ v4i tr[KW][256];
+        constexpr int GB = MT <= 2 ? 2 : 1; // 256-byte groups (4 k-steps each) per batch
+        const int ngroups = (p.K + 255) >> 8;
+        const int gper = (ngroups + KW - 1) / KW;
+        const int g_begin = min(wave * gper, ngroups), g_end = min(g_begin + gper, ngroups);
+        const int lrow = lane >> 4, lch = lane & 15;
+        const int8_t* wl[4];
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) wl[rg] = p.B + (int64_t)min(n0 + 4 * rg + lrow, p.N - 1) * KB;
+        v4i* const mytr = tr[wave];
+        for (int g0 = g_begin; g0 < g_end; g0 += GB) {
+            const int cnt = min(GB, g_end - g0);
+            v4i wr[GB][4], af[GB * 4][MT];
+#pragma unroll
+            for (int gi = 0; gi < GB; ++gi) {
+                const int gg = min(g0 + gi, g0 + cnt - 1); // (wave-uniform)
+                const int woff = min(gg * 256 + lch * 16, koff_last);
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    if (NTW) wr[gi][rg] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(wl[rg] + woff));
+                    else wr[gi][rg] = *reinterpret_cast<const v4i*>(wl[rg] + woff);
+                }
+#pragma unroll
+                for (int sp = 0; sp < 4; ++sp) {
+                    const int off = min((gg * 4 + sp) * 64 + lq * 16, koff_last) - lq * 16;
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) af[gi * 4 + sp][t] = *reinterpret_cast<const v4i*>(arow[t] + off);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0); // every load of the batch is issued before the first MFMA
+#pragma unroll
+            for (int gi = 0; gi < GB; ++gi) {
+                const int gg = min(g0 + gi, g0 + cnt - 1);
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) mytr[(4 * rg + lrow) * 16 + (lch ^ (4 * rg + lrow))] = wr[gi][rg];
+#pragma unroll
+                for (int sp = 0; sp < 4; ++sp) {
+                    v4i w = mytr[lr * 16 + ((4 * sp + lq) ^ lr)];
+                    if (gi >= cnt || (gg * 4 + sp) * 64 + lq * 16 >= p.K) w = zero4; // (a zero weight operand: zero product)
+                    v4i we, wo;
+                    widen_s4x16(w, we, wo);
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) {
+                        v4i ae, ao;
+                        widen_s4x16(af[gi * 4 + sp][t], ae, ao);
+                        acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(we, ae, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wo, ao, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    } else {
         const int s_full = ktail && s_end == nsteps ? s_end - 1 : s_end; // steps [s_begin, s_full) are whole
         int s = s_begin;
         for (; s + SMAX <= s_full; s += SMAX) do_steps(s, SMAX, std::integral_constant<int, SMAX>{}, std::true_type{});
@@ -160,10 +219,25 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_s4_kernel(const GemmParam
     }
 }
 
+static std::atomic<int> g_s4_wrows{1}; // knob 872 automatic (default) / 873 off / 874 always
+void set_s4_wrows(int mode) { g_s4_wrows.store(mode); }
+
 template <int EPI, bool NTW>
 static hipError_t launch_skinny_s4_cfg(const GemmParams& p, hipStream_t st)
 {
     const dim3 grid((unsigned)((p.N + 15) / 16)), block(4 * 64);
+    // measured cold (profiles/r05_int4_stream_bench.txt, 256-byte runs vs 64-byte fragment loads): 12288 x 4096 at 8 / 32 rows 6.6 / 10.3 vs
+    // 7.1 / 11.0 us, 4096 x 11008 at 32 / 64 rows 10.4 / 15.4 vs 11.0 / 16.9; level or behind at 1 row and on an 8-MiB weight (4096 x 4096)
+    const int wr = g_s4_wrows.load(std::memory_order_relaxed);
+    if (p.K >= 256 && (wr == 2 || (wr == 1 && p.M > 4 && (int64_t)p.N * p.K >= ((int64_t)16 << 20)))) {
+        switch ((p.M + 15) / 16) {
+        case 1: hipLaunchKernelGGL((gemm_skinny_s4_kernel<1, EPI, 4, NTW, true>), grid, block, 0, st, p); break;
+        case 2: hipLaunchKernelGGL((gemm_skinny_s4_kernel<2, EPI, 4, NTW, true>), grid, block, 0, st, p); break;
+        case 3: hipLaunchKernelGGL((gemm_skinny_s4_kernel<3, EPI, 4, NTW, true>), grid, block, 0, st, p); break;
+        default: hipLaunchKernelGGL((gemm_skinny_s4_kernel<4, EPI, 4, NTW, true>), grid, block, 0, st, p); break;
+        }
+        return hipGetLastError();
+    }
     switch ((p.M + 15) / 16) {
     case 1: hipLaunchKernelGGL((gemm_skinny_s4_kernel<1, EPI, 4, NTW>), grid, block, 0, st, p); break;
     case 2: hipLaunchKernelGGL((gemm_skinny_s4_kernel<2, EPI, 4, NTW>), grid, block, 0, st, p); break;

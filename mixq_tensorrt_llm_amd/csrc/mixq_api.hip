@@ -134,6 +134,10 @@ static void set_int4_stream(int on);
 void mixq_debug_set_gemm_variant(int variant)
 {
     if (!debug_knobs_enabled()) return;
+    if (variant >= 872 && variant <= 874) { // packed-int4 weight stream, 256-byte runs: 872 by the measured rule (default), 873 off, 874 always
+        mixq::set_s4_wrows(variant == 872 ? 1 : variant == 873 ? 0 : 2);
+        return;
+    }
     if (variant == 870 || variant == 871) { // packed-int4 weight stream for decode batches: 870 on (default), 871 off (unpack route)
         set_int4_stream(variant == 870);
         return;
@@ -148,9 +152,10 @@ void mixq_debug_reset(void)
     mixq::set_quant_stamp_buffer(nullptr);
     for (int v : {-1 /* schedule (back to the MIXQ_GEMM_VARIANT default), tile configuration, skinny K width */, 79 /* K splits over workgroups automatic */, 69, 65, 91,
                   80 /* fpA_intB forms automatic */, 85, 840, 843, 848 /* non-temporal loads of large weights on */, 850, 858, 891 /* fragment-major qA on */, 893 /* skinny range: the rule */,
-                  894 /* feature tiles automatic */, 880 /* skinny-GEMM weight image off */, 1240 /* mid-M deep form automatic */, 1238})
+                  894 /* feature tiles automatic */, 880 /* skinny-GEMM weight image off */, 884 /* row-major weights in 256-byte runs */, 1240 /* mid-M deep form automatic */, 1238})
         mixq::set_gemm_variant(v);
     set_int4_stream(1);
+    mixq::set_s4_wrows(1);
 }
 
 const char* mixq_debug_last_gemm_kernel(void) { return mixq::last_gemm_kernel(); }

@@ -139,6 +139,7 @@ void set_wo_force(int form, int ks);
 const char* last_gemm_kernel(); // kernel family launch_gemm chose last (reporting only)
 void set_skinny_kw(int kw); // measurement knob: K-split width of the skinny kernel (0 = auto)
 void set_skinny_nt(int nt);
+void set_skinny_wrows(int on); // knob 884 on (default) / 885 off: row-major weights read in 256-byte runs (gemm_skinny_kernels.hip WFRAG == 3)
 void set_skinny_wfrag(int mode); // knob 880 automatic | 881 weight images with plain loads | 882 with non-temporal loads | 883 images ignored
 // weight images (gemm_skinny_kernels.hip): a fragment-major copy of an int8 [N, K] weight, registered under the weight's pointer
 hipError_t launch_weight_image(const int8_t* W, int8_t* img, int N, int K, hipStream_t st);
@@ -174,6 +175,7 @@ hipError_t launch_dequant_columns(const int8_t* W, const void* sW, const int32_t
 hipError_t launch_quant4_rows(const void* A, uint8_t* q, void* sA, int M, int K, hipStream_t st);
 hipError_t launch_unpack_s4(const uint8_t* src, int8_t* dst, size_t packed_bytes, hipStream_t st);
 // packed-int4 weight stream (int4_gemm_kernels.hip): p.A / p.B packed int4 [M, K] / [N, K], p.K = PACKED bytes per row, p.Y addend or null
+void set_s4_wrows(int mode); // knob 872 by rule (default) / 873 off / 874 always: packed weights read in 256-byte runs (int4_gemm_kernels.hip WROWS)
 bool gemm_skinny_s4_supported(int M, int N, int k_packed);
 hipError_t launch_gemm_skinny_s4(const GemmParams& p, int epi, hipStream_t st);
 hipError_t launch_unpack_s4_columns(const uint8_t* weight, const int32_t* ind, int rows, int cols_packed, int n,

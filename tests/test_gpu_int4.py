@@ -137,7 +137,7 @@ def test_fused_norm_4bit_producer(oracle):
 
 # ---- packed-int4 weight stream for decode batches (csrc/int4_gemm_kernels.hip; VERDICT r4 missing #2) ---------------------------
 @pytest.mark.parametrize("silu", [False, True])
-@pytest.mark.parametrize("N,K", [(512, 1024), (4096, 4096), (272, 2080), (12288, 4096), (1024, 28672)])
+@pytest.mark.parametrize("N,K", [(512, 1024), (4096, 4096), (272, 2080), (12288, 4096), (1024, 28672), (4096, 11008), (144, 256)])
 @pytest.mark.parametrize("M", [1, 5, 16, 17, 33, 48, 64])
 def test_int4_weight_stream_bit_exact(oracle, M, N, K, silu):
     """M <= 64: ONE launch reads both operands PACKED (N K / 2 weight bytes) and widens the nibbles in registers (x 16 per operand,
@@ -182,6 +182,18 @@ def test_int4_weight_stream_bit_exact(oracle, M, N, K, silu):
     finally:
         lib.mixq_debug_set_gemm_variant(870)
     assert np.array_equal(bits(D.cpu().numpy()), bits(got))
+    # round 5: the packed weight is read in 256-byte runs through a wave-private LDS tile (WROWS; K / 2 = 1040 and 5504 end in a
+    # partial group, 128: half a group); knob 873 = the plain 64-byte fragment loads: same bits
+    D1 = torch.empty((M, N), dtype=torch.float16, device="cuda:0")
+    for knob in (873, 874):   # 874 = the 256-byte runs whatever the rule says (it takes them from 5 rows on 16 MiB and more)
+        lib.mixq_debug_set_gemm_variant(knob)
+        try:
+            assert f(p(ap), p(bp), p(dev(sa)), p(dev(sb)), p(dev(y)), p(D1), M, N, K // 2, None, st) == 0
+            torch.cuda.synchronize()
+            assert b"gemm_skinny_s4_kernel" in lib.mixq_debug_last_gemm_kernel()
+        finally:
+            lib.mixq_debug_set_gemm_variant(872)
+        assert np.array_equal(bits(D1.cpu().numpy()), bits(got)), knob
     # no addend, no workspace
     D2 = torch.empty((M, N), dtype=torch.float16, device="cuda:0")
     f = lib.mixq_int4_fused_dequantize_silu if silu else lib.mixq_int4_fused_dequantize

@@ -25,7 +25,7 @@ def main():
     lib = _lib.load()
     gen = torch.Generator(device=dev).manual_seed(0)
     p = lambda x: ctypes.c_void_p(x.data_ptr())  # noqa: E731
-    print("# us per call (HIP graph of 100): s4 stream | unpack route (2 unpack launches + int8 GEMM) | int8 GEMM alone (row-major qA); warm / cold")
+    print("# us per call (HIP graph of 100): s4 stream (256-byte runs) | s4 stream with 64-byte fragment loads (knob 873) | unpack route (2 unpack launches + int8 GEMM) | int8 GEMM alone (row-major qA); warm / cold")
     for shape in a.shapes.split(";"):
         N, K = (int(x) for x in shape.split())
         copies = (320 << 20) // (N * K // 2) + 2
@@ -56,12 +56,14 @@ def main():
                 return f
 
             cells = []
-            for knob, mk in ((870, s4), (871, s4), (870, i8)):
-                lib.mixq_debug_set_gemm_variant(knob)
+            for knobs, mk in (((870, 872), s4), ((870, 873), s4), ((871, 872), s4), ((870, 872), i8)):   # 873: the 64-byte fragment loads of the first build
+                for knob in knobs:
+                    lib.mixq_debug_set_gemm_variant(knob)
                 cells.append(f"{bench.graph_time_us(mk(False), dev):6.2f} / {bench.graph_time_us(mk(True), dev):6.2f}")
             lib.mixq_debug_set_gemm_variant(870)
+            lib.mixq_debug_set_gemm_variant(872)
             bw = N * K / 2 / (float(cells[0].split('/')[1]) * 1e-6) / 1e12
-            print(f"M={M:3d} N={N:6d} K={K:6d}  s4 {cells[0]}  unpack {cells[1]}  int8 {cells[2]}   (s4 cold: {bw:.2f} TB/s of packed weight)")
+            print(f"M={M:3d} N={N:6d} K={K:6d}  s4 {cells[0]}  s4 (64-B loads) {cells[1]}  unpack {cells[2]}  int8 {cells[3]}   (s4 cold: {bw:.2f} TB/s of packed weight)")
 
 
 if __name__ == "__main__":

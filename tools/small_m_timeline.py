@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--K", type=int, default=4096)
     ap.add_argument("--calls", type=int, default=100)
     ap.add_argument("--knobs", default="", help="comma list of mixq_debug_set_gemm_variant knobs to set first")
+    ap.add_argument("--cold", action="store_true", help="cycle through enough weight copies to exceed the Infinity Cache")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.load()
@@ -52,6 +53,14 @@ def main():
     in_desc = (TensorDesc * 7)(*[TensorDesc.make(t.shape) for t in ins])
     out_desc = TensorDesc.make(out.shape)
     in_ptrs = (ctypes.c_void_p * 7)(*[t.data_ptr() for t in ins])
+    copies = ((320 << 20) // (N * K) + 2) if a.cold else 1
+    alts = [W] + [W.clone() for _ in range(copies - 1)]
+    ptr_sets = []
+    for w in alts:
+        v = [t.data_ptr() for t in ins]
+        v[1] = w.data_ptr()
+        ptr_sets.append((ctypes.c_void_p * 7)(*v))
+    turn = [0]
     out_ptrs = (ctypes.c_void_p * 1)(out.data_ptr())
     h = ctypes.c_void_p(lib.mixq_create(M, N, K))
     ws = torch.empty(max(lib.mixq_workspace_size(h, M, N, K), 16), dtype=torch.uint8, device=dev)
@@ -63,7 +72,8 @@ def main():
         if par is not None:
             lib.mixq_debug_set_quant_stamp_buffer(ctypes.c_void_p(Q[par].data_ptr()))
             lib.mixq_debug_set_stamp_buffer(ctypes.c_void_p(G[par].data_ptr()))
-        rc = lib.mixq_enqueue(h, in_desc, ctypes.byref(out_desc), in_ptrs, out_ptrs, ctypes.c_void_p(ws.data_ptr()), st)
+        rc = lib.mixq_enqueue(h, in_desc, ctypes.byref(out_desc), ptr_sets[turn[0] % copies], out_ptrs, ctypes.c_void_p(ws.data_ptr()), st)
+        turn[0] += 1
         assert rc == 0
 
     st0 = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
