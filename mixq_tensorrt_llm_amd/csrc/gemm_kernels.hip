@@ -521,6 +521,10 @@ static DeepPlan deep_plan_auto(int M, int N, int K, int tiles, int nk)
     //  below that those are ahead: 448 x 4608 x 3584 19.5 vs 23.7 us, 288 x 6144 x 4096 21.6 vs 26.0, validation sweep of the table)
     const int64_t wg64 = (int64_t)((M + 63) / 64) * ((N + 63) / 64);
     if (tiles >= 140 && tiles <= 256 && nk >= 24 && nk <= 40 && wg64 > 512) return DeepPlan{1, tiles, 1}; // (measured at K = 3584 .. 5120 only)
+    // (97..128 rows on one row of 70..128 tiles at K = 3072..5120: two workgroups per tile put 140..256 workgroups on the chip where the
+    //  64 x 64 tiles with two K groups inside the workgroup run 1.5 rounds -- profiles/r05_int8_forms_cold.jsonl: 12288 x 4096 at 128 rows
+    //  24.2 -> 22.7 us, 11008 x 4096 24.2 -> 22.0; at 96 rows -1..-5 %, at 72 rows level: from 97 rows)
+    if (M > 96 && M <= 128 && tiles >= 70 && tiles <= 128 && nk >= 24 && nk <= 40) return DeepPlan{2, tiles, 1};
     if (M <= 128) return DeepPlan{0, 0, 0};
     // (second row at K < 8192 only past 256 tiles of 64 x 64: one workgroup per CU of those with K split four ways inside it is
     //  ahead below -- 160 / 192 x 5120 x 5120: 20.0 / 20.9 vs 23.1 / 23.5 us, profiles/r05_int8_forms_cold.jsonl)
@@ -831,10 +835,13 @@ bool gemm_takes_skinny(const GemmParams& p, int epi)
     // 8192 x 4096 19.1 / 18.6 / 16.0, 6144 x 4096 at 64 rows 19.1 / 20.7 / 18.5, 5120 x 5120 (32 features per workgroup) at 48 rows
     // 22.0 / 23.5 / 19.7, at 64 rows 22.2 / 26.0 / 23.0, 4096 x 4096 at 64 rows 17.9 / 14.4 / 13.2.  (Round 3 had fitted this warm:
     // 48 rows up to N = 12288, 64 rows up to 6144 whatever the weight's layout.)
-    const bool one_tile = skinny_feature_tiles(p.M, p.N, p.K) == 1;
+    const bool one_tile = skinny_feature_tiles(p.M, p.N, p.K, false) == 1 || skinny_feature_tiles(p.M, p.N, p.K, true) == 1;
+    // (round 5) with the row-major weight read in 256-byte runs (K % 256 == 0: then one_tile holds without an image) the skinny kernel keeps
+    // 33..48 rows up to N = 12288 at K <= 5120 (selection check, operator us, tiles vs skinny: 48 x 12288 x 4096 19.2 / 17.4 warm, 22.4 / 21.6 cold)
+    const bool runs = p.K % 256 == 0 && p.K <= 5120 && skinny_feature_tiles(p.M, p.N, p.K, false) == 1;
     // (the rule with an image is a SUPERSET of the rule without: a producer that probed without the weight pointer -- mixq_qa_layout --
     //  and wrote the fragment-major image must find the consumer agreeing whatever the registry holds)
-    const bool rows_plain = (p.M <= 48 && p.N <= 8192 && one_tile) || (p.M <= 64 && p.N <= 4096);
+    const bool rows_plain = (p.M <= 48 && p.N <= (runs ? 12288 : 8192) && one_tile) || (p.M <= 64 && p.N <= 4096);
     const bool rows_33_64 = frag && (rows_plain || (img && ((p.M <= 48 && p.N <= 12288) || (p.M <= 64 && p.N <= 6144 && one_tile))));
     return gemm_variant() != 1 && !xsplit_wins && gemm_skinny_supported(p) &&
            (p.M <= 16 || (p.M <= 32 && (p.N <= 12288 || g_skinny_wide.load() != 0)) || rows_33_64 ||

@@ -303,10 +303,16 @@ void set_skinny_nt(int nt) { g_skinny_nt.store(nt); }
 // operator call, 1 vs 2 tiles): 4096 x 4096 9.1 / 12.4, 6144 12.2 / 12.3, 8192 12.8 / 12.8, 11008 16.0 / 17.8, 12288 16.0 / 17.8 --
 // halving the qA bytes does not pay for halving the workgroups -- except where N / 16 workgroups are a little more than one
 // round of the chip (5120 x 5120: 320 workgroups, 18.0 -> 15.0 with 160): 2 tiles only there.
-int skinny_feature_tiles(int M, int N, int K)
+// (round 5: with the row-major weight read in 256-byte runs -- WFRAG == 3, one feature tile per workgroup -- 5120 x 5120 at 32 rows runs
+//  12.9 us on one tile against 15.3 on two, profiles/r05_selection_check.txt: two tiles only where that route does not apply, i.e. on a
+//  registered weight image or K % 256 != 0)
+static std::atomic<int> g_skinny_wrows{1}; // knob 884 / 885: row-major weights in 256-byte runs through the wave-private LDS transposition on (default) / off
+void set_skinny_wrows(int on) { g_skinny_wrows.store(on); }
+int skinny_feature_tiles(int M, int N, int K, bool image)
 {
     const int f = g_skinny_nt.load();
     if (f == 1 || f == 2) return f;
+    if (!image && K % 256 == 0 && g_skinny_wrows.load(std::memory_order_relaxed) != 0) return 1;
     const int wgs = (N + 15) / 16, cus = num_cus();
     return (wgs > cus && 8 * wgs < 11 * cus) ? 2 : 1; // (256, 352) workgroups on 256 CUs
 }
@@ -343,8 +349,7 @@ hipError_t launch_weight_image(const int8_t* W, int8_t* img, int N, int K, hipSt
 }
 
 static std::atomic<int> g_skinny_wfrag{0}; // knob 880 automatic | 881 images with plain loads | 882 with non-temporal loads | 883 images ignored
-static std::atomic<int> g_skinny_wrows{1}; // knob 884 / 885: row-major weights in 256-byte runs through the wave-private LDS transposition on (default) / off
-void set_skinny_wrows(int on) { g_skinny_wrows.store(on); }
+
 static bool g_skinny_wfrag_off() { return g_skinny_wfrag.load(std::memory_order_relaxed) == 3; }
 
 // Content tag of an int8 [N, K] tensor in EITHER layout: the image is a permutation of the weight's 16-byte chunks, so a sum over
@@ -486,7 +491,7 @@ static hipError_t launch_skinny_kw(const GemmParams& p_in, hipStream_t st)
         p.B = static_cast<const int8_t*>(p.b_image); // (resolved ONCE per call by the API layer: resolve_weight_image)
         p.b_frag = mode == 1 ? 1 : mode == 2 ? 2 : ((int64_t)p.N * p.K >= ((int64_t)32 << 20) ? 2 : 1);
     } else if (KW == 4 && ABL == 0 && EPI != EPI_INT32 && p.K % 256 == 0 && g_skinny_wrows.load(std::memory_order_relaxed) != 0 &&
-               (p.a_frag == 0 || skinny_feature_tiles(p.M, p.N, p.K) == 1)) {
+               (p.a_frag == 0 || skinny_feature_tiles(p.M, p.N, p.K, false) == 1)) {
         p.b_frag = 3; // row-major weight, 256-byte runs (WFRAG == 3)
     }
     return launch_skinny_kw_impl<EPI, KW, ABL>(p, st);
@@ -517,7 +522,7 @@ static hipError_t launch_skinny_kw_impl(const GemmParams& p, hipStream_t st)
             if (mt > 4) return hipErrorInvalidValue;
             if (mt == 3) return launch_skinny_frag<3, EPI, KW, 1>(p, grid, block, st);
             if (mt == 4) return launch_skinny_frag<4, EPI, KW, 1>(p, grid, block, st);
-            if (skinny_feature_tiles(p.M, p.N, p.K) == 2) { // 32 features per workgroup
+            if (skinny_feature_tiles(p.M, p.N, p.K, p.b_frag == 1 || p.b_frag == 2) == 2) { // 32 features per workgroup
                 const dim3 grid2((unsigned)((p.N + 31) / 32));
                 return mt == 1 ? launch_skinny_frag<1, EPI, KW, 2>(p, grid2, block, st) : launch_skinny_frag<2, EPI, KW, 2>(p, grid2, block, st);
             }

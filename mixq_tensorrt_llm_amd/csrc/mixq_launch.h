@@ -148,7 +148,7 @@ bool unregister_weight_image(const void* weight);
 const void* resolve_weight_image(const void* weight, int N, int K, hipStream_t st); // once per call; verifies the content tag on first use
 int verify_weight_image(const void* weight, hipStream_t st);  // 1 current | 0 stale (dropped) | -1 nothing registered; synchronises st
 int weight_image_stale_count();
-int skinny_feature_tiles(int M, int N, int K); // measurement knob 894 / 895 / 896: feature tiles per workgroup of the fragment-major form auto / 1 / 2
+int skinny_feature_tiles(int M, int N, int K, bool image = false); // (image: the call streams a registered weight image) measurement knob 894 / 895 / 896: feature tiles per workgroup of the fragment-major form auto / 1 / 2
 hipError_t launch_gemm_fp16(const void* fpA, const void* fpW, void* Out, int M, int N, int O, hipStream_t st);
 hipError_t launch_dequantization(void* out, const int32_t* x, const void* sRow, const void* sCol, int M, int N,
                                  hipStream_t st);

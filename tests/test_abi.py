@@ -105,7 +105,9 @@ def test_workspace_sizes_are_size_t_clean(lib):
     assert lib.mixq_workspace_size(h, 64, 4096, 4096) <= 64 * 4096 + 2 * 64 + 2 * 64 * 128 + 5 * 128  # no split form: no scratch
     assert lib.mixq_workspace_size(h, M, 0, K) >= need + bound           # N unknown: the shape-independent bound
     xsplit = 16384 + 256 * 64 * 64 * 4            # below 256 rows: the small-tile form's scratch (256 workgroups x 16 KiB)
-    assert lib.mixq_workspace_size(h, 128, N, K) <= 128 * K + 2 * 128 + 2 * 128 * 128 + xsplit + 5 * 128 + 128
+    deep = 16384 + 96 * 2 * 128 * 128 * 4         # round 5: 97..128 rows on this shape take the deep form, 2 workgroups per 128 x 128 tile
+    assert lib.mixq_workspace_size(h, 128, N, K) <= 128 * K + 2 * 128 + 2 * 128 * 128 + max(xsplit, deep) + 5 * 128 + 128
+    assert lib.mixq_workspace_size(h, 96, N, K) <= 96 * K + 2 * 96 + 2 * 96 * 128 + xsplit + 5 * 128 + 128
     assert lib.mixq_workspace_size(h, 4, N, K) <= 4 * K + 8 + 8 * 128 + 4 * 128 + 128     # decode: none
     assert lib.mixq_gemm_scratch_size(1024, 4096, 11008) == 16384 + 64 * 4 * 262144   # 4 workgroups per tile, a 256-KiB slot each
     assert lib.mixq_gemm_scratch_size(2048, 4096, 4096) == 0          # 256 tiles of 128 x 256: no K split, no scratch

@@ -94,7 +94,7 @@ def test_deep_form_other_epilogues(lib, epi, xs):
 # the cells of the automatic table (csrc/gemm_kernels.hip deep_plan_auto), one per row of it, on BASELINE (N, K)
 AUTO_CELLS = [(256, 12288, 4096, 1), (200, 11008, 4096, 1), (96, 18944, 3584, 1), (768, 4608, 3584, 1),
               (384, 4096, 11008, 2), (512, 3584, 8192, 2), (256, 4096, 11008, 4), (192, 3584, 18944, 4),
-              (512, 1280, 8192, 4), (384, 1024, 28672, 8)]
+              (512, 1280, 8192, 4), (384, 1024, 28672, 8), (128, 12288, 4096, 2), (100, 11008, 4096, 2)]
 
 
 @pytest.mark.parametrize("M,N,K,xs", AUTO_CELLS)

@@ -205,7 +205,8 @@ def main():
         del pr
     # ---- 4b. deep_plan_auto (csrc/gemm_kernels.hip): the mid-M deep form's table, COLD weights, one probe inside every row and one next to it ----
     deep = [(256, 12288, 4096), (192, 11008, 4096), (256, 4096, 11008), (384, 4096, 11008), (384, 1024, 28672), (256, 3584, 8192),
-            (768, 4096, 4096), (448, 4608, 3584), (384, 12288, 4096), (640, 4096, 11008), (128, 12288, 4096), (256, 5120, 5120)]
+            (768, 4096, 4096), (448, 4608, 3584), (384, 12288, 4096), (640, 4096, 11008), (128, 12288, 4096), (256, 5120, 5120),
+            (100, 11008, 4096), (96, 12288, 4096)]
     for M, N, K in (deep[::2] if a.quick else deep):
         pr = Int8Problem(M, N, K)
         alts = {}
