@@ -841,7 +841,9 @@ bool gemm_takes_skinny(const GemmParams& p, int epi)
     const bool runs = p.K % 256 == 0 && p.K <= 5120 && skinny_feature_tiles(p.M, p.N, p.K, false) == 1;
     // (the rule with an image is a SUPERSET of the rule without: a producer that probed without the weight pointer -- mixq_qa_layout --
     //  and wrote the fragment-major image must find the consumer agreeing whatever the registry holds)
-    const bool rows_plain = (p.M <= 48 && p.N <= (runs ? 12288 : 8192) && one_tile) || (p.M <= 64 && p.N <= 4096);
+    // (two feature tiles per workgroup on the 256-byte-run route, N = 5120..8192, K <= 8192: ahead of the tiles up to 64 rows -- gemm_skinny_kernels.hip)
+    const bool runs2 = frag && p.K % 256 == 0 && p.K <= 8192 && skinny_feature_tiles(p.M, p.N, p.K, false) == 2 && p.N >= 5120 && p.N <= 8192;
+    const bool rows_plain = (p.M <= 48 && p.N <= (runs ? 12288 : 8192) && one_tile) || (p.M <= 64 && p.N <= 4096) || (runs2 && p.M <= 64);
     const bool rows_33_64 = frag && (rows_plain || (img && ((p.M <= 48 && p.N <= 12288) || (p.M <= 64 && p.N <= 6144 && one_tile))));
     return gemm_variant() != 1 && !xsplit_wins && gemm_skinny_supported(p) &&
            (p.M <= 16 || (p.M <= 32 && (p.N <= 12288 || g_skinny_wide.load() != 0)) || rows_33_64 ||

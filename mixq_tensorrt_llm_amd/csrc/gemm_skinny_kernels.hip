@@ -158,25 +158,31 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
         // 4 s' + l / 16) -- both conflict-free (16 consecutive lanes touch 16 different 16-byte slots of the 256-byte bank row),
         // no barrier (the LDS operations of one wave execute in order).  K % 256 == 0 (host-checked); the wave's K range is counted
         // in 256-byte groups; a group past the range re-reads the last valid one with zeroed fragments.
-        static_assert(NT == 1 && KW == 4 && ABL == 0, "the transposing route: one feature tile, four K parts");
+        // NT = 2: the wave regroups its two feature tiles one after the other through the same LDS tile; every qA fragment then feeds
+        // two MFMAs (from 33 rows on the qA re-reads -- N / 16 x M K bytes through L2, 3-4 x the weight bytes -- are what paces the launch).
+        static_assert(NT <= 2 && KW == 4 && ABL == 0, "the transposing route: one or two feature tiles, four K parts");
         __shared__ v4i tr[KW][256];
-        constexpr int GB = MT <= 2 ? 2 : 1; // groups per batch (4 k-steps each)
+        constexpr int GB = MT * NT <= 2 ? 2 : 1; // groups per batch (4 k-steps each)
         const int ngroups = p.K >> 8;
         const int gper = (ngroups + KW - 1) / KW;
         const int g_begin = min(wave * gper, ngroups), g_end = min(g_begin + gper, ngroups);
         const int lrow = lane >> 4, lch = lane & 15;
-        const int8_t* wl[4];
+        const int8_t* wl[NT][4];
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) wl[rg] = p.B + (int64_t)min(n0 + 4 * rg + lrow, p.N - 1) * K + lch * 16;
+        for (int c = 0; c < NT; ++c)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) wl[c][rg] = p.B + (int64_t)min(n0 + c * 16 + 4 * rg + lrow, p.N - 1) * K + lch * 16;
         v4i* const mytr = tr[wave];
         for (int g0 = g_begin; g0 < g_end; g0 += GB) {
             const int cnt = min(GB, g_end - g0);
-            v4i wr[GB][4], af[GB * 4][MT];
+            v4i wr[GB][NT][4], af[GB * 4][MT];
 #pragma unroll
             for (int gi = 0; gi < GB; ++gi) {
                 const int gg = min(g0 + gi, g0 + cnt - 1); // (wave-uniform)
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg) wr[gi][rg] = *reinterpret_cast<const v4i*>(wl[rg] + gg * 256);
+                for (int c = 0; c < NT; ++c)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) wr[gi][c][rg] = *reinterpret_cast<const v4i*>(wl[c][rg] + gg * 256);
 #pragma unroll
                 for (int sp = 0; sp < 4; ++sp)
 #pragma unroll
@@ -188,14 +194,17 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
 #pragma unroll
             for (int gi = 0; gi < GB; ++gi) {
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg) mytr[(4 * rg + lrow) * 16 + (lch ^ (4 * rg + lrow))] = wr[gi][rg];
+                for (int c = 0; c < NT; ++c) {
 #pragma unroll
-                for (int sp = 0; sp < 4; ++sp) {
-                    v4i w = mytr[lr * 16 + ((4 * sp + lq) ^ lr)];
-                    if (gi >= cnt) w = zero4;
+                    for (int rg = 0; rg < 4; ++rg) mytr[(4 * rg + lrow) * 16 + (lch ^ (4 * rg + lrow))] = wr[gi][c][rg];
 #pragma unroll
-                    for (int t = 0; t < MT; ++t)
-                        acc[0][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w, af[gi * 4 + sp][t], acc[0][t], 0, 0, 0);
+                    for (int sp = 0; sp < 4; ++sp) {
+                        v4i w = mytr[lr * 16 + ((4 * sp + lq) ^ lr)];
+                        if (gi >= cnt) w = zero4;
+#pragma unroll
+                        for (int t = 0; t < MT; ++t)
+                            acc[c][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w, af[gi * 4 + sp][t], acc[c][t], 0, 0, 0);
+                    }
                 }
             }
             if (g0 == g_begin) dbg_stamp(p.dbg, 2);
@@ -312,7 +321,13 @@ int skinny_feature_tiles(int M, int N, int K, bool image)
 {
     const int f = g_skinny_nt.load();
     if (f == 1 || f == 2) return f;
-    if (!image && K % 256 == 0 && g_skinny_wrows.load(std::memory_order_relaxed) != 0) return 1;
+    // ... and TWO tiles on that route where N / 32 workgroups are 160..256 (N = 5120..8192): every qA fragment feeds two MFMAs and the chip is
+    // still (nearly) full -- operator us cold, one tile (or the tiles the rule took) -> two: 5120 x 5120 at 32 / 48 / 64 rows 16.8 / 18.8 / 22.4 -> 14.6 /
+    // 17.2 / 18.5; 6144 x 4096 at 64 rows 18.7 -> 16.3; 8192 x 4096 at 64 rows 20.2 -> 17.5; 8192 x 8192 at 48 / 64 rows 26.1 / 27.4 -> 23.1 / 25.1; level at
+    // N = 11008 / 12288 (1.3-1.5 rounds), behind at N = 4096 (128 workgroups) and 18944 from 48 rows (profiles/r05_skinny_256B_runs_cold.txt)
+    // (4608 x 3584 -- Qwen2-7B's qkv, 144 workgroups of 32 features -- at 8 / 16 / 32 rows 11.1 / 11.2 / 12.3 -> 9.9 / 9.9 / 11.8, behind from 33 rows)
+    if (!image && K % 256 == 0 && g_skinny_wrows.load(std::memory_order_relaxed) != 0)
+        return (N >= (M <= 32 ? 4608 : 5120) && N <= 8192) ? 2 : 1;
     const int wgs = (N + 15) / 16, cus = num_cus();
     return (wgs > cus && 8 * wgs < 11 * cus) ? 2 : 1; // (256, 352) workgroups on 256 CUs
 }
@@ -491,7 +506,7 @@ static hipError_t launch_skinny_kw(const GemmParams& p_in, hipStream_t st)
         p.B = static_cast<const int8_t*>(p.b_image); // (resolved ONCE per call by the API layer: resolve_weight_image)
         p.b_frag = mode == 1 ? 1 : mode == 2 ? 2 : ((int64_t)p.N * p.K >= ((int64_t)32 << 20) ? 2 : 1);
     } else if (KW == 4 && ABL == 0 && EPI != EPI_INT32 && p.K % 256 == 0 && g_skinny_wrows.load(std::memory_order_relaxed) != 0 &&
-               (p.a_frag == 0 || skinny_feature_tiles(p.M, p.N, p.K, false) == 1)) {
+               (p.a_frag == 0 || skinny_feature_tiles(p.M, p.N, p.K, false) <= 2)) {
         p.b_frag = 3; // row-major weight, 256-byte runs (WFRAG == 3)
     }
     return launch_skinny_kw_impl<EPI, KW, ABL>(p, st);
@@ -500,7 +515,7 @@ static hipError_t launch_skinny_kw(const GemmParams& p_in, hipStream_t st)
 template <int MT, int EPI, int KW, int NT>
 static hipError_t launch_skinny_frag(const GemmParams& p, dim3 grid, dim3 block, hipStream_t st)
 {
-    if constexpr (NT == 1 && KW == 4) {
+    if constexpr (KW == 4) {
         if (p.b_frag == 3) {
             hipLaunchKernelGGL((gemm_skinny_kernel<MT, EPI, KW, 0, true, NT, 3>), grid, block, 0, st, p);
             return hipGetLastError();
@@ -520,6 +535,10 @@ static hipError_t launch_skinny_kw_impl(const GemmParams& p, hipStream_t st)
     if constexpr (KW == 4 && ABL == 0 && EPI != EPI_INT32) {
         if (p.a_frag == 1) { // (decode batches: M <= 64)
             if (mt > 4) return hipErrorInvalidValue;
+            if (p.b_frag == 3 && mt >= 3 && skinny_feature_tiles(p.M, p.N, p.K, false) == 2) { // (256-byte runs: 32 features per workgroup)
+                const dim3 grid2((unsigned)((p.N + 31) / 32));
+                return mt == 3 ? launch_skinny_frag<3, EPI, KW, 2>(p, grid2, block, st) : launch_skinny_frag<4, EPI, KW, 2>(p, grid2, block, st);
+            }
             if (mt == 3) return launch_skinny_frag<3, EPI, KW, 1>(p, grid, block, st);
             if (mt == 4) return launch_skinny_frag<4, EPI, KW, 1>(p, grid, block, st);
             if (skinny_feature_tiles(p.M, p.N, p.K, p.b_frag == 1 || p.b_frag == 2) == 2) { // 32 features per workgroup
