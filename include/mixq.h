@@ -436,6 +436,15 @@ MIXQ_API int mixq_enqueue_tp(const mixq_handle* h, const mixq_tensor_desc* input
 MIXQ_API int mixq_preprocess_weights_int8(uint8_t* preprocessed, const int8_t* row_major, size_t rows, size_t cols);
 MIXQ_API int mixq_unprocess_weights_int8(int8_t* row_major, const uint8_t* preprocessed, size_t rows, size_t cols);
 
+/* ---- plan introspection (MI355X extension; host only, needs no GPU) ---------------------------------------------------------
+ * What mixq_enqueue would launch for a call with M rows on an [N, K] layer (128 outlier columns, workspace sized by
+ * mixq_workspace_size, knobs at their defaults), written as text into buf: the kernel family, its tile / split / weight route.  The
+ * selection is a set of tables fitted on measurements; this entry makes them readable from the outside -- an integrator
+ * can list the forms its model's shapes will take, and tests/golden/selection_table.json pins the answers on BASELINE.json's shapes so
+ * that a rule change shows up as a diff of that table.  have_weight_image != 0: as if `weight` had a registered image.
+ * Returns MIXQ_OK, or MIXQ_E_BADARG.  Without a device the 256-CU tables answer. */
+MIXQ_API int mixq_describe_plan(int64_t M, int64_t N, int64_t K, int have_weight_image, char* buf, size_t len);
+
 /* ---- debug / measurement (NOT FOR PRODUCTION) ----------------------------------------------------------------------------
  * Everything named mixq_debug_* is PROCESS-GLOBAL state (atomics: race-free, but a caller that flips a knob changes the
  * kernel selection of every thread and stream of the process) and exists for the tests, the A/B tools under tools/ and the

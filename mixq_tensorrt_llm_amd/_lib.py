@@ -153,6 +153,7 @@ SIGNATURES = {
     "mixq_debug_set_stamp_buffer": (None, [_vp]),
     "mixq_debug_set_quant_stamp_buffer": (None, [_vp]),
     "mixq_debug_last_gemm_kernel": (ctypes.c_char_p, []),
+    "mixq_describe_plan": (_i, [_i64, _i64, _i64, _i, ctypes.c_char_p, ctypes.c_size_t]),
     "mixq_version": (ctypes.c_char_p, []),
     "mixq_abi_version": (_i, []),
     "mixq_error_string": (ctypes.c_char_p, [_i]),

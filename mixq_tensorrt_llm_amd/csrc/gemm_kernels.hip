@@ -25,6 +25,7 @@
 #include "mixq_device.h"
 #include "mixq_launch.h"
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 
 namespace mixq {
@@ -900,6 +901,66 @@ hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st)
     case EPI_DEQUANT_SILU_MUL: return launch_epi<EPI_DEQUANT_SILU_MUL>(p, st);
     default: return launch_epi<EPI_INT32>(p, st);
     }
+}
+
+int gemm_deep_factor(int M, int N, int K, bool have_scratch)
+{
+    const DeepPlan pl = deep_plan(M, N, K);
+    return (pl.xs == 1 || (pl.xs > 1 && have_scratch)) ? pl.xs : 0;
+}
+
+// What launch_gemm WOULD launch for this problem, as text -- the same decisions in the same order, nothing is launched (host only: it
+// runs without a GPU, where num_cus() answers 256).  tests/test_gpu_selection.py launches a grid of shapes and compares the family with
+// last_gemm_kernel(), so the two cannot drift apart; tests/golden/selection_table.json pins the answers on BASELINE.json's shapes, so a
+// change of any rule shows up as a diff of that table (the rules are tables fitted on measurements -- this makes
+// them readable and reviewable as one).
+void describe_gemm_plan(const GemmParams& p, int epi, char* buf, size_t len)
+{
+    if (len == 0) return;
+    const int variant = gemm_variant();
+    const bool scratch = p.splitk_ws != nullptr;
+    if (gemm_takes_skinny(p, epi)) {
+        const bool image = p.a_frag == 1 && p.b_image != nullptr;
+        const int route = skinny_weight_route(p.a_frag, image, p.M, p.N, p.K);
+        const int nt = p.a_frag == 1 && ((p.M + 15) / 16 <= 2 || route == 3) ? skinny_feature_tiles(p.M, p.N, p.K, route == 1 || route == 2) : 1;
+        snprintf(buf, len, "skinny: %d features per workgroup, weight %s, qA %s", 16 * nt,
+                 route == 3 ? "row-major in 256-byte runs" : route == 0 ? "row-major in 64-byte pieces" : "from its registered image",
+                 p.a_frag == 1 ? "fragment-major" : "row-major");
+        return;
+    }
+    if (variant == 0 && epi != EPI_INT32 && p.a_frag == 0 && gemm_deep_takes(p.M, p.N, p.K, scratch)) {
+        snprintf(buf, len, "deep: 128x128 tiles, %d workgroup(s) per tile along K", gemm_deep_factor(p.M, p.N, p.K, scratch));
+        return;
+    }
+    const int64_t tiles256 = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256);
+    const int64_t n64 = (p.N + 63) / 64;
+    const int64_t wg32 = (int64_t)((p.M + 31) / 32) * n64, wg64 = (int64_t)((p.M + 63) / 64) * n64;
+    if (variant == 0 && gemm_pp128_wins(p.M, p.N, p.K)) {
+        snprintf(buf, len, "ping-pong 128x256 tiles");
+        return;
+    }
+    if (variant == 0 && epi != EPI_INT32 && scratch && gemm_splitk_factor(p.M, p.N, p.K) != 0) {
+        const SplitPlan pl = gemm_splitk_plan(p.M, p.N, p.K);
+        if (pl.solo > 0) snprintf(buf, len, "ping-pong 256x256 tiles: %d whole round(s) solo + tail split %d ways along K", pl.solo / num_cus(), pl.s);
+        else snprintf(buf, len, "ping-pong 256x256 tiles, %d workgroups per tile along K", pl.s);
+        return;
+    }
+    if (variant == 2 || (variant == 0 && p.M > 128 && tiles256 >= 96 && wg64 > 768)) {
+        snprintf(buf, len, "ping-pong 256x256 tiles");
+        return;
+    }
+    if (epi != EPI_INT32 && scratch) {
+        const XSplitPlan pl = xsplit_plan(p.M, p.N, p.K);
+        if (pl.xs > 1) {
+            snprintf(buf, len, "two-barrier %dx64 tiles, 4 K groups, %d workgroups per tile along K", pl.bm, pl.xs);
+            return;
+        }
+    }
+    if (wg32 <= 256) snprintf(buf, len, "two-barrier 32x64 tiles, 4 K groups");
+    else if (wg64 <= 256) snprintf(buf, len, "two-barrier 64x64 tiles, 4 K groups");
+    else if (wg64 <= 512) snprintf(buf, len, "two-barrier 64x64 tiles, 2 K groups");
+    else if (wg64 <= 768) snprintf(buf, len, "two-barrier 64x64 tiles");
+    else snprintf(buf, len, "two-barrier 128x128 tiles");
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -493,6 +493,16 @@ const void* resolve_weight_image(const void* weight, int N, int K, hipStream_t s
 
 void set_skinny_wfrag(int mode) { g_skinny_wfrag.store(mode); }
 
+// the weight route launch_skinny_kw takes (GemmParams::b_frag): 0 row-major in 64-byte pieces | 1 / 2 the registered image | 3 row-major in 256-byte runs
+int skinny_weight_route(int a_frag, bool image, int M, int N, int K)
+{
+    const int mode = g_skinny_wfrag.load(std::memory_order_relaxed);
+    if (a_frag == 1 && image && mode != 3 && K % 64 == 0 && N % 16 == 0)
+        return mode == 1 ? 1 : mode == 2 ? 2 : ((int64_t)N * K >= ((int64_t)32 << 20) ? 2 : 1);
+    if (K % 256 == 0 && g_skinny_wrows.load(std::memory_order_relaxed) != 0 && (a_frag == 0 || skinny_feature_tiles(M, N, K, false) <= 2)) return 3;
+    return 0;
+}
+
 template <int EPI, int KW, int ABL = 0>
 static hipError_t launch_skinny_kw_impl(const GemmParams& p, hipStream_t st);
 
@@ -501,13 +511,9 @@ static hipError_t launch_skinny_kw(const GemmParams& p_in, hipStream_t st)
 {
     GemmParams p = p_in;
     p.b_frag = 0;
-    const int mode = g_skinny_wfrag.load(std::memory_order_relaxed);
-    if (p.a_frag == 1 && p.b_image != nullptr && mode != 3 && EPI != EPI_INT32 && p.K % 64 == 0 && p.N % 16 == 0) {
-        p.B = static_cast<const int8_t*>(p.b_image); // (resolved ONCE per call by the API layer: resolve_weight_image)
-        p.b_frag = mode == 1 ? 1 : mode == 2 ? 2 : ((int64_t)p.N * p.K >= ((int64_t)32 << 20) ? 2 : 1);
-    } else if (KW == 4 && ABL == 0 && EPI != EPI_INT32 && p.K % 256 == 0 && g_skinny_wrows.load(std::memory_order_relaxed) != 0 &&
-               (p.a_frag == 0 || skinny_feature_tiles(p.M, p.N, p.K, false) <= 2)) {
-        p.b_frag = 3; // row-major weight, 256-byte runs (WFRAG == 3)
+    if (KW == 4 && ABL == 0 && EPI != EPI_INT32) {
+        p.b_frag = skinny_weight_route(p.a_frag, p.b_image != nullptr, p.M, p.N, p.K); // 1 / 2 image | 3 row-major, 256-byte runs | 0 pieces
+        if (p.b_frag == 1 || p.b_frag == 2) p.B = static_cast<const int8_t*>(p.b_image); // (resolved ONCE per call by the API layer)
     }
     return launch_skinny_kw_impl<EPI, KW, ABL>(p, st);
 }

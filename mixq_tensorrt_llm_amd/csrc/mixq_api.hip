@@ -7,6 +7,7 @@
 
 #include <atomic>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -880,6 +881,19 @@ int mixq_w8a16_gemm_forward(const void* input, const uint8_t* weight, const void
 }
 
 // ------------------------------------------------------------------------------------------- enqueue ----
+// decode batches that the weight-streaming skinny GEMM serves: the quantiser writes qA in that kernel's MFMA fragment order (1), else 0
+static int enqueue_qa_frag(int64_t M, int64_t N, int64_t K, void* scratch, const void* W, const void* img)
+{
+    if (!(M <= 64 && K % 16 == 0 && N % 16 == 0 && mixq::qa_frag_enabled() && mixq::quant_frag_layout_supported((int)M, (int)K))) return 0;
+    mixq::GemmParams probe{};
+    probe.M = (int)M, probe.N = (int)N, probe.K = (int)K, probe.O = kNumOutliers;
+    probe.splitk_ws = scratch;
+    probe.B = static_cast<const int8_t*>(W);
+    probe.b_image = img; // (a registered weight image widens the skinny kernel's range)
+    probe.a_frag = 1;    // ("if the quantiser writes the fragment-major image, does the skinny kernel take the problem?")
+    return mixq::gemm_takes_skinny(probe, mixq::EPI_DEQUANT) ? 1 : 0;
+}
+
 static int enqueue_impl(const mixq_handle* h, const mixq_tensor_desc* inputDesc, const void* const* inputs,
                         void* const* outputs, void* workspace, void* stream, void* ev_gemm_start, void* ev_gemm_stop)
 {
@@ -934,17 +948,8 @@ static int enqueue_impl(const mixq_handle* h, const mixq_tensor_desc* inputDesc,
         // (Large calls keep the row-major image: a K-slice-major one -- 8 consecutive rows of a 128-byte slice contiguous, one LDS-DMA
         //  instruction = one 1-KiB read -- was built and measured on one box: GEMM -0.3 %, quantiser +7.6 % (its row becomes 32
         //  scattered 128-byte stores), prefill tokens/s -0.35 %: docs/LAB_NOTEBOOK.md R3.10.)
-        int frag = 0;
         const void* img = M <= 64 ? mixq::resolve_weight_image(W, (int)N, (int)K, st) : nullptr; // (ONE lookup per call: probe and launch agree)
-        if (M <= 64 && K % 16 == 0 && N % 16 == 0 && mixq::qa_frag_enabled() && mixq::quant_frag_layout_supported((int)M, (int)K)) {
-            mixq::GemmParams probe{};
-            probe.M = (int)M, probe.N = (int)N, probe.K = (int)K, probe.O = kNumOutliers;
-            probe.splitk_ws = scratch;
-            probe.B = W;
-            probe.b_image = img; // (a registered weight image widens the skinny kernel's range)
-            probe.a_frag = 1;    // ("if the quantiser writes the fragment-major image, does the skinny kernel take the problem?")
-            frag = mixq::gemm_takes_skinny(probe, mixq::EPI_DEQUANT) ? 1 : 0;
-        }
+        const int frag = enqueue_qa_frag(M, N, K, scratch, W, img);
         int rc = hip_rc(mixq::launch_quant_extract(const_cast<void*>(A), qA, sA, fpA, ind, (int)M, (int)K, kNumOutliers,
                                                    false, st, scratch, frag));
         if (rc != MIXQ_OK) return rc;
@@ -955,6 +960,28 @@ static int enqueue_impl(const mixq_handle* h, const mixq_tensor_desc* inputDesc,
         return rc;
     }
     return mixq_w8a16_gemm_forward(A, q_weight, scaling_factors, Out, (int)M, (int)N, (int)K, stream);
+}
+
+// What mixq_enqueue would launch for a call with M rows on an [N, K] layer, as text (host only, no GPU needed; include/mixq.h).
+int mixq_describe_plan(int64_t M, int64_t N, int64_t K, int have_weight_image, char* buf, size_t len)
+{
+    if (!buf || len == 0 || M <= 0 || N <= 0 || K <= 0 || M > INT32_MAX || N > INT32_MAX || K > INT32_MAX) return MIXQ_E_BADARG;
+    if (M <= kSmallMFastPath) {
+        snprintf(buf, len, "w8a16: one launch on qweight (fpA_intB GEMV / skinny form)");
+        return MIXQ_OK;
+    }
+    static int dummy_scratch, dummy_image;
+    void* scratch = enqueue_scratch_bytes(M, N, K) ? &dummy_scratch : nullptr;
+    const void* img = have_weight_image && M <= 64 && K % 64 == 0 && N % 16 == 0 ? &dummy_image : nullptr;
+    mixq::GemmParams p{};
+    p.M = (int)M, p.N = (int)N, p.K = (int)K, p.O = kNumOutliers;
+    p.splitk_ws = scratch;
+    p.b_image = img;
+    p.a_frag = enqueue_qa_frag(M, N, K, scratch, &dummy_image, img);
+    char plan[160];
+    mixq::describe_gemm_plan(p, mixq::EPI_DEQUANT, plan, sizeof plan);
+    snprintf(buf, len, "quantise + extract (1 launch), then %s", plan);
+    return MIXQ_OK;
 }
 
 int mixq_enqueue(const mixq_handle* h, const mixq_tensor_desc* inputDesc, const mixq_tensor_desc* /*outputDesc*/,

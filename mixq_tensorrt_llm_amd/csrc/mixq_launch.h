@@ -91,6 +91,9 @@ struct GemmParams {
 };
 
 hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st);
+void describe_gemm_plan(const GemmParams& p, int epi, char* buf, size_t len); // what launch_gemm would launch, as text (host only)
+int gemm_deep_factor(int M, int N, int K, bool have_scratch);                 // workgroups per 128 x 128 tile of the deep form, 0: not taken
+int skinny_weight_route(int a_frag, bool image, int M, int N, int K);         // GemmParams::b_frag the skinny launcher would set
 hipError_t launch_gemm_pp(const GemmParams& p, int epi, hipStream_t st);  // 256x256 ping-pong schedule
 hipError_t launch_gemm_pp128(const GemmParams& p, int epi, hipStream_t st);
 hipError_t launch_gemm_pp_tp(const GemmParams& p, hipStream_t st); // EPI_DEQUANT with p.tp.ndst destinations instead of p.D

@@ -359,3 +359,19 @@ def test_measurement_knobs_need_an_opt_in():
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
         assert r.returncode == 0, r.stderr[-2000:]
         assert r.stdout.split("\n")[:3] == want, (env_val, r.stdout)
+
+
+def test_selection_table_is_the_pinned_one(lib):
+    """The kernel selection is a set of tables fitted on measurements; mixq_describe_plan (host only) says what mixq_enqueue
+    would launch, and tests/golden/selection_table.json pins its answers on every BASELINE (N, K) x a ladder of row counts, with and
+    without a registered weight image: a change of any rule must come with a regenerated table (tools/selection_table.py), so that it is
+    visible as a diff -- and docs/SELECTION_TABLE.md, its readable form, stays true."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "selection_table.py"), "--check"], capture_output=True, text=True,
+                       timeout=300, env=dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES=""))   # (the 256-CU tables, wherever this runs)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    buf = ctypes.create_string_buffer(8)
+    assert lib.mixq_describe_plan(32, 4096, 4096, 0, buf, 8) == 0 and len(buf.value) == 7      # truncated, terminated
+    assert lib.mixq_describe_plan(0, 4096, 4096, 0, buf, 8) != 0 and lib.mixq_describe_plan(32, 4096, 4096, 0, None, 8) != 0

@@ -34,3 +34,46 @@ def test_automatic_selection_is_within_10_percent_of_the_best_alternative_on_eve
         r2, flagged2 = _run()
         both = flagged & flagged2
         assert not both, f"flagged twice: {sorted(both)}\n{r.stdout[-3000:]}\n{r2.stdout[-3000:]}"
+
+
+FAMILY = [("skinny", b"gemm_skinny_kernel"), ("deep", b"<DEEP>"), ("ping-pong 128x256", b"pp128_kernel"),
+          ("ping-pong 256x256 tiles,", b"pp_kernel<SPLITK>"), ("ping-pong 256x256 tiles:", b"pp_kernel<SPLITK>"),
+          ("ping-pong 256x256 tiles", b"gemm_w8a8o16_pp_kernel (256x256"), ("two-barrier", b"two-barrier tiles")]
+
+
+def test_described_plan_is_what_enqueue_launches():
+    """mixq_describe_plan (host only) restates launch_gemm's decisions; here every cell of a grid over BASELINE.json's (N, K) x a ladder of
+    row counts is really launched through mixq_enqueue and the family the library reports afterwards must be the one described."""
+    import ctypes
+    sys.path.insert(0, ROOT)
+    import bench
+    from mixq_tensorrt_llm_amd import _lib
+    from mixq_tensorrt_llm_amd._lib import TensorDesc
+    lib = _lib.load()
+    lib.mixq_debug_reset()
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev).manual_seed(0)
+    st0 = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    buf = ctypes.create_string_buffer(320)
+    n = 0
+    for (N, K) in [(12288, 4096), (4096, 11008), (4096, 4096), (4608, 3584), (18944, 3584), (3584, 8192), (1024, 28672), (5120, 5120)]:
+        t = bench.synth_layer(N, K, dev, gen)
+        for M in (5, 17, 32, 48, 64, 96, 128, 192, 256, 384, 512, 1024, 2048):
+            A = bench.synth_activation(M, K, t["ind_i32"], dev, gen)
+            o = torch.empty((M, N), dtype=torch.float16, device=dev)
+            ins = [A, t["weight"], t["weights_scaling_factor"], t["fp_weight"], t["fp_ind"], t["qweight"], t["weights_scaling_factor"]]
+            in_desc = (TensorDesc * 7)(*[TensorDesc.make(x.shape) for x in ins])
+            out_desc = TensorDesc.make(o.shape)
+            h = ctypes.c_void_p(lib.mixq_create(M, N, K))
+            ws = torch.empty(max(lib.mixq_workspace_size(h, M, N, K), 16), dtype=torch.uint8, device=dev)
+            assert lib.mixq_enqueue(h, in_desc, ctypes.byref(out_desc), (ctypes.c_void_p * 7)(*[x.data_ptr() for x in ins]),
+                                    (ctypes.c_void_p * 1)(o.data_ptr()), ctypes.c_void_p(ws.data_ptr()), st0) == 0
+            torch.cuda.synchronize()
+            launched = lib.mixq_debug_last_gemm_kernel()
+            lib.mixq_destroy(h)
+            assert lib.mixq_describe_plan(M, N, K, 0, buf, 320) == 0
+            said = buf.value.decode().split(", then ")[1]
+            want = next(k for p_, k in FAMILY if said.startswith(p_))
+            assert want in launched, (M, N, K, said, launched)
+            n += 1
+    assert n == 104
