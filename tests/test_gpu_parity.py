@@ -550,13 +550,13 @@ def test_full_size_linearity_and_row_independence():
     assert torch.isfinite(out).all()
 
 
-@pytest.mark.parametrize("M", [3, 48, 700])
-def test_enqueue_is_capturable_in_a_hip_graph(oracle, M):
+@pytest.mark.parametrize("M,N,K", [(3, 1024, 2048), (48, 1024, 2048), (700, 1024, 2048), (24, 4096, 2304), (57, 6144, 1280)])
+def test_enqueue_is_capturable_in_a_hip_graph(oracle, M, N, K):
     """The operator is a fixed sequence of launches on the caller's stream (no allocation, no host sync): after one warm
     call it can be captured into a HIP graph and replayed on new data in the same buffers -- decode (M <= 4), the
-    split-K tile kernel and the ping-pong kernel."""
+    split-K tile kernel, the ping-pong kernel, and (round 5) the decode-batch GEMM on its 256-byte-run weight route with one and
+    with two feature tiles per workgroup."""
     from mixq_tensorrt_llm_amd import plugin
-    N, K = 1024, 2048
     A, W, act = make_layer(M, N, K, seed=77 + M)
     p = oracle.pack_linear_weights(W, act)
     layer = plugin.MixQLinear(K, N, device=dev()).load(p)
