@@ -662,8 +662,8 @@ void set_gemm_variant(int v)
         set_deep_force(v == 1240 ? -1 : v - 1241);
         return;
     }
-    if (v == 884 || v == 885) { // decode-batch GEMM, row-major weights in 256-byte runs through LDS: 884 on (default), 885 off
-        set_skinny_wrows(v == 884);
+    if (v >= 884 && v <= 887) { // decode-batch GEMM, row-major weights in 256-byte runs through LDS: 884 on, non-temporal from 32 MiB (default), 885 off, 886 / 887 on with non-temporal loads always / never
+        set_skinny_wrows(v == 884 ? 1 : v == 885 ? 0 : v == 886 ? 2 : 3);
         return;
     }
     if (v >= 880 && v <= 883) { // registered weight images in the decode-batch GEMM: 880 automatic, 881 plain loads, 882 non-temporal loads, 883 ignored

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
         }
     };
     dbg_stamp(p.dbg, 1); // epilogue operands requested
-    if constexpr (WFRAG == 3) {
+    if constexpr (WFRAG == 3 || WFRAG == 4) { // (4: the same with non-temporal loads)
         // ROW-MAJOR weight in whole 256-byte runs (round 5, R5.8).  The plain fragment load above takes 64 bytes of 16 rows per
         // instruction: every 256-byte DRAM chunk of the weight is asked for in four pieces by four different instructions, and a
         // cold stream of such pieces ran at ~3.5 TB/s against ~4.5 from a registered image (1-KiB reads) in the SAME kernel
@@ -182,7 +182,10 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
 #pragma unroll
                 for (int c = 0; c < NT; ++c)
 #pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) wr[gi][c][rg] = *reinterpret_cast<const v4i*>(wl[c][rg] + gg * 256);
+                    for (int rg = 0; rg < 4; ++rg) {
+                        if (WFRAG == 4) wr[gi][c][rg] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(wl[c][rg] + gg * 256));
+                        else wr[gi][c][rg] = *reinterpret_cast<const v4i*>(wl[c][rg] + gg * 256);
+                    }
 #pragma unroll
                 for (int sp = 0; sp < 4; ++sp)
 #pragma unroll
@@ -315,8 +318,17 @@ void set_skinny_nt(int nt) { g_skinny_nt.store(nt); }
 // (round 5: with the row-major weight read in 256-byte runs -- WFRAG == 3, one feature tile per workgroup -- 5120 x 5120 at 32 rows runs
 //  12.9 us on one tile against 15.3 on two, profiles/r05_selection_check.txt: two tiles only where that route does not apply, i.e. on a
 //  registered weight image or K % 256 != 0)
-static std::atomic<int> g_skinny_wrows{1}; // knob 884 / 885: row-major weights in 256-byte runs through the wave-private LDS transposition on (default) / off
+static std::atomic<int> g_skinny_wrows{1}; // knob 884 / 885 / 886 / 887: row-major weights in 256-byte runs through the wave-private LDS transposition: on, non-temporal by size (default) / off / on, always non-temporal / on, never
 void set_skinny_wrows(int on) { g_skinny_wrows.store(on); }
+// Non-temporal loads on that route for weights of 32 MiB and more -- cold by construction in any model (a decode step reads every layer's
+// weights once; the same rule as the registered images' and the W8A16 stream's): operator us cold, plain -> non-temporal: 12288 x 4096 at 8 / 32 rows
+// 15.9 / 19.3 -> 15.2 / 18.2, 4096 x 11008 17.5 / 19.6 -> 16.0 / 18.6, 8192 x 8192 19.5 / 20.9 -> 17.9 / 19.9; a loop over ONE such layer (warm: served by the
+// Infinity Cache) is 4-12 % slower by construction (profiles/r05_skinny_256B_runs_cold.txt).  Knob 886 / 887: always / never.
+static bool skinny_runs_nontemporal(int N, int K)
+{
+    const int m = g_skinny_wrows.load(std::memory_order_relaxed);
+    return m == 2 || (m == 1 && (int64_t)N * K >= ((int64_t)32 << 20));
+}
 int skinny_feature_tiles(int M, int N, int K, bool image)
 {
     const int f = g_skinny_nt.load();
@@ -523,7 +535,8 @@ static hipError_t launch_skinny_frag(const GemmParams& p, dim3 grid, dim3 block,
 {
     if constexpr (KW == 4) {
         if (p.b_frag == 3) {
-            hipLaunchKernelGGL((gemm_skinny_kernel<MT, EPI, KW, 0, true, NT, 3>), grid, block, 0, st, p);
+            if (skinny_runs_nontemporal(p.N, p.K)) hipLaunchKernelGGL((gemm_skinny_kernel<MT, EPI, KW, 0, true, NT, 4>), grid, block, 0, st, p);
+            else hipLaunchKernelGGL((gemm_skinny_kernel<MT, EPI, KW, 0, true, NT, 3>), grid, block, 0, st, p);
             return hipGetLastError();
         }
     }
@@ -557,6 +570,15 @@ static hipError_t launch_skinny_kw_impl(const GemmParams& p, hipStream_t st)
     if (p.a_frag != 0) return hipErrorInvalidValue;
     if constexpr (KW == 4 && ABL == 0 && EPI != EPI_INT32) {
         if (p.b_frag == 3) { // row-major qA, row-major weight in 256-byte runs
+            if (skinny_runs_nontemporal(p.N, p.K)) {
+                switch (mt) {
+                case 1: hipLaunchKernelGGL((gemm_skinny_kernel<1, EPI, KW, 0, false, 1, 4>), grid, block, 0, st, p); break;
+                case 2: hipLaunchKernelGGL((gemm_skinny_kernel<2, EPI, KW, 0, false, 1, 4>), grid, block, 0, st, p); break;
+                case 3: hipLaunchKernelGGL((gemm_skinny_kernel<3, EPI, KW, 0, false, 1, 4>), grid, block, 0, st, p); break;
+                default: hipLaunchKernelGGL((gemm_skinny_kernel<4, EPI, KW, 0, false, 1, 4>), grid, block, 0, st, p); break;
+                }
+                return hipGetLastError();
+            }
             switch (mt) {
             case 1: hipLaunchKernelGGL((gemm_skinny_kernel<1, EPI, KW, 0, false, 1, 3>), grid, block, 0, st, p); break;
             case 2: hipLaunchKernelGGL((gemm_skinny_kernel<2, EPI, KW, 0, false, 1, 3>), grid, block, 0, st, p); break;
