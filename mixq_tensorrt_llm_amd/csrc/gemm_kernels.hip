@@ -163,6 +163,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KG * 64) void gemm_w8a8o16_kernel
     if (PREO && has_outliers) stage_outliers(); // older than every slice copy: retired by the loop's first wait
 
     const unsigned lds_group0 = (unsigned)(size_t)(MIXQ_LDS_PTR(smem)); // LDS byte address of this group's stages (ADMA)
+    const bool ntw = (p.flags & 2) != 0; // (launch_cfg: one tile row reads a weight of 32 MiB and more -- each of its lines exactly once)
     auto stage = [&](int buf, int kt) {
         char* xb = smem + buf * STAGE_BYTES;
         char* yb = xb + X_BYTES;
@@ -172,8 +173,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KG * 64) void gemm_w8a8o16_kernel
         for (int i = 0; i < XL; ++i) {
             const char* s = xsrc[i] + kbyte;
             if (last_partial && (kbyte + xkoff >= K)) s = static_cast<const char*>(p.zeros);
-            if (ADMA) glds16_vaddr(s, lds_group0 + buf * STAGE_BYTES + (i * T + wave * 64) * 16);
-            else glds16(s, xb + (i * T + wave * 64) * 16);
+            if (ADMA) {
+                if (ntw) glds16_vaddr_nt(s, lds_group0 + buf * STAGE_BYTES + (i * T + wave * 64) * 16);
+                else glds16_vaddr(s, lds_group0 + buf * STAGE_BYTES + (i * T + wave * 64) * 16);
+            } else {
+                if (ntw) glds16_nt(s, xb + (i * T + wave * 64) * 16);
+                else glds16(s, xb + (i * T + wave * 64) * 16);
+            }
         }
 #pragma unroll
         for (int i = 0; i < YL; ++i) {
@@ -418,6 +424,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KG * 64) void gemm_w8a8o16_kernel
     }
 }
 
+static std::atomic<int> g_tile_nt{0}; // 0 by rule (default) | 1 never | 2 whenever one tile row
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int NSTAGE = 2, int KG = 1, bool PREO = false, bool XSP = false,
           bool ADMA = false>
 static hipError_t launch_cfg(const GemmParams& p, hipStream_t st)
@@ -429,7 +436,14 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t st)
     static DeviceOnce once;
     if (hipError_t e = ensure_dynamic_lds(kern, lds, once); e != hipSuccess) return e;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * (XSP ? p.xsplit : 1))), dim3(T), lds, st, p);
+    GemmParams q = p;
+    // one tile row: every weight line is read by exactly one workgroup -> non-temporal copies for weights of 32 MiB and more (knob 1290 / 1291 / 1292:
+    // by that rule / never / whenever there is one tile row).  Operator us cold at 64 rows, plain -> non-temporal: 12288 x 4096 23.1 -> 22.1, 11008 x 4096
+    // 23.0 -> 21.8, 18944 x 3584 28.4 -> 26.9, 3584 x 18944 33.4 -> 32.1; deep form at 97..128 rows -1 %; warm loops over one layer +5..+12 % by construction
+    // (profiles/r05_tile_nontemporal.txt)
+    const int ntm = g_tile_nt.load(std::memory_order_relaxed);
+    if (p.M <= BM && EPI != EPI_INT32 && (ntm == 2 || (ntm == 0 && (int64_t)p.N * p.K >= ((int64_t)32 << 20)))) q.flags |= 2;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * (XSP ? p.xsplit : 1))), dim3(T), lds, st, q);
     return hipGetLastError();
 }
 
@@ -660,6 +674,10 @@ void set_gemm_variant(int v)
     }
     if (v >= 1240 && v <= 1269) { // mid-M deep form: 1240 automatic, 1241 off, 1241 + xs (1242 / 1243 / 1245 / 1249) forced, + 10 the 8-wave build
         set_deep_force(v == 1240 ? -1 : v - 1241);
+        return;
+    }
+    if (v >= 1290 && v <= 1292) { // tile kernels, non-temporal weight copies on a single tile row: 1290 by rule, 1291 never, 1292 always
+        g_tile_nt.store(v - 1290);
         return;
     }
     if (v >= 884 && v <= 887) { // decode-batch GEMM, row-major weights in 256-byte runs through LDS: 884 on, non-temporal from 32 MiB (default), 885 off, 886 / 887 on with non-temporal loads always / never

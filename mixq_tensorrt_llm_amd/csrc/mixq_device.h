@@ -83,6 +83,12 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base)
     __builtin_amdgcn_global_load_lds(MIXQ_GLOBAL_PTR(gsrc), MIXQ_LDS_PTR(lds_wave_base), 16, 0, 0);
 }
 
+// (non-temporal form: aux = 2 is the NT cache-policy bit of gfx94x / gfx950 -- for weight tiles that exactly one workgroup row reads)
+__device__ __forceinline__ void glds16_nt(const void* gsrc, void* lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds(MIXQ_GLOBAL_PTR(gsrc), MIXQ_LDS_PTR(lds_wave_base), 16, 0, 2);
+}
+
 // The same copy in asm form: wave-uniform 64-bit base in SGPRs + per-lane 32-bit byte offset; LDS destination = M0
 // (wave-uniform LDS byte address) + lane * 16.  M0 is saved / restored inside the statement (it is compiler-reserved).
 // WHY asm: the compiler's s_waitcnt insertion treats the builtin as a FLAT access that may touch LDS and memory, and
@@ -112,6 +118,19 @@ __device__ __forceinline__ void glds16_vaddr(const void* gsrc, unsigned lds_addr
                  "s_mov_b32 m0, %2\n\t"
                  "s_nop 0\n\t"
                  "global_load_lds_dwordx4 %1, off\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_addr)
+                 : "memory");
+}
+
+__device__ __forceinline__ void glds16_vaddr_nt(const void* gsrc, unsigned lds_addr)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %2\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off nt\n\t"
                  "s_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(gsrc), "s"(lds_addr)
