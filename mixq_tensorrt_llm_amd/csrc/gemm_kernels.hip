@@ -862,10 +862,13 @@ bool gemm_takes_skinny(const GemmParams& p, int epi)
     //  and wrote the fragment-major image must find the consumer agreeing whatever the registry holds)
     // (two feature tiles per workgroup on the 256-byte-run route, N = 5120..8192, K <= 8192: ahead of the tiles up to 64 rows -- gemm_skinny_kernels.hip)
     const bool runs2 = frag && p.K % 256 == 0 && p.K <= 8192 && skinny_feature_tiles(p.M, p.N, p.K, false) == 2 && p.N >= 5120 && p.N <= 8192;
+    // (17..32 rows beyond N = 12288: with two feature tiles per workgroup on the run route the skinny kernel stays ahead of the tiles up to N ~ 20000 at
+    //  K <= 5120 -- 18944 x 3584 at 32 rows 25.1 -> 23.0 / 23.6 -> 21.3 us on two boxes)
+    const bool wide2 = frag && p.K % 256 == 0 && p.K <= 5120 && p.N > 12288 && p.N <= 20480 && skinny_feature_tiles(p.M, p.N, p.K, false) == 2;
     const bool rows_plain = (p.M <= 48 && p.N <= (runs ? 12288 : 8192) && one_tile) || (p.M <= 64 && p.N <= 4096) || (runs2 && p.M <= 64);
     const bool rows_33_64 = frag && (rows_plain || (img && ((p.M <= 48 && p.N <= 12288) || (p.M <= 64 && p.N <= 6144 && one_tile))));
     return gemm_variant() != 1 && !xsplit_wins && gemm_skinny_supported(p) &&
-           (p.M <= 16 || (p.M <= 32 && (p.N <= 12288 || g_skinny_wide.load() != 0)) || rows_33_64 ||
+           (p.M <= 16 || (p.M <= 32 && (p.N <= 12288 || wide2 || g_skinny_wide.load() != 0)) || rows_33_64 ||
             (p.M <= 64 && g_skinny_wide.load() == 2));
     // (33..64 rows, fragment-major image only, operator us, tiles vs skinny: 4096 x 4096 at 40 / 48 / 64 rows 13.4 / 13.5 / 13.5 vs
     //  10.3 / 10.3 / 11.9; 3584 x 3584 at 64 12.7 / 11.1; 8192 x 4096 at 48 15.9 / 14.5; 12288 x 4096 at 48 19.2 / 18.7, at 64 19.9 / 22.4)

@@ -338,8 +338,10 @@ int skinny_feature_tiles(int M, int N, int K, bool image)
     // 17.2 / 18.5; 6144 x 4096 at 64 rows 18.7 -> 16.3; 8192 x 4096 at 64 rows 20.2 -> 17.5; 8192 x 8192 at 48 / 64 rows 26.1 / 27.4 -> 23.1 / 25.1; level at
     // N = 11008 / 12288 (1.3-1.5 rounds), behind at N = 4096 (128 workgroups) and 18944 from 48 rows (profiles/r05_skinny_256B_runs_cold.txt)
     // (4608 x 3584 -- Qwen2-7B's qkv, 144 workgroups of 32 features -- at 8 / 16 / 32 rows 11.1 / 11.2 / 12.3 -> 9.9 / 9.9 / 11.8, behind from 33 rows)
+    // (... and up to 32 rows where N / 16 one-tile workgroups would not all be resident at once -- more than 3 per CU: 18944 x 3584 at 32 rows 25.1 -> 23.0 /
+    //  23.6 -> 21.3 us on two boxes)
     if (!image && K % 256 == 0 && g_skinny_wrows.load(std::memory_order_relaxed) != 0)
-        return (N >= (M <= 32 ? 4608 : 5120) && N <= 8192) ? 2 : 1;
+        return ((N >= (M <= 32 ? 4608 : 5120) && N <= 8192) || (M <= 32 && (N + 15) / 16 > 3 * num_cus())) ? 2 : 1;
     const int wgs = (N + 15) / 16, cus = num_cus();
     return (wgs > cus && 8 * wgs < 11 * cus) ? 2 : 1; // (256, 352) workgroups on 256 CUs
 }
