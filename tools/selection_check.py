@@ -147,6 +147,9 @@ def main():
             t, kern = pr.time(79, 69, 0, k, 1241)      # (1241: the mid-M deep form off -- this table's own alternatives)
             alts[name] = t
         auto, kern = pr.time(79, 69, 0, 1240)
+        if "DEEP" in kern:   # (round 5: the mid-M deep form, fitted on COLD weights, owns this cell -- this table's row is measured warm with that form off;
+                             #  the cell is judged under deep_plan_auto, cold)
+            auto, kern = pr.time(79, 69, 0, 1241)
         report("gemm_splitk_plan", f"{M}x{N}x{K}", auto, alts)
         knobs(79, 69, 0)
         del pr
