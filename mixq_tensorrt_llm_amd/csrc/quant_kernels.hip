@@ -329,6 +329,13 @@ static hipError_t launch_qe(uint16_t* A, int8_t* qA, uint16_t* sA, uint16_t* fpA
     return hipGetLastError();
 }
 
+// Rows up to which a whole 256-thread block takes ONE row (one load round trip of 1-4 vectors per lane) instead of one wavefront per row (8-16 vectors
+// per lane, four rows per block).  Round 3 set it to 64 for decode batches; round 5 measured the rest of the band (operator us cold, 64 -> 2048):
+// 12288 x 4096 at 96 / 128 / 256 / 512 / 1024 rows 28.5 / 29.7 / 34.5 / 42.1 / 58.8 -> 26.1 / 28.0 / 32.2 / 40.7 / 57.6; 3584 x 8192 28.5 / 30.0 / 34.6 / 43.1 / 54.0
+// -> 24.1 / 25.1 / 30.8 / 40.6 / 50.6 (up to 16 %: at K = 8192 a wavefront holds 16 vectors per lane); level from 2048 rows (110 / 186 / 367 us at 2048 / 4096 /
+// 8192 rows either way), so prefill keeps the streaming form (profiles/r05_quant_block_rows.txt; knobs 1301..1309 = 64 << n).
+static std::atomic<int> g_quant_block_rows{2048};
+void set_quant_block_rows(int m) { g_quant_block_rows.store(m); }
 bool quant_frag_layout_supported(int M, int K) { return M > 0 && M <= 64 && K % 8 == 0 && K / 8 > 64 * 2 && K / 8 <= 256 * 8; }
 
 hipError_t launch_quant_extract(void* A, int8_t* qA, void* sA, void* fpA, const int32_t* ind, int M, int K, int O,
@@ -344,7 +351,7 @@ hipError_t launch_quant_extract(void* A, int8_t* qA, void* sA, void* fpA, const 
     const int nvec = K / 8;
     // Decode batches (few rows: the launch is a chain of latencies, not a stream): a whole 256-thread block per row, so
     // that a row is ONE load round trip of 1-4 vectors per lane instead of 8-16 on a single wavefront
-    if (M <= 64 && nvec > 64 * 2) {
+    if ((M <= g_quant_block_rows.load(std::memory_order_relaxed) || frag == 1) && nvec > 64 * 2) {
         if (nvec <= 256 * 2) return launch_qe<256, 2>(a, qA, s, f, ind, M, K, O, zero, st, zw, frag);
         if (nvec <= 256 * 4) return launch_qe<256, 4>(a, qA, s, f, ind, M, K, O, zero, st, zw, frag);
     }
