@@ -676,8 +676,8 @@ void set_gemm_variant(int v)
         set_deep_force(v == 1240 ? -1 : v - 1241);
         return;
     }
-    if (v >= 1301 && v <= 1309) { // quantiser: rows up to which one 256-thread block takes one row: 64 / 128 / 256 / 512 / 1024 / 2048
-        set_quant_block_rows(64 << (v - 1301));
+    if (v >= 1300 && v <= 1312) { // quantisers: rows up to which one 256-thread block takes one row: 1300 the measured rules (default), 1301 + n: 64 << n rows
+        set_quant_block_rows(v == 1300 ? -1 : 64 << (v - 1301));
         return;
     }
     if (v >= 1290 && v <= 1292) { // tile kernels, non-temporal weight copies on a single tile row: 1290 by rule, 1291 never, 1292 always

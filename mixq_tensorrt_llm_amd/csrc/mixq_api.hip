@@ -153,7 +153,7 @@ void mixq_debug_reset(void)
     mixq::set_quant_stamp_buffer(nullptr);
     for (int v : {-1 /* schedule (back to the MIXQ_GEMM_VARIANT default), tile configuration, skinny K width */, 79 /* K splits over workgroups automatic */, 69, 65, 91,
                   80 /* fpA_intB forms automatic */, 85, 840, 843, 848 /* non-temporal loads of large weights on */, 850, 858, 891 /* fragment-major qA on */, 893 /* skinny range: the rule */,
-                  894 /* feature tiles automatic */, 880 /* skinny-GEMM weight image off */, 884 /* row-major weights in 256-byte runs */, 1240 /* mid-M deep form automatic */, 1238, 1290 /* non-temporal weight copies of single-row tile launches: by rule */, 1306 /* quantiser: a block per row up to 2048 rows */})
+                  894 /* feature tiles automatic */, 880 /* skinny-GEMM weight image off */, 884 /* row-major weights in 256-byte runs */, 1240 /* mid-M deep form automatic */, 1238, 1290 /* non-temporal weight copies of single-row tile launches: by rule */, 1300 /* quantisers: block-per-row by the measured rules */})
         mixq::set_gemm_variant(v);
     set_int4_stream(1);
     mixq::set_s4_wrows(1);

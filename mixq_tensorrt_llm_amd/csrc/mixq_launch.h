@@ -161,7 +161,8 @@ hipError_t launch_quant_extract(void* A, int8_t* qA, void* sA, void* fpA, const 
                                 bool zero, hipStream_t st,
                                 void* zero_words = nullptr, // (kSplitkWordsBytes to clear on the way, or null)
                                 int frag = 0); // qA layout: 0 row-major | 1 the skinny GEMM's fragment order (quant_frag_layout_supported)
-void set_quant_block_rows(int m); // measurement knob 1301..1306
+void set_quant_block_rows(int m); // measurement knob 1300 (rules) / 1301..1312 (64 << n rows)
+int quant_block_rows(int nvec, bool norm_producer); // rows up to which a whole 256-thread block takes one row of nvec 16-byte vectors
 bool quant_frag_layout_supported(int M, int K);   // the quantiser can write the fragment-major image for this shape
 bool gemm_takes_skinny(const GemmParams& p, int epi);
 bool qa_frag_enabled(); // test knob 890 / 891 (default on)

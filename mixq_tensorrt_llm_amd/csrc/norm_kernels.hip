@@ -284,7 +284,7 @@ hipError_t launch_rmsnorm_quant(const void* X, const void* gamma, void* out, voi
     // Decode batches (few rows: the launch is a chain of latencies, not a stream): a whole 256-thread block per row, so that
     // a row is ONE load round trip of 1-4 vectors per lane instead of 8-16 on a single wavefront -- the same rule as the
     // quantiser's (quant_kernels.hip); 32 x 4096: 11.0 -> ~4.5 us for the fused producer (profiles/r03_small_m_timeline.txt)
-    if (M <= 64 && nvec > 64 * 2) {
+    if ((M <= quant_block_rows(nvec, true) || q_layout == 1) && nvec > 64 * 2) { // (round 5: at every size here -- the table in quant_kernels.hip)
         if (nvec <= 256 * 2) return launch_norm<256, 2>(x, g, o, ol, ind, q, sc, eps, M, K, O, quant, st, q_layout);
         if (nvec <= 256 * 4) return launch_norm<256, 4>(x, g, o, ol, ind, q, sc, eps, M, K, O, quant, st, q_layout);
     }

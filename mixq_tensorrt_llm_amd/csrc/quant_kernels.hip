@@ -330,12 +330,21 @@ static hipError_t launch_qe(uint16_t* A, int8_t* qA, uint16_t* sA, uint16_t* fpA
 }
 
 // Rows up to which a whole 256-thread block takes ONE row (one load round trip of 1-4 vectors per lane) instead of one wavefront per row (8-16 vectors
-// per lane, four rows per block).  Round 3 set it to 64 for decode batches; round 5 measured the rest of the band (operator us cold, 64 -> 2048):
-// 12288 x 4096 at 96 / 128 / 256 / 512 / 1024 rows 28.5 / 29.7 / 34.5 / 42.1 / 58.8 -> 26.1 / 28.0 / 32.2 / 40.7 / 57.6; 3584 x 8192 28.5 / 30.0 / 34.6 / 43.1 / 54.0
-// -> 24.1 / 25.1 / 30.8 / 40.6 / 50.6 (up to 16 %: at K = 8192 a wavefront holds 16 vectors per lane); level from 2048 rows (110 / 186 / 367 us at 2048 / 4096 /
-// 8192 rows either way), so prefill keeps the streaming form (profiles/r05_quant_block_rows.txt; knobs 1301..1309 = 64 << n).
-static std::atomic<int> g_quant_block_rows{2048};
+// per lane, four rows per block).  Round 3 set it to 64 for decode batches; round 5 measured the rest (profiles/r05_quant_block_rows.txt):
+//   * this kernel, K <= 4096 (8 vectors per lane in the wavefront form): operator us cold, 12288 x 4096 at 96 / 128 / 256 / 512 / 1024 rows 28.5 / 29.7 / 34.5 / 42.1 /
+//     58.8 -> 26.1 / 28.0 / 32.2 / 40.7 / 57.6; kernel alone at 2048 rows 7.5 -> 6.3 us, level at 8192 / 16384, 16 % SLOWER at 65536 (142.6 -> 165.6): up to 2048 rows;
+//   * this kernel, 4096 < K <= 8192 (16 vectors per lane): ahead at every size -- 2048 rows 15.8 -> 9.3 us, 16384 rows 77.0 -> 67.1, 65536 rows 283.6 -> 278.5: always;
+//   * the fused RMSNorm producer (norm_kernels.hip): ahead at every size at both widths (K = 4096: 128 rows 10.1 -> 4.6 us, 16384 rows 70.6 -> 61.4, 65536 rows 262.5 -> 254.6;
+//     K = 8192: 128 rows 16.7 -> 6.5, 65536 rows 617.8 -> 466.8): always.
+// Knobs 1301..1312 force one threshold (64 << n rows) for all three, 1300 = these rules.
+static std::atomic<int> g_quant_block_rows{-1};
 void set_quant_block_rows(int m) { g_quant_block_rows.store(m); }
+int quant_block_rows(int nvec, bool norm_producer)
+{
+    const int f = g_quant_block_rows.load(std::memory_order_relaxed);
+    if (f >= 0) return f;
+    return norm_producer || nvec > 256 * 2 ? INT32_MAX : 2048;
+}
 bool quant_frag_layout_supported(int M, int K) { return M > 0 && M <= 64 && K % 8 == 0 && K / 8 > 64 * 2 && K / 8 <= 256 * 8; }
 
 hipError_t launch_quant_extract(void* A, int8_t* qA, void* sA, void* fpA, const int32_t* ind, int M, int K, int O,
@@ -351,7 +360,7 @@ hipError_t launch_quant_extract(void* A, int8_t* qA, void* sA, void* fpA, const 
     const int nvec = K / 8;
     // Decode batches (few rows: the launch is a chain of latencies, not a stream): a whole 256-thread block per row, so
     // that a row is ONE load round trip of 1-4 vectors per lane instead of 8-16 on a single wavefront
-    if ((M <= g_quant_block_rows.load(std::memory_order_relaxed) || frag == 1) && nvec > 64 * 2) {
+    if ((M <= quant_block_rows(nvec, false) || frag == 1) && nvec > 64 * 2) {
         if (nvec <= 256 * 2) return launch_qe<256, 2>(a, qA, s, f, ind, M, K, O, zero, st, zw, frag);
         if (nvec <= 256 * 4) return launch_qe<256, 4>(a, qA, s, f, ind, M, K, O, zero, st, zw, frag);
     }
