@@ -10,7 +10,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -fno-fast-math -Wall -Wno-unused-function)
 OBJS=()
 PIDS=()
-for f in quant_kernels gemm_kernels gemm_pp_kernels gemm_pp128_kernels gemm_skinny_kernels decode_kernels w8a16_gemm_kernels norm_kernels outlier_kernels int4_kernels int4_gemm_kernels tp_kernels mixq_api; do
+for f in quant_kernels gemm_kernels gemm_pp_kernels gemm_pp128_kernels gemm_mid_kernels gemm_skinny_kernels decode_kernels w8a16_gemm_kernels norm_kernels outlier_kernels int4_kernels int4_gemm_kernels tp_kernels mixq_api; do
   src="${HERE}/${f}.hip"; obj="${HERE}/${f}.o"
   if [[ ! -f "$obj" || "$src" -nt "$obj" || "${HERE}/mixq_device.h" -nt "$obj" || "${HERE}/mixq_launch.h" -nt "$obj" || "${HERE}/../../include/mixq.h" -nt "$obj" ]]; then
     rm -f "$obj"   # a failed compile must not leave a stale object behind

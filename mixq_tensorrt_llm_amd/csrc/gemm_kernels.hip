@@ -582,6 +582,10 @@ static hipError_t launch_deep_epi(const GemmParams& p, hipStream_t st)
     GemmParams q = p;
     q.xsplit = pl.xs;
     q.flags = g_deep_late.load() ? 0 : 1;
+    if (pl.waves8 == 3 && p.K % KSLICE == 0) { // round 6: copy-only waves, two slices per barrier (gemm_mid_kernels.hip)
+        q.flags = 0;
+        return launch_gemm_mid(q, EPI, st);
+    }
     if (pl.waves8 == 2) { // five stages = the whole 160 KiB of LDS: four slices in flight
         if (pl.xs > 1) return launch_cfg<128, 128, 2, 4, EPI, 5, 1, false, true, true>(q, st);
         return launch_cfg<128, 128, 2, 4, EPI, 5, 1, false, false, true>(q, st);
@@ -672,7 +676,7 @@ void set_gemm_variant(int v)
         g_deep_late.store(v == 1238);
         return;
     }
-    if (v >= 1240 && v <= 1269) { // mid-M deep form: 1240 automatic, 1241 off, 1241 + xs (1242 / 1243 / 1245 / 1249) forced, + 10 the 8-wave build
+    if (v >= 1240 && v <= 1279) { // mid-M deep form: 1240 automatic, 1241 off, 1241 + xs (1242 / 1243 / 1245 / 1249) forced, + 10 the 8-wave build, + 30 the round-6 schedule
         set_deep_force(v == 1240 ? -1 : v - 1241);
         return;
     }

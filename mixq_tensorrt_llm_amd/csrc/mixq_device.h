@@ -109,6 +109,20 @@ __device__ __forceinline__ void glds16_sbase(const char* sbase, unsigned voff, u
                  : "memory");
 }
 
+// (non-temporal form of glds16_sbase: weight tiles that exactly one workgroup row reads)
+__device__ __forceinline__ void glds16_sbase_nt(const char* sbase, unsigned voff, unsigned lds_addr)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %3\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2 nt\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_addr)
+                 : "memory");
+}
+
 // The asm form with a per-lane 64-bit source address (for copies whose source is not base + 32-bit offset, e.g. a row
 // clamp or a redirection to the zero page).  Same rules: not counted by the compiler.
 __device__ __forceinline__ void glds16_vaddr(const void* gsrc, unsigned lds_addr)

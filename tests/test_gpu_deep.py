@@ -31,7 +31,7 @@ SHAPES = [(300, 528, 2064),     # ragged M and N, partial last K slice, 3 x 5 ti
           (200, 784, 4352)]
 
 
-@pytest.mark.parametrize("build", [0, 10, 20])          # 4 waves x 64 x 64 | 8 waves x 64 x 32 | 8 waves, 5 stages
+@pytest.mark.parametrize("build", [0, 10, 20, 30])      # 4 waves x 64 x 64 | 8 waves x 64 x 32 | 8 waves, 5 stages | round 6: copy-only waves, a barrier per pair of slices (gemm_mid_kernels.hip; K % 128 != 0 falls back to build 10)
 @pytest.mark.parametrize("xs", [1, 2, 4, 8])
 @pytest.mark.parametrize("M,N,K", SHAPES)
 @pytest.mark.parametrize("O", [128, 0, 40, 256])   # 256: side GEMM first, then the addend form (C = D = Out)
@@ -40,6 +40,8 @@ def test_deep_form_gives_the_bits_of_the_one_workgroup_form(lib, build, xs, M, N
         pytest.skip("a subset for the builds the table does not select")
     if xs == 8:
         K = 2 * K + 16          # 8 ways need >= 32 K slices
+    if build == 30 and (M, N) != (300, 528):
+        K = (K + 127) // 128 * 128 + (128 if xs == 2 else 0)   # whole slices (odd and even counts); the ragged shape keeps its partial slice = the fall-back
     qA, W, sA, sW, fpA, fpW = operands(M, N, K, O, seed=M + N + K + O)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     fa, fw = (p(fpA), p(fpW)) if O else (None, None)
@@ -61,8 +63,9 @@ def test_deep_form_gives_the_bits_of_the_one_workgroup_form(lib, build, xs, M, N
 
 @pytest.mark.parametrize("xs", [1, 4])
 @pytest.mark.parametrize("epi", ["dequant+y", "silu", "silu_mul"])
-def test_deep_form_other_epilogues(lib, epi, xs):
-    M, N, K = 260, 1040, 8208
+@pytest.mark.parametrize("build,K", [(10, 8208), (30, 8192 + 128)])   # (round 6's schedule takes whole 128-byte slices only)
+def test_deep_form_other_epilogues(lib, epi, xs, build, K):
+    M, N = 260, 1040
     qA, W, sA, sW, _, _ = operands(M, N, K, 0, seed=4)
     g = torch.Generator(device="cpu").manual_seed(5)
     y = (torch.randn((M, N), generator=g) * 0.5).to(torch.float16).to("cuda:0") if "+y" in epi else None
@@ -83,7 +86,7 @@ def test_deep_form_other_epilogues(lib, epi, xs):
 
     lib.mixq_debug_set_gemm_variant(OFF)
     ref = run(None)
-    lib.mixq_debug_set_gemm_variant(OFF + 10 + xs)
+    lib.mixq_debug_set_gemm_variant(OFF + build + xs)
     scr = torch.zeros(max(lib.mixq_gemm_scratch_size(M, N, K), 16), dtype=torch.uint8, device="cuda:0")
     for _ in range(3):
         got = run(scr)
