@@ -74,6 +74,11 @@ MIXQ_API const char* mixq_plugin_version(void); /* "1"     getPluginVersion .cpp
 /* ---- plugin object lifecycle (TsinghuaMixQPlugin.h:34-89) ------------------------------------- */
 MIXQ_API mixq_handle* mixq_create(int32_t m, int32_t n, int32_t k);                       /* ctor .cpp:217-225 */
 MIXQ_API mixq_handle* mixq_create_from_fields(const mixq_plugin_field* fields, int32_t nbFields); /* createPlugin .cpp:895-933 */
+/* MixQPluginCreator::getFieldNames (.cpp:890-893, .h:100): the table the creator ADVERTISES, exactly as the reference fills it in its
+ * constructor (.cpp:868-878): three INT32 fields named "mm", "mn", "mk", data == NULL, length == -1.  (createPlugin above parses
+ * "m", "n", "k" -- .cpp:906-919 -- as the reference does; a host that enumerates the advertised names finds what the reference
+ * would show it.)  Returns a pointer to a static array, *nbFields receives its length (3); never NULL. */
+MIXQ_API const mixq_plugin_field* mixq_get_field_names(int32_t* nbFields);
 MIXQ_API mixq_handle* mixq_deserialize(const void* data, size_t length);                  /* .cpp:227-234, 935-951 */
 MIXQ_API size_t mixq_serialization_size(const mixq_handle* h);                            /* == 12, .cpp:808-811 */
 MIXQ_API void mixq_serialize(const mixq_handle* h, void* buffer);                         /* .cpp:813-820 */
@@ -475,7 +480,7 @@ MIXQ_API const char* mixq_version(void);
  * mixq_tp_buffer_alloc / mixq_tp_push_columns / mixq_tp_wait signatures of round 3), so that a host built against an older
  * header can refuse to run instead of passing shifted arguments: `if (mixq_abi_version() != MIXQ_ABI_VERSION) fail`.  The
  * reference-named entries (initOpenAiTritonPlugins, the plugin lifecycle, mixq_enqueue) have not changed since revision 1. */
-#define MIXQ_ABI_VERSION 3
+#define MIXQ_ABI_VERSION 4
 MIXQ_API int mixq_abi_version(void);
 MIXQ_API const char* mixq_error_string(int code);
 

@@ -110,7 +110,8 @@ private:
 
 class MixQPluginCreator {                                                                /* .cpp:868-960 */
 public:
-    MixQPluginCreator() {}
+    MixQPluginCreator() { mFC.fields = mixq_get_field_names(&mFC.nbFields); }           /* .cpp:868-878: "mm", "mn", "mk" */
+    const PluginFieldCollection* getFieldNames() noexcept { return &mFC; }              /* .cpp:890-893 */
     const char* getPluginName() const noexcept { return mixq_plugin_type(); }
     const char* getPluginVersion() const noexcept { return mixq_plugin_version(); }
     /* reads the INT32 fields "m", "n", "k" (.cpp:906-919); nullptr on a malformed collection (the reference catches and logs) */
@@ -148,6 +149,7 @@ private:
         return p;
     }
     std::string ns_;
+    PluginFieldCollection mFC{0, nullptr};
 };
 
 } // namespace mixq_plugin

@@ -64,6 +64,7 @@ SIGNATURES = {
     "mixq_plugin_version": (ctypes.c_char_p, []),
     "mixq_create": (_vp, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     "mixq_create_from_fields": (_vp, [ctypes.POINTER(PluginField), ctypes.c_int32]),
+    "mixq_get_field_names": (ctypes.POINTER(PluginField), [ctypes.POINTER(ctypes.c_int32)]),
     "mixq_deserialize": (_vp, [_vp, _sz]),
     "mixq_serialization_size": (_sz, [_vp]),
     "mixq_serialize": (None, [_vp, _vp]),
@@ -160,7 +161,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 3   # include/mixq.h MIXQ_ABI_VERSION
+ABI_VERSION = 4   # include/mixq.h MIXQ_ABI_VERSION
 
 
 def load():

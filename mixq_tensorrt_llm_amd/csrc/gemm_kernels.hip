@@ -676,6 +676,10 @@ void set_gemm_variant(int v)
         g_deep_late.store(v == 1238);
         return;
     }
+    if (v >= 1400 && v <= 1409) { // round-6 mid kernel build (gemm_mid_kernels.hip)
+        set_mid_build(v - 1400);
+        return;
+    }
     if (v >= 1240 && v <= 1279) { // mid-M deep form: 1240 automatic, 1241 off, 1241 + xs (1242 / 1243 / 1245 / 1249) forced, + 10 the 8-wave build, + 30 the round-6 schedule
         set_deep_force(v == 1240 ? -1 : v - 1241);
         return;

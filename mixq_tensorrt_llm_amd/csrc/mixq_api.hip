@@ -153,7 +153,7 @@ void mixq_debug_reset(void)
     mixq::set_quant_stamp_buffer(nullptr);
     for (int v : {-1 /* schedule (back to the MIXQ_GEMM_VARIANT default), tile configuration, skinny K width */, 79 /* K splits over workgroups automatic */, 69, 65, 91,
                   80 /* fpA_intB forms automatic */, 85, 840, 843, 848 /* non-temporal loads of large weights on */, 850, 858, 891 /* fragment-major qA on */, 893 /* skinny range: the rule */,
-                  894 /* feature tiles automatic */, 880 /* skinny-GEMM weight image off */, 884 /* row-major weights in 256-byte runs */, 1240 /* mid-M deep form automatic */, 1238, 1290 /* non-temporal weight copies of single-row tile launches: by rule */, 1300 /* quantisers: block-per-row by the measured rules */})
+                  894 /* feature tiles automatic */, 880 /* skinny-GEMM weight image off */, 884 /* row-major weights in 256-byte runs */, 1240 /* mid-M deep form automatic */, 1238, 1400 /* round-6 mid kernel: default build */, 1290 /* non-temporal weight copies of single-row tile launches: by rule */, 1300 /* quantisers: block-per-row by the measured rules */})
         mixq::set_gemm_variant(v);
     set_int4_stream(1);
     mixq::set_s4_wrows(1);
@@ -203,6 +203,16 @@ mixq_handle* mixq_create_from_fields(const mixq_plugin_field* fields, int32_t nb
         else if (!std::strcmp(f.name, "k")) k = v;
     }
     return mixq_create(m, n, k);
+}
+
+const mixq_plugin_field* mixq_get_field_names(int32_t* nbFields)
+{
+    // TsinghuaMixQPlugin.cpp:868-878: PluginField("mm" / "mn" / "mk", nullptr, PluginFieldType::kINT32, -1)
+    static const mixq_plugin_field kFields[3] = {{"mm", nullptr, MIXQ_FIELD_INT32, -1},
+                                                 {"mn", nullptr, MIXQ_FIELD_INT32, -1},
+                                                 {"mk", nullptr, MIXQ_FIELD_INT32, -1}};
+    if (nbFields) *nbFields = 3;
+    return kFields;
 }
 
 mixq_handle* mixq_deserialize(const void* data, size_t length)

@@ -125,6 +125,7 @@ void set_deep_force(int v);
 hipError_t launch_gemm_deep(const GemmParams& p, int epi, hipStream_t st);
 // round-6 schedule of the same tiles (gemm_mid_kernels.hip): 2 copy-only waves + 8 compute waves, one barrier per pair of slices; p.xsplit workgroups per tile
 hipError_t launch_gemm_mid(const GemmParams& p, int epi, hipStream_t st);
+void set_mid_build(int b); // measurement knob 1400 + b (gemm_mid_kernels.hip)
 bool gemm_skinny_supported(const GemmParams& p);
 hipError_t launch_gemm_skinny(const GemmParams& p, int epi, hipStream_t st); // M <= 64: GEMV-like, HBM-bound on W
 hipError_t launch_gemm_pp_ablate(const GemmParams& p, int abl, hipStream_t st);  // timing experiments only

@@ -18,7 +18,7 @@ __all__ = [
     "select_outliers", "pack_linear_weights", "eetq_symmetric_quantize", "eetq_preprocess", "w8a16_gemv",
     "int_to_half", "int8_matrix_to_half", "rmsnorm_extract_quant", "find_outliers", "dequant_weight_columns",
     "MixLinearState", "mixlinear_forward", "quant4_rows", "unpack_i4", "pack_i4", "mixlinear4_from_linear",
-    "mixlinear4_forward",
+    "mixlinear4_forward", "hdiv_cuda", "quant_rows_cuda_hdiv",
 ]
 
 
@@ -104,6 +104,48 @@ def quant_rows(A, zero_cols=None):
     lib().mixq_oracle_quant_rows(_i64(M), _i64(K), _p(A), _p(qA), _p(sA), _p(zc),
                                  ctypes.c_int(0 if zc is None else zc.size))
     return qA, sA
+
+
+def hdiv_cuda(a, b, rcp_ulps=0):
+    """CUDA's DEVICE `__hdiv` as cuda_fp16.hpp writes it (the form kernel/i8gemm.cu:99-104 really executes; `quant_rows` uses the IEEE
+    quotient): v = fp16(fa * rcp.approx.ftz.f32(fb)), with the fma correction step for results below the half 0x008F.
+    `rcp.approx` is specified to 1 ulp, not bit for bit: ``rcp_ulps`` in {-1, 0, +1} evaluates the reciprocal at that many fp32 ulps from
+    the correctly rounded one, which brackets every conforming implementation.  numpy, vectorised; a, b float16 arrays (broadcast)."""
+    a = np.asarray(a, np.float16)
+    b = np.asarray(b, np.float16)
+    fa, fb = np.broadcast_arrays(a.astype(np.float32), b.astype(np.float32))
+    with np.errstate(all="ignore"):
+        rcp = (np.float32(1.0) / fb).astype(np.float32)
+        if rcp_ulps:
+            toward = np.where(rcp_ulps > 0, np.float32(np.inf), np.float32(-np.inf)) * np.where(rcp < 0, np.float32(-1), np.float32(1))
+            shifted = rcp
+            for _ in range(abs(int(rcp_ulps))):
+                shifted = np.nextafter(shifted, toward.astype(np.float32)).astype(np.float32)
+            rcp = np.where(np.isfinite(rcp) & (rcp != 0), shifted, rcp)
+        tiny = np.float32(2.0 ** -126)
+        rcp = np.where(np.abs(rcp) < tiny, np.copysign(np.float32(0), rcp), rcp).astype(np.float32)   # .ftz on the result
+        fv = (rcp * fa).astype(np.float32)
+        v = fv.astype(np.float16)
+        den = np.array([0x008F], np.uint16).view(np.float16)[0]
+        fix = (np.abs(v) < den) & (np.abs(v) > 0)
+        if np.any(fix):   # (results this small quantise to 0 either way; kept for fidelity)
+            err = (-fb.astype(np.float64) * fv.astype(np.float64) + fa.astype(np.float64)).astype(np.float32)            # __fmaf_rn(-fb, fv, fa)
+            fv2 = (rcp.astype(np.float64) * err.astype(np.float64) + fv.astype(np.float64)).astype(np.float32)           # __fmaf_rn(rcp, err, fv)
+            v = np.where(fix, fv2.astype(np.float16), v)
+    return v
+
+
+def quant_rows_cuda_hdiv(A, rcp_ulps=0):
+    """kernel/i8gemm.cu:66-107 with BOTH divisions (:99 the scale, :104 the elements) through `hdiv_cuda` -> (qA int8, sA fp16).
+    With the IEEE quotient this is `quant_rows`; the difference between the two is the known deviation DESIGN.md §7 bounds."""
+    A = _h(A)
+    with np.errstate(all="ignore"):
+        amax = np.fmax.reduce(np.abs(A.astype(np.float32)), axis=1, initial=0).astype(np.float16)   # __hmax drops NaN operands
+        sA = hdiv_cuda(amax, np.float16(127.0), rcp_ulps)
+        q = hdiv_cuda(A, sA[:, None], rcp_ulps).astype(np.float32)
+        r = np.where(np.isnan(q), 0, np.where(np.isinf(q), np.where(q > 0, 2.0 ** 31 - 1, -2.0 ** 31), np.rint(q)))   # __half2int_rn
+    qA = (r.astype(np.int64) & 0xff).astype(np.uint8).view(np.int8)
+    return qA, sA.astype(np.float16)
 
 
 def extract_outliers(A, ind, set_zero=False):

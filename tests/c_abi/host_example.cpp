@@ -83,6 +83,13 @@ int main(int argc, char** argv)
     creator.setPluginNamespace("tensorrt_llm");
     const PluginField fields[3] = {{"m", &M, MIXQ_FIELD_INT32, 1}, {"n", &N, MIXQ_FIELD_INT32, 1}, {"k", &K, MIXQ_FIELD_INT32, 1}};
     const PluginFieldCollection fc = {3, fields};
+    { // getFieldNames (TsinghuaMixQPlugin.cpp:890-893): the advertised table is the reference's "mm", "mn", "mk" (INT32, no data, length -1)
+        const PluginFieldCollection* adv = creator.getFieldNames();
+        if (!adv || adv->nbFields != 3 || std::string(adv->fields[0].name) != "mm" || std::string(adv->fields[1].name) != "mn" ||
+            std::string(adv->fields[2].name) != "mk" || adv->fields[0].type != MIXQ_FIELD_INT32 || adv->fields[0].data != nullptr ||
+            adv->fields[2].length != -1)
+            return 5;
+    }
     MixQPlugin* plugin = creator.createPlugin("layer", &fc);
     if (!plugin || plugin->initialize() != 0 || std::string(plugin->getPluginType()) != "MixQ" || plugin->getNbOutputs() != 1) return 5;
     const PluginFieldCollection bad = {2, fields};

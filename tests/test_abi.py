@@ -46,6 +46,17 @@ def test_registry_matches_reference_loader(lib):
     assert lib.mixq_plugin_type() == b"MixQ" and lib.mixq_plugin_version() == b"1"
 
 
+def test_creator_advertises_the_reference_field_table(lib):
+    """MixQPluginCreator::getFieldNames (TsinghuaMixQPlugin.cpp:890-893) returns the table its constructor fills (:868-878): three INT32
+    fields "mm", "mn", "mk" with no data and length -1 -- while createPlugin parses "m", "n", "k" (:906-919).  Both are mirrored."""
+    n = ctypes.c_int32(0)
+    f = lib.mixq_get_field_names(ctypes.byref(n))
+    assert n.value == 3
+    assert [(f[i].name, f[i].data, f[i].type, f[i].length) for i in range(3)] == [(b"mm", None, _lib.MIXQ_FIELD_INT32, -1), (b"mn", None, _lib.MIXQ_FIELD_INT32, -1),
+                                                                                   (b"mk", None, _lib.MIXQ_FIELD_INT32, -1)]
+    assert lib.mixq_get_field_names(None)   # a NULL count pointer is tolerated
+
+
 def test_lifecycle_serialize_clone(lib):
     vals = [np.array([v], np.int32) for v in (8192, 12288, 4096)]
     fields = (PluginField * 4)()

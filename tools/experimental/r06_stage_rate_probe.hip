@@ -226,7 +226,16 @@ int main(int argc, char** argv)
     CK(hipMalloc(&g_sink, 64));
     const Scenario scs[] = {{"l2priv", 256, 4096, 2, false}, {"l2shared", 1, 4096, 32, false}, {"mall", 128, 4096, 32, false},
                             {"hbm", 256, 4096, 32, true}};
-    const int slices = 256;
+    const int slices = argc > 1 ? atoi(argv[1]) : 256;
+    if (argc > 2) { // short form: the cold scenarios only, the GEMM-like issue shapes only (how much of a SHORT launch is ramp?)
+        for (int rep = 0; rep < 2; ++rep)
+            for (const Scenario& sc : {scs[3], scs[2], scs[0]}) {
+                run<0, 2, 3, 0>(sc, slices, 0);
+                run<0, 2, 3, 8>(sc, slices, 8);
+                run<0, 8, 3, 0>(sc, slices, 0);
+            }
+        return 0;
+    }
     for (const Scenario& sc : scs) {
         // who issues: 1 / 2 / 4 / 8 loader waves, LDS-DMA with SGPR base, 3 slices in flight (1 loader: vmcnt caps at 63 = 2 slices)
         run<0, 1, 2, 0>(sc, slices, 0);
