@@ -34,6 +34,7 @@ LLAMA2_7B = dict(name="Llama-2-7B", layers=32, linears=[("attention.qkv", 12288,
 # BASELINE.json configs 4 and 5: the other two models, as the (N, K) of their MixQ linears on ONE GPU
 QWEN2_7B = dict(name="Qwen2-7B-Instruct", layers=28, linears=[("attention.qkv", 4608, 3584), ("mlp.gate", 18944, 3584),
                                                             ("mlp.proj", 3584, 18944)])
+LLAMA2_70B = dict(name="Llama-2-70B", layers=80, linears=[("attention.qkv", 10240, 8192), ("mlp.gate", 28672, 8192), ("mlp.proj", 8192, 28672)])
 LLAMA2_70B_TP8 = dict(name="Llama-2-70B, one GPU's row shard at TP=8", layers=80,
                       linears=[("attention.qkv", 10240 // 8, 8192), ("mlp.gate", 28672 // 8, 8192), ("mlp.proj", 8192 // 8, 28672)])
 NUM_OUTLIERS = 128
@@ -637,6 +638,8 @@ def main():
     ap.add_argument("--no-tp-leg", action="store_true", help="skip the tp = N measurement at N > 1")
     ap.add_argument("--no-tp-alternatives", action="store_true", help="tp = N leg: do not time the other transports (one step each)")
     ap.add_argument("--tp-steps", type=int, default=3, help="timed steps of the tp = N measurement")
+    ap.add_argument("--no-config5", action="store_true", help="tp = N leg: skip BASELINE configs[4] (Llama-2-70B, rows of W sharded N ways + the all-gather)")
+    ap.add_argument("--config5-layers", type=int, default=80, help="decoder layers of the Llama-2-70B leg (80 = the model; the one-GPU tests run 1)")
     ap.add_argument("--variant", type=int, default=0, help="GEMM schedule: 0 auto, 1 two-barrier, 2 ping-pong (A/B runs)")
     args = ap.parse_args()
 
@@ -1060,6 +1063,42 @@ def main():
                 except Exception as e:  # noqa: BLE001
                     alts["error"] = repr(e)
                 tp_obj["alternatives_one_step_each"] = alts
+            # ---- BASELINE configs[4]: Llama-2-70B W8A8O16, rows of W sharded over the N GPUs of the node + ONE all-gather of the fp16
+            # output per linear (reference: tensorrt_llm plugin.py:97,155-156), bs x seq = the same tokens, 2 timed steps.
+            # The transport is opened -- and self-tested against the push-kernel transport, as the 7B leg above -- on the 70B shapes.
+            if not args.no_config5 and "error" not in tp_obj:
+                wd.cancel()
+                wd = threading.Timer(900.0, bail)
+                wd.daemon = True
+                wd.start()
+                c5 = None
+                try:
+                    tmodel.close()
+                    del tmodel
+                    torch.cuda.empty_cache()
+                    spec5 = dict(LLAMA2_70B, layers=args.config5_layers)
+                    m5 = Model(lib, TensorDesc, parallel, dev, gen, chunk, world, rank, spec=spec5, nrot=2)
+                    m5.open_peer_transport(parallel, rank)
+                    c_el, c_med, _, _ = timed_run(m5, None, 2, 1, False)
+                    c_to = any(g.timed_out() for g in m5.gatherers.values())
+                    recv5 = sum((world - 1) * args.tokens * (c[8] // world) * 2 for c in m5.calls)
+                    gop5 = sum(2.0 * n * k for _, n, k in spec5["linears"]) * spec5["layers"] / 1e9
+                    c5 = {"tp": world, "world_size": world, "value": args.tokens * 2 / c_el, "unit": "tokens/s", "ms_per_step": c_el / 2 * 1e3,
+                          "median_ms_per_step": c_med, "steps": 2, "warmup": 1, "scaling": "strong", "layers": spec5["layers"],
+                          "workload": (f"{spec5['name']}: {spec5['layers']} layers x " + ", ".join(f"{nm} {n}x{k}" for nm, n, k in spec5["linears"]) +
+                                       f", rows of W sharded {world} ways, bs x seq = {args.tokens} tokens"),
+                          "collective": "one all-gather of the fp16 output per linear per chunk", "transport": m5.transport,
+                          "transport_self_tested": "every gatherer against a known pattern, the fused store path against operator + push (Model.open_peer_transport)",
+                          "peer_wait_timed_out": c_to, "allgather_recv_GB_per_gpu_per_step": recv5 / 1e9, "int8_gop_per_token": gop5,
+                          "int8_tops_all_gpus": args.tokens * 2 / c_el * gop5 / 1e3, "tokens_per_step": args.tokens}
+                    if c_to:
+                        c5 = {"tp": world, "transport": m5.transport, "error": "a peer-write wait timed out: the gathered outputs of this leg are not valid"}
+                    m5.close()
+                    del m5
+                except Exception as e:  # noqa: BLE001 -- costs only this object
+                    c5 = {"tp": world, "error": repr(e)}
+                if rank == 0:
+                    res.setdefault("configs", {})[f"llama2_70b_tp{world}"] = c5
         except Exception as e:  # noqa: BLE001 -- the main measurement must survive
             tp_obj = {"tp": world, "error": repr(e)}
         wd.cancel()

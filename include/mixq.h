@@ -204,18 +204,21 @@ MIXQ_API int mixq_gemm_mixed_scratch(const int8_t* qA, const int8_t* W, const vo
  *   mixq_weight_image_register(...)      builds the image of `weight` into caller-owned device memory `image` and registers it under the
  *                                        pointer `weight` together with a 64-bit CONTENT TAG of the weight; registering again replaces it.
  *                                        Set-up work: two passes over the weight on `stream`, which it SYNCHRONISES (the only entries of
- *                                        this header that do, with _verify and the first use below)
+ *                                        this header that do, with _verify)
  *   mixq_weight_image_unregister(weight) forgets it -- REQUIRED before `weight` or `image` is freed or rewritten
  *   mixq_weight_image_verify(weight, s)  MIXQ_OK if the bytes behind `weight` still carry the registered tag, MIXQ_E_STALE if not (the
- *                                        entry is dropped: calls go back to reading `weight`), MIXQ_E_BADARG if nothing is registered;
- *                                        synchronises `s`
+ *                                        entry is dropped: calls go back to reading `weight`), MIXQ_E_BADARG if nothing is registered (or the
+ *                                        check itself failed: the entry is dropped as well); synchronises `s`
  * An address says nothing about what lives there: a weight freed and re-allocated at the same address with the same shape must not be
  * served the old tensor's image.  The image of a registration is therefore NOT TRUSTED until the bytes behind the pointer have been
- * compared with the tag on its FIRST USE (one pass over the weight + one synchronisation of the call's stream, once per registration;
- * a first use inside a stream capture cannot verify and reads `weight` itself -- run a call eagerly before capturing, as any graph
- * warm-up does); a mismatch drops the entry and counts in mixq_weight_image_stale_count().  After the first use the contract is the
- * usual one for a pointer held by a library: unregister before the memory changes hands (a captured graph holds the image pointer
- * like any other argument: keep image and registration alive as long as the graph).
+ * compared with the tag once more around its FIRST USE -- without blocking anybody: the first call on a registered weight enqueues the
+ * tag kernel (one pass over the weight) and an 8-byte copy on its own stream and reads `weight` itself, like every call until that work
+ * has completed; the first call that finds it complete compares the tags (equal: the image is streamed from then on; different: the
+ * entry is dropped and counted in mixq_weight_image_stale_count()).  The hot entries never allocate, free or synchronise (round 6:
+ * everything the check needs is allocated by _register).  A first use inside a stream capture cannot enqueue the check and reads `weight`
+ * itself -- call mixq_weight_image_verify after registering, or run a call eagerly before capturing, as any graph warm-up does.  After
+ * the check the contract is the usual one for a pointer held by a library: unregister before the memory changes hands (a captured graph
+ * holds the image pointer like any other argument: keep image and registration alive as long as the graph).
  * Process-global, thread-safe (readers share a lock; with nothing registered a lookup is one atomic load); every call looks its
  * weight up ONCE. */
 MIXQ_API size_t mixq_weight_image_bytes(int64_t N, int64_t K);
@@ -322,11 +325,13 @@ MIXQ_API int mixq_int4quant(int rows, int cols, const void* src_f16, uint8_t* ds
  * count).  gfx950 has no int4 MFMA; the int32 accumulators are nevertheless the reference's, bit for bit:
  *   M <= 64 (decode batches): ONE launch that streams the PACKED weight -- N * k_packed bytes, the HBM saving 4-bit weights are
  *     for -- and widens the nibbles in registers on their way into the int8 MFMA (csrc/int4_gemm_kernels.hip); `workspace` is not
- *     used and may be NULL;
+ *     used and may be NULL (K < 131040 elements: beyond, the unpack route below);
  *   M > 64: both operands are sign-extended to int8 in `workspace` (mixq_int4_fused_workspace_size bytes, caller-owned, 16-byte
  *     aligned) and the int8 MFMA kernels run on them.  A caller that can spare N * K bytes per layer widens the weight ONCE at
  *     load time (mixq_unpack_int4_to_int8) and calls mixq_int4_fused_dequantize_w8 instead: per call only A is widened.
- * k_packed % 16 == 0, N % 16 == 0.  y may be NULL (no addend). */
+ * k_packed % 16 == 0, N % 16 == 0.  y may be NULL (no addend).
+ * mixq_int4_fused_workspace_size(M, N, k_packed) = the bytes the call with these sizes REALLY needs: 0 where it streams the packed weight,
+ * both widened operands otherwise; N = 0 asks for the activation's part alone (the _w8 entry below). */
 MIXQ_API size_t mixq_int4_fused_workspace_size(int M, int N, int k_packed);
 MIXQ_API int mixq_int4_fused_dequantize(const uint8_t* A, const uint8_t* B, const void* scale_row, const void* scale_col,
                                         const void* y, void* D, int M, int N, int k_packed, char* workspace,
@@ -399,14 +404,18 @@ MIXQ_API int mixq_tp_wait(const void* flags, int nprod, int word0, int nwords, u
  *                             into peer_ack_words[r] (rank r's acknowledge word for THIS consumer: MIXQ_TP_FLAG_WORDS-strided block
  *                             of r, one word per consumer) for every r < npeer, then waits until own_ack_words[c * MIXQ_TP_FLAG_WORDS]
  *                             == s for every consumer c < npeer of OUR push
- *   mixq_tp_push_columns_seq  as mixq_tp_push_columns with seq = s, one flag word
+ *   mixq_tp_push_columns_seq  as mixq_tp_push_columns with seq = s, one flag word; status_dev (may be NULL) = the sticky status word of the
+ *                             arrive / wait calls: once it is raised (an arrive timed out: some peer has not acknowledged that its single
+ *                             destination buffer may be overwritten) the push stores NOTHING and publishes no flag, so that a slow peer
+ *                             never reads a torn tensor -- its own wait of this call times out instead
  *   mixq_tp_wait_seq          waits for flags[r * MIXQ_TP_FLAG_WORDS] == s for every producer r < nprod, then *seq_word = s
  * The three may be captured in a HIP graph, replayed any number of times and mixed with eager calls on the same objects.
  * Time-outs as mixq_tp_wait (sticky status word; optional trap). */
 MIXQ_API int mixq_tp_arrive(void* const* peer_ack_words, const void* own_ack_words, int npeer, const void* seq_word,
                             void* status_dev, int trap_on_timeout, uint32_t patience_ms, void* stream);
 MIXQ_API int mixq_tp_push_columns_seq(const void* src, void* const* dst_bases, void* const* dst_flags, int ndst, int M,
-                                      int n_local, int N, int col0, const void* seq_word, void* done_counter, void* stream);
+                                      int n_local, int N, int col0, const void* seq_word, void* done_counter, const void* status_dev,
+                                      void* stream);
 MIXQ_API int mixq_tp_wait_seq(const void* flags, int nprod, void* seq_word, void* status_dev, int trap_on_timeout,
                               uint32_t patience_ms, void* stream);
 

@@ -141,7 +141,7 @@ SIGNATURES = {
                                   _vp, _vp]),
     "mixq_tp_wait": (_i, [_vp, _i, _i, _i, ctypes.c_uint32, _vp, _i, ctypes.c_uint32, _vp]),
     "mixq_tp_arrive": (_i, [ctypes.POINTER(_vp), _vp, _i, _vp, _vp, _i, ctypes.c_uint32, _vp]),
-    "mixq_tp_push_columns_seq": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "mixq_tp_push_columns_seq": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "mixq_tp_wait_seq": (_i, [_vp, _i, _vp, _vp, _i, ctypes.c_uint32, _vp]),
     "mixq_tp_fused_supported": (_i, [_i64, _i64, _i64]),
     "mixq_tp_flag_words": (_i, [_i64]),

@@ -261,6 +261,22 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KG * 64) void gemm_w8a8o16_kernel
         }
     }
 
+    // ---- (round 6) the scales the epilogue multiplies by are requested HERE, under the hand-overs and the outlier staging below: the store
+    // loop used to load sA[m] and sW[n .. n + 3] right where it needed them -- a dependent L2 round trip in front of every tile's first store
+    // (the mid-M kernel's timeline priced the same pattern at 1.3 us per tile, profiles/r06_mid_v1_timeline.txt).  Clamped: rows / columns past
+    // the edge are never stored.
+    float sa_pre[TM];
+    uint2 sw_pre[TN][4];
+    if (EPI != EPI_INT32) {
+#pragma unroll
+        for (int j = 0; j < TM; ++j) sa_pre[j] = h2f(p.sA[min(m0 + wm * WM + j * 32 + lr, p.M - 1)]);
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                sw_pre[i][g] = *reinterpret_cast<const uint2*>(p.sW + min(n0 + wn * WN + i * 32 + 4 * lh + 8 * g, p.N - 4));
+    }
+
     // ---- in-workgroup split-K: partial accumulators of groups 1.. -> LDS -> added by group 0 ----------
     if (KG > 1) {
         __syncthreads(); // main-loop LDS is dead
@@ -383,12 +399,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* KG * 64) void gemm_w8a8o16_kernel
                 }
             }
             if (m < p.M) {
-                const float sa = h2f(p.sA[m]);
+                const float sa = sa_pre[j];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int nb = nb0 + 8 * g;
                     if (nb < p.N) {
-                        const uint2 swb = *reinterpret_cast<const uint2*>(p.sW + nb);
+                        const uint2 swb = sw_pre[i][g];
                         const uint16_t swh[4] = {(uint16_t)(swb.x & 0xffffu), (uint16_t)(swb.x >> 16),
                                                  (uint16_t)(swb.y & 0xffffu), (uint16_t)(swb.y >> 16)};
                         uint16_t yh[4] = {0, 0, 0, 0};
@@ -514,7 +530,7 @@ static std::atomic<int> g_deep_force{-1}; // -1 automatic, 0 off, 1 / 2 / 4 / 8:
 struct DeepPlan {
     int xs;    // 0 = not used; workgroups per 128 x 128 tile otherwise
     int tiles;
-    int waves8; // build: 0 = 4 waves x 64 x 64, 1 = 8 waves x 64 x 32 (4 stages), 2 = 8 waves, 5 stages
+    int waves8; // build: 0 = 4 waves x 64 x 64, 1 = 8 waves x 64 x 32 (4 stages), 2 = 8 waves, 5 stages, 3 = round 6: copy-only waves + one barrier per pair of slices (gemm_mid_kernels.hip)
 };
 // The automatic rule: a table over (128 x 128 tiles, K slices), read off a sweep of every build x split against the selection as it
 // was, on COLD weights (a model's layer never finds its weights cache-resident), profiles/r05_deep_form_sweep_cold.txt -- 110 cells
@@ -527,15 +543,21 @@ struct DeepPlan {
 // Everywhere else it is level or behind (the ping-pong tiles multiply a slice in less than half the time per CU; warm weights:
 // level) and is not used.  8 waves x (64 x 32) beat 4 waves x (64 x 64) in every cell; a fifth LDS stage changed nothing, neither did
 // 16 waves x (32 x 32); the same loop on 128 x 256 tiles is behind the ping-pong kernel of that tile (profiles/r05_deep_form_builds.txt).
+static std::atomic<int> g_deep_mid{1}; // measurement knob 1420 (default) / 1421: the automatic plan takes the round-6 schedule from 129 rows on / never
 static DeepPlan deep_plan_auto(int M, int N, int K, int tiles, int nk)
 {
-    (void)N, (void)K;
+    (void)N;
     const int cus = num_cus();
     if (cus != 256) return DeepPlan{0, 0, 0}; // (the table counts workgroups against the 256 CUs it was measured on)
     // (first row: only where the 64 x 64 tiles are past their forms with K split inside the workgroup -- more than 512 of them;
     //  below that those are ahead: 448 x 4608 x 3584 19.5 vs 23.7 us, 288 x 6144 x 4096 21.6 vs 26.0, validation sweep of the table)
     const int64_t wg64 = (int64_t)((M + 63) / 64) * ((N + 63) / 64);
-    if (tiles >= 140 && tiles <= 256 && nk >= 24 && nk <= 40 && wg64 > 512) return DeepPlan{1, tiles, 1}; // (measured at K = 3584 .. 5120 only)
+    // (round 6) from 129 rows on every row of the table runs the round-6 schedule of the same tiles (gemm_mid_kernels.hip; whole 128-byte slices only):
+    // cold, all ten BASELINE (N, K), 35 cells: ahead of the round-5 build in 33, by 6-25 % (12288 / 11008 x 4096 at 160..256 rows 27-28 -> 24.4-26.2 us,
+    // 3584 x 8192 at 320 / 384 rows 30.5 -> 26 us, 4608 x 3584 at 512 rows 24.7 -> 20.6, 1280 x 8192 at 1024 rows 30.4 -> 24.3, 1024 x 28672 at 320 rows
+    // 34.7 -> 31.3); level at 97..128 rows, which keep the round-5 build (profiles/r06_mid_final_sweep_cold.txt)
+    const int mid = M > 128 && K % KSLICE == 0 && g_deep_mid.load() ? 3 : 1;
+    if (tiles >= 140 && tiles <= 256 && nk >= 24 && nk <= 40 && wg64 > 512) return DeepPlan{1, tiles, mid}; // (measured at K = 3584 .. 5120 only)
     // (97..128 rows on one row of 70..128 tiles at K = 3072..5120: two workgroups per tile put 140..256 workgroups on the chip where the
     //  64 x 64 tiles with two K groups inside the workgroup run 1.5 rounds -- profiles/r05_int8_forms_cold.jsonl: 12288 x 4096 at 128 rows
     //  24.2 -> 22.7 us, 11008 x 4096 24.2 -> 22.0; at 96 rows -1..-5 %, at 72 rows level: from 97 rows)
@@ -543,9 +565,9 @@ static DeepPlan deep_plan_auto(int M, int N, int K, int tiles, int nk)
     if (M <= 128) return DeepPlan{0, 0, 0};
     // (second row at K < 8192 only past 256 tiles of 64 x 64: one workgroup per CU of those with K split four ways inside it is
     //  ahead below -- 160 / 192 x 5120 x 5120: 20.0 / 20.9 vs 23.1 / 23.5 us, profiles/r05_int8_forms_cold.jsonl)
-    if (tiles >= 70 && tiles <= 128 && nk >= 40 && nk <= 100 && (nk >= 64 || wg64 > 256)) return DeepPlan{2, tiles, 1};
-    if (tiles >= 36 && tiles <= 64 && nk >= 64 && nk <= 160) return DeepPlan{4, tiles, 1};
-    if (M > 256 && tiles >= 20 && tiles <= 32 && nk >= 200) return DeepPlan{8, tiles, 1};
+    if (tiles >= 70 && tiles <= 128 && nk >= 40 && nk <= 100 && (nk >= 64 || wg64 > 256)) return DeepPlan{2, tiles, mid};
+    if (tiles >= 36 && tiles <= 64 && nk >= 64 && nk <= 160) return DeepPlan{4, tiles, mid};
+    if (M > 256 && tiles >= 20 && tiles <= 32 && nk >= 200) return DeepPlan{8, tiles, mid};
     return DeepPlan{0, 0, 0};
 }
 static DeepPlan deep_plan(int M, int N, int K)
@@ -563,6 +585,7 @@ static DeepPlan deep_plan(int M, int N, int K)
     }
     return deep_plan_auto(M, N, K, (int)tiles, nk);
 }
+int gemm_deep_build(int M, int N, int K);
 bool gemm_deep_takes(int M, int N, int K, bool have_scratch)
 {
     const DeepPlan pl = deep_plan(M, N, K);
@@ -676,8 +699,12 @@ void set_gemm_variant(int v)
         g_deep_late.store(v == 1238);
         return;
     }
-    if (v >= 1400 && v <= 1409) { // round-6 mid kernel build (gemm_mid_kernels.hip)
-        set_mid_build(v - 1400);
+    if (v == 1420 || v == 1421) { // the automatic deep plan: round-6 schedule from 129 rows on (1420, default) / the round-5 build everywhere (1421)
+        g_deep_mid.store(v == 1420);
+        return;
+    }
+    if (v >= 1410 && v <= 1412) { // round-6 mid kernel: tile rows start at different K slices: 1410 where K is not split over workgroups (default) / 1411 never / 1412 always
+        set_mid_rot(v == 1410 ? 1 : v == 1411 ? 0 : 2);
         return;
     }
     if (v >= 1240 && v <= 1279) { // mid-M deep form: 1240 automatic, 1241 off, 1241 + xs (1242 / 1243 / 1245 / 1249) forced, + 10 the 8-wave build, + 30 the round-6 schedule
@@ -905,7 +932,8 @@ hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st)
         return launch_gemm_skinny(p, epi, st);
     }
     if (variant == 0 && epi != EPI_INT32 && p.a_frag == 0 && gemm_deep_takes(p.M, p.N, p.K, p.splitk_ws != nullptr)) {
-        chose("gemm_w8a8o16_kernel<DEEP> (128x128 tiles, 4 stages in flight, K split over workgroups)");
+        if (gemm_deep_build(p.M, p.N, p.K) == 3) chose("gemm_w8a8o16_mid_kernel<DEEP> (128x128 tiles, copy-only waves, one barrier per pair of slices, K split over workgroups)");
+        else chose("gemm_w8a8o16_kernel<DEEP> (128x128 tiles, 4 stages in flight, K split over workgroups)");
         return launch_gemm_deep(p, epi, st);
     }
     const int64_t tiles256 = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256);
@@ -936,6 +964,8 @@ hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st)
     }
 }
 
+int gemm_deep_build(int M, int N, int K) { return deep_plan(M, N, K).waves8; }
+
 int gemm_deep_factor(int M, int N, int K, bool have_scratch)
 {
     const DeepPlan pl = deep_plan(M, N, K);
@@ -962,7 +992,8 @@ void describe_gemm_plan(const GemmParams& p, int epi, char* buf, size_t len)
         return;
     }
     if (variant == 0 && epi != EPI_INT32 && p.a_frag == 0 && gemm_deep_takes(p.M, p.N, p.K, scratch)) {
-        snprintf(buf, len, "deep: 128x128 tiles, %d workgroup(s) per tile along K", gemm_deep_factor(p.M, p.N, p.K, scratch));
+        snprintf(buf, len, "deep: 128x128 tiles, %d workgroup(s) per tile along K%s", gemm_deep_factor(p.M, p.N, p.K, scratch),
+                 gemm_deep_build(p.M, p.N, p.K) == 3 ? ", copy-only waves" : "");
         return;
     }
     const int64_t tiles256 = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256);

@@ -19,8 +19,9 @@
 //   * ONE barrier per PAIR of slices (1024 MFMA cycles per SIMD between barriers): ring of five 32-KiB stages, two being
 //     multiplied, three in flight;
 //   * after the loop the groups swap halves through LDS (each wave gives away one 64 x 32 half and adds the partner's to the one it
-//     keeps: integer adds, same sums), so the epilogue runs on all eight waves; the outlier operands were copied by the loader
-//     waves under that exchange.
+//     keeps: integer adds, same sums), so the epilogue runs on all eight waves; the outlier operands are copied by the loader
+//     waves behind the LAST loop barrier into the two stages the last-but-one pair has handed back, and the scales / addends the
+//     epilogue needs were requested at kernel start: nothing in the epilogue waits for global memory.
 // K split over XS workgroups per tile ("last arriver adds", as in gemm_kernels.hip) on the post-exchange layout.
 #include "mixq_device.h"
 #include "mixq_launch.h"
@@ -45,20 +46,59 @@ static_assert(EXCH + (BM + BN) * OSLICE <= LDS, "exchange + outlier tiles must f
 // ---- what a compute wave does behind the main loop (both schedules): swap halves, K split over workgroups, epilogue ------------
 // `acc`: the wave's 64 x 64 sums over its group's slices; barriers B0, B1 (+ B2, B3 with XSP) are executed by EVERY wave of the
 // workgroup (the copy-only waves run mid_loader_tail next to this).
+// LDS regions (byte offsets, wave-uniform): ex0 / ex1 = 32 KiB each, the exchange slots of waves 0-3 / 4-7; ow / oa = the fpW / fpA tiles
+// (32 KiB each) the copy-only waves staged.
+// What the epilogue reads from global memory, requested by a compute wave at KERNEL START and carried through the loop (10 registers, + 16
+// with an addend; the multiplicand of gate * up is requested in front of the exchange instead: 16 registers more through the loop spill): the first build loaded sA / sW / y inside the store loop -- a dependent L2 round trip per 8-byte store
+// group, 3.8 us of epilogue per tile in its timeline (profiles/r06_mid_v1_timeline.txt).  Clamped addresses: rows / columns past the edge
+// are never stored.
+struct MidEpiPre {
+    float sa[2];
+    uint2 sw[4], y[2][4];
+};
+template <int EPI>
+__device__ __forceinline__ void mid_epi_prefetch(MidEpiPre& e, const GemmParams& p, int wave, int lane, int m0, int n0)
+{
+    const int group = wave >> 2, w4 = wave & 3, wm = w4 >> 1, wn = w4 & 1;
+    const int lr = lane & 31, lh = lane >> 5;
+    if (EPI == EPI_INT32) return;
+    const int nb0p = n0 + wn * 64 + group * 32 + 4 * lh;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) e.sw[g] = *reinterpret_cast<const uint2*>(p.sW + min(nb0p + 8 * g, p.N - 4));
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int mp = min(m0 + wm * 64 + jj * 32 + lr, p.M - 1);
+        e.sa[jj] = h2f(p.sA[mp]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int64_t at = (int64_t)mp * p.N + min(nb0p + 8 * g, p.N - 4);
+            e.y[jj][g] = p.Y != nullptr ? *reinterpret_cast<const uint2*>(p.Y + at) : make_uint2(0u, 0u);
+        }
+    }
+}
+
 template <int EPI, bool XSP, int TC>
 __device__ __forceinline__ void mid_finish(const GemmParams& p, char* smem, v16i (&acc)[2][2], int wave, int lane, int tid, int m0, int n0,
-                                           int t_lin, int xrank, int XS)
+                                           int t_lin, int xrank, int XS, const MidEpiPre& pre, int ex0, int ex1, int ow, int oa)
 {
     using namespace mid;
     const int group = wave >> 2, w4 = wave & 3, wm = w4 >> 1, wn = w4 & 1;
     const int lr = lane & 31, lh = lane >> 5;
     const bool has_outliers = p.O > 0;
     dbg_stamp(p.dbg, 3); // last MFMA issued (this wave)
+    uint2 mulq[2][4]; // (the multiplicand of gate * up: requested here, in front of the exchange)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int64_t at = (int64_t)min(m0 + wm * 64 + jj * 32 + lr, p.M - 1) * p.N + min(n0 + wn * 64 + group * 32 + 4 * lh + 8 * g, p.N - 4);
+            mulq[jj][g] = EPI == EPI_DEQUANT_SILU_MUL ? *reinterpret_cast<const uint2*>(p.Mul + at) : make_uint2(0u, 0u);
+        }
     // ---- the two groups swap halves: group 0 keeps n half 0 and adds group 1's, group 1 keeps n half 1 ---------------------------
     __syncthreads(); // B0
     v16i fin[2];
     {
-        char* const mine = smem + wave * 8192;
+        char* const mine = smem + (wave < 4 ? ex0 : ex1) + (wave & 3) * 8192;
         // (compile-time half index: a run-time index into acc[][] would put the accumulators into scratch memory)
         auto park = [&](auto half_tag) __attribute__((always_inline)) {
             constexpr int hx = decltype(half_tag)::value;
@@ -72,7 +112,7 @@ __device__ __forceinline__ void mid_finish(const GemmParams& p, char* smem, v16i
         if (group == 0) park(std::integral_constant<int, 1>{});
         else park(std::integral_constant<int, 0>{});
         __syncthreads(); // B1 (the loader waves' outlier copies have landed by now as well)
-        const char* const theirs = smem + (wave ^ 4) * 8192;
+        const char* const theirs = smem + (wave < 4 ? ex1 : ex0) + (wave & 3) * 8192;
         if (group == 0) {
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) fin[jj] = acc[0][jj];
@@ -94,7 +134,10 @@ __device__ __forceinline__ void mid_finish(const GemmParams& p, char* smem, v16i
 
     // ---- K split over workgroups: park, count in, and only the last one to arrive goes on (gemm_kernels.hip, XSP) -------------
     if (XSP) {
-        volatile unsigned& arrived_s = *reinterpret_cast<volatile unsigned*>(smem);
+        // (the word lives in the exchange region, dead behind B2; explicit LDS address space: a generic pointer becomes a FLAT access, whose
+        //  LDS aperture ends at 64 KiB)
+        typedef __attribute__((address_space(3))) volatile unsigned lds_vu32;
+        lds_vu32& arrived_s = *(lds_vu32*)MIXQ_LDS_PTR(smem + ex0);
         constexpr int TILE_DW = 2 * 16 * TC; // dwords of one parked tile: [m half][16][512 compute threads]
         unsigned* const counter = static_cast<unsigned*>(p.splitk_ws) + t_lin;
         int* const slots = reinterpret_cast<int*>(static_cast<char*>(p.splitk_ws) + kSplitkWordsBytes) + (size_t)t_lin * XS * TILE_DW;
@@ -121,7 +164,6 @@ __device__ __forceinline__ void mid_finish(const GemmParams& p, char* smem, v16i
     }
 
     // ---- epilogue: two 32 x 32 tiles per wave (gemm_kernels.hip's arithmetic, statement by statement) ----------------------------
-    const char* const osmem = smem + EXCH;
     const int osteps = has_outliers ? (p.O + 15) / 16 : 0;
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
@@ -144,8 +186,8 @@ __device__ __forceinline__ void mid_finish(const GemmParams& p, char* smem, v16i
 #pragma unroll
         for (int e = 0; e < 16; ++e) P[e] = 0.f;
         if (has_outliers) {
-            const char* xo = osmem + (wn * 64 + nh * 32 + lr) * OSLICE;
-            const char* yo = osmem + BN * OSLICE + (wm * 64 + jj * 32 + lr) * OSLICE;
+            const char* xo = smem + ow + (wn * 64 + nh * 32 + lr) * OSLICE;
+            const char* yo = smem + oa + (wm * 64 + jj * 32 + lr) * OSLICE;
             const int sw16 = lr & 15;
             if (osteps == 8) { // O = 128 (every shipped checkpoint): all sixteen fragment reads in flight, then eight MFMAs (same order, same sums)
                 v8h xfo[8], yfo[8];
@@ -167,17 +209,17 @@ __device__ __forceinline__ void mid_finish(const GemmParams& p, char* smem, v16i
             }
         }
         if (m < p.M) {
-            const float sa = h2f(p.sA[m]);
+            const float sa = pre.sa[jj];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int nb = nb0 + 8 * g;
                 if (nb < p.N) {
-                    const uint2 swb = *reinterpret_cast<const uint2*>(p.sW + nb);
+                    const uint2 swb = pre.sw[g];
                     const uint16_t swh[4] = {(uint16_t)(swb.x & 0xffffu), (uint16_t)(swb.x >> 16), (uint16_t)(swb.y & 0xffffu),
                                              (uint16_t)(swb.y >> 16)};
                     uint16_t yh[4] = {0, 0, 0, 0};
                     if (p.Y != nullptr) {
-                        const uint2 yb = *reinterpret_cast<const uint2*>(p.Y + (int64_t)m * p.N + nb);
+                        const uint2 yb = pre.y[jj][g];
                         yh[0] = (uint16_t)(yb.x & 0xffffu), yh[1] = (uint16_t)(yb.x >> 16);
                         yh[2] = (uint16_t)(yb.y & 0xffffu), yh[3] = (uint16_t)(yb.y >> 16);
                     }
@@ -191,7 +233,7 @@ __device__ __forceinline__ void mid_finish(const GemmParams& p, char* smem, v16i
                         oh[e] = f2h_bits_of_f32_result(v);
                     }
                     if (EPI == EPI_DEQUANT_SILU_MUL) { // gate * up: one fp16 multiply of the rounded result
-                        const uint2 mb = *reinterpret_cast<const uint2*>(p.Mul + (int64_t)m * p.N + nb);
+                        const uint2 mb = mulq[jj][g];
                         const uint16_t mh[4] = {(uint16_t)(mb.x & 0xffffu), (uint16_t)(mb.x >> 16), (uint16_t)(mb.y & 0xffffu),
                                                 (uint16_t)(mb.y >> 16)};
 #pragma unroll
@@ -212,34 +254,22 @@ __device__ __forceinline__ void mid_finish(const GemmParams& p, char* smem, v16i
     }
 }
 
-// ---- what a copy-only wave does behind the main loop: the outlier operands -> LDS under the compute waves' exchange ------------
-template <int EPI, bool XSP>
-__device__ __forceinline__ void mid_loader_tail(const GemmParams& p, unsigned lds0, int lw /* 0: fpW, 1: fpA, 2: nothing */, int lane, int m0, int n0)
+// ---- copy-only waves: the outlier operands -> LDS (wave lw = 0: the fpW tile, 1: the fpA tile; 32 copies of 1 KiB, not waited for here) -----
+__device__ __forceinline__ void mid_stage_outliers(const GemmParams& p, unsigned lds_dst, int lw, int lane, int m0, int n0)
 {
     using namespace mid;
-    const bool has_outliers = p.O > 0;
     const int rows_total = lw == 0 ? p.N : p.M, r0 = lw == 0 ? n0 : m0;
-        __syncthreads(); // B0: every slice multiplied, the ring is dead
-        if (EPI != EPI_INT32 && has_outliers && lw < 2) { // fpW (wave 8) / fpA (wave 9) tiles -> LDS, 256-B rows, slot = chunk ^ (row & 15)
-            const int obytes = p.O * 2;
-            const char* const ob = lw == 0 ? reinterpret_cast<const char*>(p.fpW) : reinterpret_cast<const char*>(p.fpA);
-            const unsigned dst = lds0 + EXCH + lw * (BN * OSLICE);
+    const int obytes = p.O * 2;
+    const char* const ob = lw == 0 ? reinterpret_cast<const char*>(p.fpW) : reinterpret_cast<const char*>(p.fpA);
 #pragma unroll 8
-            for (int q = 0; q < 32; ++q) {
-                const int row = q * 4 + (lane >> 4);
-                const int c = ((lane & 15) ^ (row & 15)) << 4;
-                const int grow = min(r0 + row, rows_total - 1);
-                const char* s = ob + (int64_t)grow * obytes + c;
-                if (c >= obytes) s = static_cast<const char*>(p.zeros);
-                glds16_vaddr(s, dst + q * 1024);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads(); // B1
-        if (XSP) {
-            __syncthreads(); // B2
-            __syncthreads(); // B3
-        }
+    for (int q = 0; q < 32; ++q) { // 256-B rows, slot = chunk ^ (row & 15); chunks past O come from the zero page
+        const int row = q * 4 + (lane >> 4);
+        const int c = ((lane & 15) ^ (row & 15)) << 4;
+        const int grow = min(r0 + row, rows_total - 1);
+        const char* s = ob + (int64_t)grow * obytes + c;
+        if (c >= obytes) s = static_cast<const char*>(p.zeros);
+        glds16_vaddr(s, lds_dst + q * 1024);
+    }
 }
 
 template <int EPI, bool XSP>
@@ -293,9 +323,17 @@ __global__ __launch_bounds__(mid::T) void gemm_w8a8o16_mid_kernel(const GemmPara
         const char* const base = (lw == 0 ? reinterpret_cast<const char*>(p.B) : reinterpret_cast<const char*>(p.A)) +
                                  (int64_t)r0 * K + (int64_t)kbeg * KS;
         const bool nt = lw == 0 && (p.flags & 2) != 0;
+        // Tiles that share a W panel (the tile rows of one tile column) run at the same time on neighbouring CUs.  Walking K from the same
+        // slice they ask for the same cold lines at the same moment: one is the miss, the others wait on it, and every one of them has a queue
+        // slot tied up for the whole HBM round trip (a CU keeps ~32 KiB of requests outstanding, R6.5).  Each tile row therefore STARTS at a
+        // different slice of its K range (integer sums commute: same bits): a line is then fetched from HBM by one CU and found in L2 / the
+        // Infinity Cache by the others a few microseconds later.  (p.flags bit 2 off: measurement knob 1411.)
+        const int rot = (p.flags & 4) ? (int)(((int64_t)tile_m * nk) / tiles_m + ((tile_n * 5) % 7)) % nk : 0;
         auto issue = [&](int s) __attribute__((always_inline)) {
             const unsigned dst = lds0 + (unsigned)(s % NST) * STAGE + lw * XB;
-            const char* b = base + (int64_t)s * KS; // wave-uniform
+            int sr = s + rot;
+            if (sr >= nk) sr -= nk;
+            const char* b = base + (int64_t)sr * KS; // wave-uniform
             if (nt) {
 #pragma unroll
                 for (int i = 0; i < PER; ++i) glds16_sbase_nt(b, voff[i], dst + i * 1024);
@@ -307,15 +345,31 @@ __global__ __launch_bounds__(mid::T) void gemm_w8a8o16_mid_kernel(const GemmPara
 #pragma unroll
         for (int s = 0; s < 3; ++s)
             if (s < nk) issue(s);
+        unsigned long long t_wait = 0, t_bar = 0; // (measurement only, p.dbg != NULL: 100 MHz ticks this wave spent waiting for its copies / at the barrier)
         for (int j = 0; j < npair; ++j) {
             // issued so far: slices .. 2j + 2; the pair 2j, 2j + 1 must have landed (copies complete in order)
+            const unsigned long long ta = p.dbg ? wall_clock64() : 0;
             if (2 * j + 2 < nk) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long tb = p.dbg ? wall_clock64() : 0;
             __syncthreads(); // pair j handed over; the compute waves are done with pair j - 1
+            if (p.dbg) t_wait += tb - ta, t_bar += wall_clock64() - tb;
             if (2 * j + 3 < nk) issue(2 * j + 3);
             if (2 * j + 4 < nk) issue(2 * j + 4);
         }
-        mid_loader_tail<EPI, XSP>(p, lds0, lw, lane, m0, n0);
+        // the outlier operands go into the two stages the LAST BUT ONE pair has just handed back (nothing is issued into them any more), so
+        // that they land under the last pair's MFMAs and the exchange instead of behind it; the exchange takes the last pair's own stages
+        const bool has_o = EPI != EPI_INT32 && has_outliers;
+        if (has_o) mid_stage_outliers(p, lds0 + (unsigned)((2 * npair + 1 + lw) % NST) * STAGE, lw, lane, m0, n0);
+        if (p.dbg != nullptr && lane == 0) // slot 7: the W loader, slot 2: the qA loader; (ticks waiting for copies) << 32 | ticks at the barrier
+            static_cast<unsigned long long*>(p.dbg)[(size_t)blockIdx.x * 8 + (lw == 0 ? 7 : 2)] = (t_wait << 32) | (t_bar & 0xffffffffull);
+        __syncthreads(); // B0
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the outlier tiles
+        __syncthreads(); // B1
+        if (XSP) {
+            __syncthreads(); // B2
+            __syncthreads(); // B3
+        }
         return;
     }
 
@@ -331,6 +385,8 @@ __global__ __launch_bounds__(mid::T) void gemm_w8a8o16_mid_kernel(const GemmPara
     const int xrow = (wn * 64 + lr) * KS;
     const int yrow = XB + (wm * 64 + lr) * KS;
 
+    MidEpiPre pre;
+    mid_epi_prefetch<EPI>(pre, p, wave, lane, m0, n0);
     v16i acc[2][2]; // [n half][m half]
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -343,7 +399,6 @@ __global__ __launch_bounds__(mid::T) void gemm_w8a8o16_mid_kernel(const GemmPara
     for (int j = 0; j < npair; ++j) {
         __syncthreads();
         if (j == 0) dbg_stamp(p.dbg, 1);           // first pair of slices handed over
-        if (j == npair / 2) dbg_stamp(p.dbg, 2);   // half of the pairs multiplied
         const int kt = 2 * j + group;
         if (kt < nk) {
             const char* base = smem + (kt % NST) * STAGE;
@@ -372,233 +427,14 @@ __global__ __launch_bounds__(mid::T) void gemm_w8a8o16_mid_kernel(const GemmPara
         }
     }
 
-    mid_finish<EPI, XSP, TC>(p, smem, acc, wave, lane, tid, m0, n0, t_lin, xrank, XS);
+    // (pair P = npair - 1 is the last: its slices 2P, 2P + 1 sit in stages 2P % 5, (2P + 1) % 5 -> the exchange; the pair before it in
+    //  (2P + 3) % 5, (2P + 4) % 5 -> the outlier tiles)
+    mid_finish<EPI, XSP, TC>(p, smem, acc, wave, lane, tid, m0, n0, t_lin, xrank, XS, pre, ((2 * npair - 2) % NST) * STAGE, ((2 * npair - 1) % NST) * STAGE,
+                             ((2 * npair + 1) % NST) * STAGE, ((2 * npair + 2) % NST) * STAGE);
 }
 
-// ---- second schedule (round 6, R6.3): NO barrier in the main loop -- slices are handed over through LDS flag words -------------------------
-// v1 above waits, once per pair, for a slice it issued in the same iteration (a ring of five 32-KiB stages is all of LDS), so an iteration
-// costs at least one L2 round trip (~1 us warm, ~2 us cold).  Here each operand has its OWN ring of 16-KiB stages (W: NW deep, qA: NQ deep,
-// NW + NQ <= 9: 144 KiB + the flag words), filled by its loader wave as far ahead as the ring allows, and a slice is multiplied the moment it
-// has landed:
-//   landed[w]      slices of operand w that have landed, published by the loader after `s_waitcnt vmcnt(16 LAG)` (copies complete in order);
-//   done[w][stage] +1 per compute wave that has taken its last fragment of the stage's current slice (4 per use: one group); the loader
-//                  re-fills a stage when its count reaches 4 x uses.
-// Compute waves poll `landed` (one broadcast ds_read_b64, s_sleep between polls); group g multiplies slices g, g + 2, ... as before, so on
-// every SIMD one wave multiplies while its partner polls or reads.  PF: a third producer wave touches one dword per 128-byte line of the W
-// slices PFD ahead of the W loader (global -> register, thrown away): the lines are in L2 when the copy asks for them -- for COLD weights
-// (a model's layer never finds its weights cache-resident), where three or four 16-KiB copies in flight per CU do not cover HBM's latency.
-namespace midf {
-constexpr int REG = 16384;  // one operand's 128 rows x 128 B
-constexpr int PFD = 8;      // slices the prefetch wave runs ahead of `landed`
-}
-
-template <int EPI, bool XSP, int NW, int NQ, bool PF>
-__global__ __launch_bounds__((10 + (PF ? 1 : 0)) * 64) void gemm_w8a8o16_midf_kernel(const GemmParams p)
-{
-    using namespace mid;
-    constexpr int REG = midf::REG;
-    static_assert(NW + NQ <= 9 && NW >= 3 && NQ >= 3, "rings + flag words must fit 160 KiB");
-    static_assert((NW + NQ) * REG >= EXCH + (BM + BN) * OSLICE, "exchange + outlier tiles must fit the rings' LDS");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int XS = XSP ? p.xsplit : 1;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-    const int nwg = tiles_m * tiles_n;
-    int t_lin;
-    const int xrank = XSP ? (int)blockIdx.x % XS : 0;
-    {
-        const int bid = XSP ? (int)blockIdx.x / XS : (int)blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-        t_lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    int tile_m, tile_n;
-    {
-        const int per_group = GROUP_M * tiles_n;
-        const int g = t_lin / per_group, first_m = g * GROUP_M;
-        const int gsz = min(tiles_m - first_m, GROUP_M);
-        const int within = t_lin - g * per_group;
-        tile_m = first_m + within % gsz;
-        tile_n = within / gsz;
-    }
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int64_t K = p.K;
-    const int nk_all = p.K / KS;
-    const int kbeg = XSP ? nk_all * xrank / XS : 0;
-    const int nk = (XSP ? nk_all * (xrank + 1) / XS : nk_all) - kbeg;
-    const unsigned lds0 = (unsigned)(size_t)(MIXQ_LDS_PTR(smem));
-    // flag words behind the rings: [0] landed W, [1] landed qA, [4 + st] done W stage st, [12 + st] done qA stage st
-    // (explicit LDS address space: through a generic pointer hipcc emits FLAT accesses, and the flat LDS aperture does not reach words
-    //  beyond 64 KiB -- the first build died with a memory-aperture violation on exactly these)
-    typedef __attribute__((address_space(3))) volatile unsigned lds_vu32;
-    typedef unsigned v2u __attribute__((ext_vector_type(2)));
-    typedef __attribute__((address_space(3))) volatile v2u lds_v2u;
-    lds_vu32* const flags = (lds_vu32*)MIXQ_LDS_PTR(smem + (NW + NQ) * REG);
-    const unsigned flags_addr = lds0 + (NW + NQ) * REG;
-    if (tid < 32) flags[tid] = 0u;
-    __syncthreads();
-
-    if (wave >= NCW) {
-        const int lw = wave - NCW; // 0: W loader, 1: qA loader, 2: W prefetch
-        if (lw < 2) {
-            const int rows_total = lw == 0 ? p.N : p.M, r0 = lw == 0 ? n0 : m0;
-            unsigned voff[PER];
-#pragma unroll
-            for (int i = 0; i < PER; ++i) {
-                const int row = i * 8 + (lane >> 3);
-                const int rr = min(r0 + row, rows_total - 1) - r0;
-                voff[i] = (unsigned)rr * (unsigned)p.K + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
-            }
-            const char* const base = (lw == 0 ? reinterpret_cast<const char*>(p.B) : reinterpret_cast<const char*>(p.A)) +
-                                     (int64_t)r0 * K + (int64_t)kbeg * KS;
-            const bool nt = lw == 0 && (p.flags & 2) != 0;
-            auto run = [&](auto nr_tag, unsigned ring0, lds_vu32* landed, lds_vu32* done) __attribute__((always_inline)) {
-                constexpr int NR = decltype(nr_tag)::value;
-                constexpr int LAG = NR - 2 > 3 ? 3 : NR - 2; // slices still in flight when one is published (vmcnt counts <= 63 operations)
-                int st = 0;
-                unsigned use = 0;
-                for (int s = 0; s < nk; ++s) {
-                    if (use > 0) { // the stage holds slice s - NR: every wave of its group must have taken its last fragment
-                        const unsigned need = 4u * use;
-                        if (__builtin_amdgcn_readfirstlane(done[st]) < need) {
-                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (ahead of the consumers: publish everything issued so far)
-                            *landed = (unsigned)s;
-                            while (__builtin_amdgcn_readfirstlane(done[st]) < need) __builtin_amdgcn_s_sleep(1);
-                        }
-                    }
-                    const unsigned dst = ring0 + (unsigned)st * REG;
-                    const char* b = base + (int64_t)s * KS;
-                    if (nt) {
-#pragma unroll
-                        for (int i = 0; i < PER; ++i) glds16_sbase_nt(b, voff[i], dst + i * 1024);
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < PER; ++i) glds16_sbase(b, voff[i], dst + i * 1024);
-                    }
-                    if (s >= LAG) {
-                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(16 * LAG) : "memory");
-                        *landed = (unsigned)(s - LAG + 1);
-                    }
-                    if (++st == NR) st = 0, ++use;
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                *landed = (unsigned)nk;
-            };
-            if (lw == 0) run(std::integral_constant<int, NW>{}, lds0, flags + 0, flags + 4);
-            else run(std::integral_constant<int, NQ>{}, lds0 + NW * REG, flags + 1, flags + 12);
-        } else if (PF) {
-            // one dword of every 128-byte line of W slice s: 128 rows = two instructions; the data is thrown away
-            unsigned voff2[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) voff2[i] = (unsigned)(min(n0 + i * 64 + lane, p.N - 1) - n0) * (unsigned)p.K;
-            const char* const base = reinterpret_cast<const char*>(p.B) + (int64_t)n0 * K + (int64_t)kbeg * KS;
-            for (int s = NW; s < nk; ++s) { // (the first NW slices are requested by the loader itself at once)
-                while ((int)__builtin_amdgcn_readfirstlane(flags[0]) + midf::PFD < s) __builtin_amdgcn_s_sleep(2);
-                const char* b = base + (int64_t)s * KS;
-                unsigned d0, d1;
-                asm volatile("global_load_dword %0, %2, %4\n\tglobal_load_dword %1, %3, %4"
-                             : "=&v"(d0), "=&v"(d1)
-                             : "v"(voff2[0]), "v"(voff2[1]), "s"(b)
-                             : "memory");
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        mid_loader_tail<EPI, XSP>(p, lds0, lw, lane, m0, n0);
-        return;
-    }
-
-    // ======================================== compute wave ========================================
-    const int group = wave >> 2;
-    const int w4 = wave & 3;
-    const int wm = w4 >> 1, wn = w4 & 1;
-    const int lr = lane & 31, lh = lane >> 5;
-    const int sw = (lr >> 1) & 7;
-    int koff[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) koff[ks] = ((ks * 2 + lh) ^ sw) << 4;
-    const int xrow = (wn * 64 + lr) * KS;
-    const int yrow = NW * REG + (wm * 64 + lr) * KS;
-
-    v16i acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
-
-    int stw = group, stq = group; // ring stages of slice s (NW, NQ >= 3 > group)
-    dbg_stamp(p.dbg, 0);
-    for (int s = group; s < nk; s += 2) {
-        for (;;) { // both operands of slice s have landed?
-            const v2u v = *(lds_v2u*)flags;
-            if ((int)__builtin_amdgcn_readfirstlane(min(v[0], v[1])) > s) break;
-            __builtin_amdgcn_s_sleep(1);
-        }
-        asm volatile("" ::: "memory");
-        if (s == group) dbg_stamp(p.dbg, 1);
-        if (s == group + (nk / 2 & ~1)) dbg_stamp(p.dbg, 2);
-        const char* xb = smem + stw * REG + xrow;
-        const char* yb = smem + stq * REG + yrow;
-        v4i xf[2][2], yf[2][2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            xf[0][h] = *reinterpret_cast<const v4i*>(xb + h * 32 * KS + koff[0]);
-            yf[0][h] = *reinterpret_cast<const v4i*>(yb + h * 32 * KS + koff[0]);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int cur = ks & 1, nxt = cur ^ 1;
-            if (ks + 1 < 4) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    xf[nxt][h] = *reinterpret_cast<const v4i*>(xb + h * 32 * KS + koff[ks + 1]);
-                    yf[nxt][h] = *reinterpret_cast<const v4i*>(yb + h * 32 * KS + koff[ks + 1]);
-                }
-            }
-            if (ks == 3) { // the last fragments are in registers once the MFMAs below may issue: hand the two stages back first
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (lane < 2) {
-                    const unsigned a = flags_addr + 4u * (lane == 0 ? 4 + stw : 12 + stq), one = 1u;
-                    asm volatile("ds_add_u32 %0, %1" ::"v"(a), "v"(one) : "memory");
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj)
-                    acc[i][jj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xf[cur][i], yf[cur][jj], acc[i][jj], 0, 0, 0);
-        }
-        stw += 2;
-        if (stw >= NW) stw -= NW;
-        stq += 2;
-        if (stq >= NQ) stq -= NQ;
-    }
-    mid_finish<EPI, XSP, TC>(p, smem, acc, wave, lane, tid, m0, n0, t_lin, xrank, XS);
-}
-
-static std::atomic<int> g_mid_build{0}; // measurement knob 1400 + b: 0 barrier pairs | 1 flags 5 + 4 | 2 flags 6 + 3 | 3 / 4 the same with the prefetch wave
-void set_mid_build(int b) { g_mid_build.store(b); }
-
-template <int EPI, int NW, int NQ, bool PF>
-static hipError_t launch_midf_cfg(const GemmParams& q, int tiles, hipStream_t st)
-{
-    constexpr size_t lds = (size_t)(NW + NQ) * midf::REG + 256;
-    constexpr int T = (10 + (PF ? 1 : 0)) * 64;
-    if (q.xsplit > 1) {
-        auto kern = gemm_w8a8o16_midf_kernel<EPI, true, NW, NQ, PF>;
-        static DeviceOnce once;
-        if (hipError_t e = ensure_dynamic_lds(kern, lds, once); e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * q.xsplit)), dim3(T), lds, st, q);
-    } else {
-        auto kern = gemm_w8a8o16_midf_kernel<EPI, false, NW, NQ, PF>;
-        static DeviceOnce once;
-        if (hipError_t e = ensure_dynamic_lds(kern, lds, once); e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(T), lds, st, q);
-    }
-    return hipGetLastError();
-}
+static std::atomic<int> g_mid_rot{1}; // measurement knob 1410 (default: where the tiles are not split along K) / 1411 (never) / 1412 (always): tile rows start at different K slices
+void set_mid_rot(int mode) { g_mid_rot.store(mode); }
 
 template <int EPI>
 static hipError_t launch_mid_epi(const GemmParams& p, hipStream_t st)
@@ -607,14 +443,13 @@ static hipError_t launch_mid_epi(const GemmParams& p, hipStream_t st)
     // one tile row: every weight line is read by exactly one workgroup -> non-temporal copies for weights of 32 MiB and more
     // (the rule of gemm_kernels.hip's launch_cfg)
     if (p.M <= mid::BM && (int64_t)p.N * p.K >= ((int64_t)32 << 20)) q.flags |= 2;
+    // (the walk is rotated where the tiles alone fill the chip: cold, h vs j in profiles/r06_mid_final_sweep_cold.txt, ahead in every such cell, by up
+    //  to 16 %.  With K split over workgroups the parts of a tile already start at different slices, and rotating them as well is BIMODAL --
+    //  4096 x 11008 at 256 rows with four parts ran 29.5 us in one process and 35 us in the next, at 512 rows with two parts 39.7 / 47.9 -- and
+    //  tripped the selection gate (+16.8 % behind the round-5 build): not rotated.  Knob 1412 rotates always, for measurements.)
+    const int rotm = g_mid_rot.load();
+    if (rotm == 2 || (rotm == 1 && p.xsplit <= 1)) q.flags |= 4;
     const int tiles = ((p.M + mid::BM - 1) / mid::BM) * ((p.N + mid::BN - 1) / mid::BN);
-    switch (g_mid_build.load()) {
-    case 1: return launch_midf_cfg<EPI, 5, 4, false>(q, tiles, st);
-    case 2: return launch_midf_cfg<EPI, 6, 3, false>(q, tiles, st);
-    case 3: return launch_midf_cfg<EPI, 5, 4, true>(q, tiles, st);
-    case 4: return launch_midf_cfg<EPI, 6, 3, true>(q, tiles, st);
-    default: break;
-    }
     if (p.xsplit > 1) {
         auto kern = gemm_w8a8o16_mid_kernel<EPI, true>;
         static DeviceOnce once;

@@ -247,7 +247,9 @@ static hipError_t launch_skinny_s4_cfg(const GemmParams& p, hipStream_t st)
     return hipGetLastError();
 }
 
-bool gemm_skinny_s4_supported(int M, int N, int k_packed) { return M >= 1 && M <= 64 && N % 16 == 0 && k_packed % 16 == 0 && k_packed <= 65536; }
+// (k_packed < 65536: the accumulators hold 256 x the true sums -- an all -8 row against an all -8 feature reaches exactly 2^31 at K = 131072
+//  elements and wraps; every shorter row is exact.  ADVICE r5.)
+bool gemm_skinny_s4_supported(int M, int N, int k_packed) { return M >= 1 && M <= 64 && N % 16 == 0 && k_packed % 16 == 0 && k_packed <= 65520; }
 
 // p.A / p.B = PACKED int4 [M, K] / [N, K] with p.K = packed bytes per row; p.Y = fp16 addend or null; p.O unused
 hipError_t launch_gemm_skinny_s4(const GemmParams& p, int epi, hipStream_t st)

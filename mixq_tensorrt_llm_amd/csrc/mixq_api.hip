@@ -153,7 +153,7 @@ void mixq_debug_reset(void)
     mixq::set_quant_stamp_buffer(nullptr);
     for (int v : {-1 /* schedule (back to the MIXQ_GEMM_VARIANT default), tile configuration, skinny K width */, 79 /* K splits over workgroups automatic */, 69, 65, 91,
                   80 /* fpA_intB forms automatic */, 85, 840, 843, 848 /* non-temporal loads of large weights on */, 850, 858, 891 /* fragment-major qA on */, 893 /* skinny range: the rule */,
-                  894 /* feature tiles automatic */, 880 /* skinny-GEMM weight image off */, 884 /* row-major weights in 256-byte runs */, 1240 /* mid-M deep form automatic */, 1238, 1400 /* round-6 mid kernel: default build */, 1290 /* non-temporal weight copies of single-row tile launches: by rule */, 1300 /* quantisers: block-per-row by the measured rules */})
+                  894 /* feature tiles automatic */, 880 /* skinny-GEMM weight image off */, 884 /* row-major weights in 256-byte runs */, 1240 /* mid-M deep form automatic */, 1238, 1410 /* its K walk rotated per tile row */, 1420 /* the deep plan takes it from 129 rows on */, 1290 /* non-temporal weight copies of single-row tile launches: by rule */, 1300 /* quantisers: block-per-row by the measured rules */})
         mixq::set_gemm_variant(v);
     set_int4_stream(1);
     mixq::set_s4_wrows(1);
@@ -531,6 +531,9 @@ static void set_int4_stream(int on) { g_int4_stream.store(on); }
 size_t mixq_int4_fused_workspace_size(int M, int N, int k_packed)
 {
     if (M < 0 || N < 0 || k_packed < 0) return 0;
+    // (round 6, ADVICE r5: the size the call REALLY needs -- 0 where mixq_int4_fused_dequantize[_silu] streams the packed weight (decode batches
+    //  that int4_gemm_kernels.hip serves, knob 870 on); N == 0 asks for the activation's part alone, the _w8 entry's need)
+    if (N > 0 && g_int4_stream.load(std::memory_order_relaxed) && mixq::gemm_skinny_s4_supported(M, N, k_packed)) return 0;
     return align16_up((size_t)M * 2 * k_packed) + align16_up((size_t)N * 2 * k_packed);
 }
 
@@ -1167,7 +1170,7 @@ int mixq_tp_arrive(void* const* peer_ack_words, const void* own_ack_words, int n
 }
 
 int mixq_tp_push_columns_seq(const void* src, void* const* dst_bases, void* const* dst_flags, int ndst, int M, int n_local,
-                             int N, int col0, const void* seq_word, void* done_counter, void* stream)
+                             int N, int col0, const void* seq_word, void* done_counter, const void* status_dev, void* stream)
 {
     if (!dst_bases || !dst_flags || !done_counter || !seq_word || ndst < 1 || ndst > 8 || M < 0 || n_local <= 0 || N <= 0 ||
         col0 < 0 || col0 + n_local > N || (M > 0 && !src))
@@ -1181,7 +1184,7 @@ int mixq_tp_push_columns_seq(const void* src, void* const* dst_bases, void* cons
     }
     return hip_rc(mixq::launch_tp_push(src, dst_bases, flags, ndst, M, n_local, N, col0, 0u, 1,
                                        static_cast<unsigned*>(done_counter), static_cast<hipStream_t>(stream),
-                                       static_cast<const unsigned*>(seq_word)));
+                                       static_cast<const unsigned*>(seq_word), static_cast<const unsigned*>(status_dev)));
 }
 
 int mixq_tp_wait_seq(const void* flags, int nprod, void* seq_word, void* status_dev, int trap_on_timeout, uint32_t patience_ms,

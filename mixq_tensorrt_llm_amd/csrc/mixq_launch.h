@@ -125,7 +125,7 @@ void set_deep_force(int v);
 hipError_t launch_gemm_deep(const GemmParams& p, int epi, hipStream_t st);
 // round-6 schedule of the same tiles (gemm_mid_kernels.hip): 2 copy-only waves + 8 compute waves, one barrier per pair of slices; p.xsplit workgroups per tile
 hipError_t launch_gemm_mid(const GemmParams& p, int epi, hipStream_t st);
-void set_mid_build(int b); // measurement knob 1400 + b (gemm_mid_kernels.hip)
+void set_mid_rot(int mode);  // measurement knob 1410 (default: 1 = by rule) / 1411 (0 = never) / 1412 (2 = always)
 bool gemm_skinny_supported(const GemmParams& p);
 hipError_t launch_gemm_skinny(const GemmParams& p, int epi, hipStream_t st); // M <= 64: GEMV-like, HBM-bound on W
 hipError_t launch_gemm_pp_ablate(const GemmParams& p, int abl, hipStream_t st);  // timing experiments only
@@ -196,7 +196,8 @@ void note_gemm_kernel(const char* name);
 // seq_word != null (capturable form): the call number is *seq_word + 1, read on the device; launch_tp_wait stores it back
 hipError_t launch_tp_push(const void* src, void* const* dst_bases, unsigned* const* dst_flags, int ndst, int M, int n_loc,
                           int N, int col0, unsigned seq, int nflags, unsigned* done_counter, hipStream_t st,
-                          const unsigned* seq_word = nullptr);
+                          const unsigned* seq_word = nullptr,
+                          const unsigned* status = nullptr); // (capturable form) the sticky status word: raised -> nothing is stored or published
 hipError_t launch_tp_wait(const unsigned* flags, int nprod, int word0, int nwords, unsigned seq, unsigned* status, int trap,
                           unsigned patience_ms, hipStream_t st, unsigned* seq_word = nullptr);
 hipError_t launch_tp_arrive(unsigned* const* peer_acks, const unsigned* own_acks, int npeer, const unsigned* seq_word,

@@ -42,9 +42,14 @@ __global__ __launch_bounds__(256) void tp_push_columns_kernel(const uint4* __res
                                                                int vec_per_row /* n_loc / 8 */, int64_t dst_row_vecs
                                                                /* N / 8 */, int col0_vec, unsigned seq, int nflags,
                                                                unsigned* __restrict__ done_counter,
-                                                               const unsigned* __restrict__ seq_word)
+                                                               const unsigned* __restrict__ seq_word,
+                                                               const unsigned* __restrict__ status)
 {
     if (seq_word != nullptr) seq = *seq_word + 1u; // capturable form: the call's number lives on the device (tp_wait bumps it)
+    // (capturable form, ADVICE r5: this rank's tp_arrive may have given up -- a peer has NOT acknowledged that its single destination
+    //  buffer may be overwritten and can still be reading the previous call's tensor.  With the sticky status raised nothing is stored and
+    //  no flag is published: the peers' waits of this call time out in turn instead of consuming a torn tensor.)
+    if (status != nullptr && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return;
     const int64_t total = (int64_t)M * vec_per_row;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t m = i / vec_per_row;
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(64) void tp_arrive_kernel(TpAck a, const unsigned* 
 
 hipError_t launch_tp_push(const void* src, void* const* dst_bases, unsigned* const* dst_flags, int ndst, int M, int n_loc,
                           int N, int col0, unsigned seq, int nflags, unsigned* done_counter, hipStream_t st,
-                          const unsigned* seq_word)
+                          const unsigned* seq_word, const unsigned* status)
 {
     if (ndst < 1 || ndst > kTpMaxPeers || n_loc % 8 || N % 8 || col0 % 8 || nflags < 1 || nflags > kTpFlagWords || M < 0 ||
         n_loc <= 0)
@@ -153,7 +158,7 @@ hipError_t launch_tp_push(const void* src, void* const* dst_bases, unsigned* con
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1; // M == 0: one workgroup that only publishes the flags
     hipLaunchKernelGGL(tp_push_columns_kernel, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const uint4*>(src), d,
-                       ndst, M, n_loc / 8, (int64_t)(N / 8), col0 / 8, seq, nflags, done_counter, seq_word);
+                       ndst, M, n_loc / 8, (int64_t)(N / 8), col0 / 8, seq, nflags, done_counter, seq_word, status);
     return hipGetLastError();
 }
 

@@ -44,8 +44,8 @@ class WeightImage:
     is alive, every decode-batch call (5 .. 64 rows) of the library on that weight POINTER streams the copy -- one contiguous 1-KiB
     read per load instead of 64 bytes of 16 rows -- with bit-identical results (-10..-15 % operator time at 32 rows).  Costs N * K
     bytes.  ``close()`` (or garbage collection) unregisters it; the weight tensor must not be freed or rewritten before that.  The
-    library records a content tag of the weight at registration and compares the bytes behind the pointer with it on the image's first
-    use (``verify()`` re-checks on demand): a tensor that was replaced behind the same address is served from its own bytes, not from
+    library records a content tag of the weight at registration and compares the bytes behind the pointer with it around the image's first
+    use (asynchronously: until that check has completed, calls read the weight itself; ``verify()`` checks on demand and synchronises): a tensor that was replaced behind the same address is served from its own bytes, not from
     the stale image.  A captured HIP graph holds the image pointer: keep this object alive as long as the graph."""
 
     def __init__(self, weight_int8):
@@ -222,7 +222,8 @@ def _fused4(name, A, B, scale_row, scale_col, y, M, N, K, B_int8=None):
     _dev(*(t for t in (A, B, scale_row, scale_col, y) if t is not None))
     lib = _lib.load()
     D = torch.empty((M, N), dtype=torch.float16, device=A.device)
-    if M <= 64:      # decode batches: ONE launch streams the packed weight (csrc/int4_gemm_kernels.hip); no workspace
+    need = int(lib.mixq_int4_fused_workspace_size(M, N, K))   # 0: the call streams the packed weight in ONE launch (decode batches the
+    if need == 0:                                             # stream kernel serves, csrc/int4_gemm_kernels.hip); asked, not assumed
         ws = None
     elif B_int8 is not None:   # prefill size with the weight widened once at load: only A is widened per call
         ws = torch.empty(max(16, lib.mixq_int4_fused_workspace_size(M, 0, K)), dtype=torch.uint8, device=A.device)
@@ -230,7 +231,7 @@ def _fused4(name, A, B, scale_row, scale_col, y, M, N, K, B_int8=None):
                                                      1 if name.endswith("_silu") else 0, _p(ws), _st(A)), name + "_w8")
         return D
     else:
-        ws = torch.empty(max(16, lib.mixq_int4_fused_workspace_size(M, N, K)), dtype=torch.uint8, device=A.device)
+        ws = torch.empty(max(16, need), dtype=torch.uint8, device=A.device)
     _lib.check(getattr(lib, name)(_p(A), _p(B), _p(scale_row), _p(scale_col), _p(y), _p(D), M, N, K, _p(ws), _st(A)),
                name)
     return D

@@ -117,6 +117,10 @@ class MixLinear_GEMM:
                 self.ind = torch.empty((fp_features_num,), dtype=torch.int32, device=dev)
         self.bias = torch.empty((out_features,), dtype=torch.float16, device=dev) if bias else None
         self.cnt = 0
+        # linear.py:86 `self.arch = torch.cuda.get_device_capability()[0]`, read at :231 / :317: 9 (sm90) takes the UNFUSED route
+        # mixlib.gemm -> outlier product -> mixlib.dequantizeInt8[Silu]; everything else the fused GEMM.  An MI355X reports no CUDA
+        # capability of 9, so the default is the fused route; set `arch = 9` to run the reference's sm90 sequence op for op (bit = 8).
+        self.arch = 0
         self.forward_without_precondition_len = fp_features_num if (bit == 4 and not weight_only) else -1  # :68-71
         self.add_outliers = True
         self.sigma = None
@@ -246,7 +250,10 @@ class MixLinear_GEMM:
                 self.add_outliers = False
 
         y = outlier_product(cache.activation_outliers, self.weight_cache) if self.ind.shape[0] else None
-        if self.bit == 8:
+        if self.arch == 9 and self.bit == 8:   # :231-238
+            y1 = mixlib.dequantizeInt8(mixlib.gemm(self._row_major_q(cache, M), self.q_weight, M, self.out_features, self.in_features),
+                                       cache.x_scale, self.scale_col, y if y is not None else self._zeros(M, inputs.device), 8, M, self.out_features)
+        elif self.bit == 8:
             q, lay = self._cached_q(cache, M)
             y1 = mixlib.int8FusedDequantize(q, self.q_weight, cache.x_scale, self.scale_col, y, M,
                                             self.out_features, self.in_features, lay)
@@ -258,6 +265,21 @@ class MixLinear_GEMM:
         return y1.reshape(cache.shape)
 
     __call__ = forward
+
+    def _row_major_q(self, cache, M):
+        """q_xcache as the reference's unfused route reads it (row-major int8 [M, K])."""
+        if getattr(cache, "q_layout", 0):
+            cache.q_xcache = mixlib.qa_to_row_major(cache.q_xcache, M, self.in_features)
+            cache.q_layout = 0
+        return cache.q_xcache
+
+    def _zeros(self, M, device):
+        """`self.cache.zeros` of the reference (Cache.py: an [inputdim, 36864] zero matrix handed to dequantizeInt8 as the addend when
+        there are no outliers): here an [M, N] block, allocated on first use and kept."""
+        z = getattr(self, "_zero_addend", None)
+        if z is None or z.shape[0] < M or z.device != device:
+            z = self._zero_addend = torch.zeros((M, self.out_features), dtype=torch.float16, device=device)
+        return z[:M]
 
     def _cached_q(self, cache, M):
         """(q_xcache, layout) as THIS consumer's GEMM can read it.  The producer chose the image for one consumer's N (the
@@ -293,8 +315,12 @@ class MixLinear_GEMM:
             self.ind = cache.ind
             self.forward_without_precondition_len = self.ind.shape[0]
         y = outlier_product(cache.activation_outliers, self.weight_cache) if self.ind.shape[0] else None
-        fused_mul = mul is not None and self.bit == 8 and self.bias is None
-        if fused_mul:
+        fused_mul = mul is not None and self.bit == 8 and self.bias is None and self.arch != 9
+        if self.arch == 9 and self.bit == 8:   # :317-324
+            y1 = mixlib.dequantizeInt8Silu(mixlib.gemm(self._row_major_q(cache, M), self.q_weight, M, self.out_features, self.in_features),
+                                           cache.x_scale, self.scale_col, y if y is not None else self._zeros(M, inputs.device), 8, M,
+                                           self.out_features)
+        elif fused_mul:
             q, lay = self._cached_q(cache, M)
             y1 = mixlib.int8FusedDequantizeSiluMul(q, self.q_weight, cache.x_scale, self.scale_col, y,
                                                    mul.reshape(M, self.out_features), M, self.out_features,

@@ -234,7 +234,7 @@ class PeerGather:
             _lib.check(self.lib.mixq_tp_arrive(acks, self._flag_ptr(self.rank, 1, 0), self.tp, seq_word, self._status_dev,
                                                self.trap, self.patience_ms, st), "mixq_tp_arrive")
             _lib.check(self.lib.mixq_tp_push_columns_seq(x_local.data_ptr() if m else None, bases, flags, self.tp, m, self.n_loc,
-                                                         self.N, self.rank * self.n_loc, seq_word, self.small.data_ptr(), st),
+                                                         self.N, self.rank * self.n_loc, seq_word, self.small.data_ptr(), self._status_dev, st),
                        "mixq_tp_push_columns_seq")
             _lib.check(self.lib.mixq_tp_wait_seq(self._flag_ptr(self.rank, 0, 0), self.tp, seq_word, self._status_dev,
                                                  self.trap, self.patience_ms, st), "mixq_tp_wait_seq")

@@ -275,7 +275,7 @@ def test_argument_validation_returns_codes_and_never_touches_the_device():
     assert lib.mixq_int4_fused_dequantize_w8(p16, p16, p16, p16, None, p16, 80, 64, 32, 2, p16, None) == BADARG  # epilogue 0 | 1
     assert lib.mixq_find_outliers(p16, 4, 60, ctypes.c_float(6.0), p16, p16, p16, 8, None) == SHAPE
     assert lib.mixq_find_outliers(p16, 4, 64, ctypes.c_float(6.0), None, p16, p16, 8, None) == BADARG
-    assert lib.mixq_find_outliers_workspace_size(4096) == 512 and lib.mixq_int4_fused_workspace_size(32, 64, 16) == 32 * 32 + 64 * 32
+    assert lib.mixq_find_outliers_workspace_size(4096) == 512 and lib.mixq_int4_fused_workspace_size(65, 64, 16) == 65 * 32 + 64 * 32 and lib.mixq_int4_fused_workspace_size(32, 64, 16) == 0 and lib.mixq_int4_fused_workspace_size(32, 0, 16) == 32 * 32
     for code in (1, 2, 3, 4, 5):
         assert lib.mixq_error_string(code)
 

@@ -170,10 +170,12 @@ def test_int4_weight_stream_bit_exact(oracle, M, N, K, silu):
         assert np.array_equal(bits(got), bits(want))
     # the route this replaces (both operands unpacked to int8 in a workspace, then the int8 kernels): same bits, SiLU included
     D = torch.empty((M, N), dtype=torch.float16, device="cuda:0")
-    ws = torch.empty(max(16, lib.mixq_int4_fused_workspace_size(M, N, K // 2)), dtype=torch.uint8, device="cuda:0")
+    assert lib.mixq_int4_fused_workspace_size(M, N, K // 2) == 0          # the stream route needs none ...
     p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     lib.mixq_debug_set_gemm_variant(871)
+    ws = torch.empty(lib.mixq_int4_fused_workspace_size(M, N, K // 2), dtype=torch.uint8, device="cuda:0")   # ... the unpack route both operands widened
+    assert ws.numel() >= (M + N) * K
     try:
         f = lib.mixq_int4_fused_dequantize_silu if silu else lib.mixq_int4_fused_dequantize
         assert f(p(ap), p(bp), p(dev(sa)), p(dev(sb)), p(dev(y)), p(D), M, N, K // 2, p(ws), st) == 0

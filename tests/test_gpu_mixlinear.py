@@ -121,6 +121,50 @@ def test_mixlinear_no_outliers_and_3d_input(oracle):
     assert layer.ind.numel() == 0 and rel_err(got.reshape(-1, N), want) < REL_TOL
 
 
+@pytest.mark.parametrize("with_outliers", [False, True])
+def test_mixlinear_arch9_takes_the_reference_sm90_route(oracle, with_outliers):
+    """linear.py:231-238 / :317-324: with `arch == 9` the module runs mixlib.gemm -> (outlier product) -> mixlib.dequantizeInt8[Silu]
+    instead of the fused GEMM.  Op for op against the oracle's restatement of those two kernels (bit-exact given the side product: the
+    unfused epilogue rounds the scaled sum to fp16 BEFORE adding y, unlike the fused one), and close to the fused route's answer."""
+    from mixq_tensorrt_llm_amd import mixlib, mixlinear
+    rng = np.random.default_rng(41)
+    N, K, M = 384, 1024, 24
+    W, _ = make_layer(rng, N, K, False)
+    outs = {}
+    for arch in (0, 9):
+        cache = mixlinear.MixLibCache(inputdim=64, sigma=6, device="cuda:0")
+        layer = mixlinear.MixLinear_GEMM.from_linear(torch.from_numpy(W), cache=cache, dev="cuda:0")
+        layer.arch = arch
+        x = (rng.standard_normal((M, K)) * 0.5).astype(np.float16) if arch == 0 else x0.copy()
+        if arch == 0:
+            if with_outliers:
+                x[3, 70] = np.float16(25.0)
+                x[11, 901] = np.float16(-31.0)
+            x0 = x.copy()
+        xt = dev(x)
+        got = layer.forward(xt, cache, True)
+        torch.cuda.synchronize()
+        assert layer.ind.numel() == (2 if with_outliers else 0)
+        outs[arch] = got.cpu().numpy()
+        if arch == 9:   # the same ops on the same cache contents, restated
+            acc = oracle.gemm_s8s8s32(cache.q_xcache.cpu().numpy(), layer.q_weight.cpu().numpy())
+            assert np.array_equal(mixlib.gemm(cache.q_xcache, layer.q_weight, M, N, K).cpu().numpy(), acc)
+            y = (mixlinear.outlier_product(cache.activation_outliers, layer.weight_cache).cpu().numpy() if with_outliers
+                 else np.zeros((M, N), np.float16))
+            want = oracle.dequantization(acc, cache.x_scale[:M].cpu().numpy(), layer.scale_col.cpu().numpy(), y)
+            assert np.array_equal(outs[9].view(np.uint16), want.view(np.uint16))
+            # the gate projection's twin (:317-324) on the same cache
+            gate = mixlinear.MixLinear_GEMM.from_linear(torch.from_numpy(W), cache=cache, dev="cuda:0")
+            gate.arch = 9
+            g = gate.forward_without_preconditionFusedSilu(xt, cache).cpu().numpy()
+            yg = (mixlinear.outlier_product(cache.activation_outliers, gate.weight_cache).cpu().numpy() if with_outliers
+                  else np.zeros((M, N), np.float16))
+            want_g = oracle.dequantization_silu(acc, cache.x_scale[:M].cpu().numpy(), gate.scale_col.cpu().numpy(), yg)
+            d = np.abs(g.astype(np.float64) - want_g.astype(np.float64))
+            assert (d <= 2.0 ** -10 * np.maximum(np.abs(want_g.astype(np.float64)), 2.0 ** -14) + 1e-7).all()   # SiLU: <= 1 ulp (conftest bounds)
+    assert rel_err(outs[9], outs[0]) < REL_TOL
+
+
 def test_mixlinear_weight_only_mode(oracle):
     from mixq_tensorrt_llm_amd import mixlinear
     rng = np.random.default_rng(4)

@@ -77,3 +77,56 @@ def test_described_plan_is_what_enqueue_launches():
             assert want in launched, (M, N, K, said, launched)
             n += 1
     assert n == 104
+
+
+@pytest.mark.parametrize("M", [32, 64])
+def test_a_registered_weight_image_is_never_slower(M):
+    """`mixq_weight_image_register` costs + N K bytes per layer; a call on a registered weight must not be slower than
+    the same call without the image.  The three Llama-2-7B linears, cold weights (a rotation over > 320 MiB of copies, each with its own
+    image), device-paced graphs: sum over the three shapes, image <= 1.03 x no image (the box-to-box spread of a launch is +-4 %; at
+    64 rows both now take the same kernels -- csrc/gemm_skinny_kernels.hip skinny_weight_route)."""
+    import ctypes
+    sys.path.insert(0, ROOT)
+    import bench
+    from mixq_tensorrt_llm_amd import _lib
+    from mixq_tensorrt_llm_amd._lib import TensorDesc
+    lib = _lib.load()
+    lib.mixq_debug_reset()
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev).manual_seed(1)
+    st0 = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    total = {False: 0.0, True: 0.0}
+    for (N, K) in [(12288, 4096), (11008, 4096), (4096, 11008)]:
+        t = bench.synth_layer(N, K, dev, gen)
+        copies = [t["weight"]] + [t["weight"].clone() for _ in range((320 << 20) // (N * K) + 1)]
+        A = bench.synth_activation(M, K, t["ind_i32"], dev, gen)
+        o = torch.empty((M, N), dtype=torch.float16, device=dev)
+        h = ctypes.c_void_p(lib.mixq_create(M, N, K))
+        ws = torch.empty(max(lib.mixq_workspace_size(h, M, N, K), 16), dtype=torch.uint8, device=dev)
+        sets = []
+        for w in copies:
+            ins = [A, w, t["weights_scaling_factor"], t["fp_weight"], t["fp_ind"], t["qweight"], t["weights_scaling_factor"]]
+            sets.append(((TensorDesc * 7)(*[TensorDesc.make(x.shape) for x in ins]), (ctypes.c_void_p * 7)(*[x.data_ptr() for x in ins])))
+        out_desc, out_ptrs = TensorDesc.make(o.shape), (ctypes.c_void_p * 1)(o.data_ptr())
+        turn = [0]
+
+        def run(st):
+            d, ptrs = sets[turn[0] % len(sets)]
+            turn[0] += 1
+            assert lib.mixq_enqueue(h, d, ctypes.byref(out_desc), ptrs, out_ptrs, ctypes.c_void_p(ws.data_ptr()), st) == 0
+
+        for with_image in (False, True):
+            imgs = []
+            if with_image:
+                for w in copies:
+                    im = torch.empty(N * K, dtype=torch.int8, device=dev)
+                    assert lib.mixq_weight_image_register(ctypes.c_void_p(w.data_ptr()), N, K, ctypes.c_void_p(im.data_ptr()), st0) == 0
+                    assert lib.mixq_weight_image_verify(ctypes.c_void_p(w.data_ptr()), st0) == 0
+                    imgs.append(im)
+            torch.cuda.synchronize()
+            turn[0] = -1
+            total[with_image] += min(bench.graph_time_us(run, dev, calls=len(sets) * 4, reps=10) for _ in range(2))
+            for w in copies:
+                lib.mixq_weight_image_unregister(ctypes.c_void_p(w.data_ptr()))
+        lib.mixq_destroy(h)
+    assert total[True] <= 1.03 * total[False], total

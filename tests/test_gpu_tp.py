@@ -329,6 +329,72 @@ def test_lost_peer_surfaces_as_an_error_not_a_stale_tensor(tmp_path):
         assert res == "1", f"rank {r}: {res}"
 
 
+def _slow_peer_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import time
+
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mixq_tensorrt_llm_amd import parallel
+    ok, notes = True, []
+    try:
+        pg = parallel.PeerGather(64, 256, world, rank, "cuda:0", capturable=True, patience_ms=300)
+        x1 = torch.full((64, 128), float(rank + 1), dtype=torch.float16, device="cuda:0")
+        got = pg.gather(x1)                      # call 1: both ranks arrive -> fine; `got` is this rank's ONE destination buffer
+        torch.cuda.synchronize()
+        pg.check()
+        ok &= bool((got[:, :128] == 1).all() and (got[:, 128:] == 2).all())
+        snapshot = got.clone()
+        dist.barrier()
+        x2 = torch.full((64, 128), float(10 * (rank + 1)), dtype=torch.float16, device="cuda:0")
+        if rank == 0:
+            # call 2: rank 1 is SLOW (it has not reached the call: it may still be reading call 1's tensor).  Rank 0's arrive gives up
+            # after 300 ms; its push must then leave rank 1's buffer alone and publish nothing.
+            pg.gather(x2)
+            torch.cuda.synchronize()
+            ok &= pg.timed_out()
+            if not pg.timed_out():
+                notes.append("rank 0: the arrive of call 2 did not time out")
+            open(os.path.join(tmp, "slow_rank0_done"), "w").write("1")
+        else:
+            t0 = time.perf_counter()
+            while not os.path.exists(os.path.join(tmp, "slow_rank0_done")) and time.perf_counter() - t0 < 30:
+                time.sleep(0.05)                 # "reading" call 1's tensor for longer than the producer's patience
+            torch.cuda.synchronize()
+            same = bool((got == snapshot).all())  # the single destination buffer was NOT overwritten behind the slow reader's back
+            ok &= same
+            if not same:
+                notes.append("rank 1: its destination buffer was overwritten although it never acknowledged call 2")
+            pg.gather(x2)                        # the late call: rank 0 published nothing, so this wait times out -- an error, not a torn tensor
+            torch.cuda.synchronize()
+            ok &= pg.timed_out()
+            if not pg.timed_out():
+                notes.append("rank 1: its late call 2 did not surface the failure")
+        dist.barrier()
+        pg.close()
+    except Exception:  # noqa: BLE001
+        import traceback
+        ok = False
+        notes.append(traceback.format_exc())
+    open(os.path.join(tmp, f"slow{rank}"), "w").write("1" if ok else "0\n" + "\n".join(notes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_capturable_gather_does_not_overwrite_a_slow_peers_buffer(tmp_path):
+    """in the capturable form every rank has ONE destination buffer whose reuse is acknowledged by `mixq_tp_arrive`.  When that
+    arrive times out (a peer that is merely slow), the push that follows on the stream must not store into the peer's buffer nor publish
+    its flag: the slow peer keeps a consistent tensor and gets a time-out on its own late call instead of a torn one."""
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_slow_peer_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        res = open(tmp_path / f"slow{r}").read()
+        assert res == "1", f"rank {r}: {res}"
+
+
 @pytest.mark.parametrize("gpus", [2, 8])
 def test_bench_self_launches(tmp_path, gpus):
     """`python bench.py --gpus N ...` exactly as the driver types it (no torch.distributed.run in front, no WORLD_SIZE):
@@ -343,7 +409,7 @@ def test_bench_self_launches(tmp_path, gpus):
         env.pop(k, None)
     tokens = "16384" if gpus == 2 else "8192"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--tokens", tokens, "--steps", "1",
-                        "--warmup", "1"], capture_output=True, text=True, env=env, timeout=1500)
+                        "--warmup", "1", "--config5-layers", "1"], capture_output=True, text=True, env=env, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -357,6 +423,12 @@ def test_bench_self_launches(tmp_path, gpus):
     alts = tp.get("alternatives_one_step_each")   # the other transports of the same layout, one timed step each
     assert isinstance(alts, dict) and "error" not in alts, alts
     assert any("rccl" in k for k in alts) and all(v["ms_per_step"] > 0 for v in alts.values()), alts
+    # BASELINE configs[4] (Llama-2-70B, rows of W sharded N ways WITH the all-gather; one decoder layer here): its own leg, its own
+    # transport self-test on the 10240 / 28672 / 8192-wide outputs
+    c5 = rec["configs"][f"llama2_70b_tp{gpus}"]
+    assert "error" not in c5, c5
+    assert c5["tp"] == gpus and c5["layers"] == 1 and c5["value"] > 0 and c5["transport"] and c5["peer_wait_timed_out"] is False
+    assert "10240x8192" in c5["workload"] and "28672x8192" in c5["workload"] and "8192x28672" in c5["workload"]
 
 
 def _fused_worker(rank, world, port, tmp):

@@ -115,7 +115,7 @@ def test_graph_replay_and_the_mixlib_flavour(oracle):
 
 def test_a_weight_replaced_behind_the_same_address_is_not_served_the_old_image(oracle):
     """the registry is keyed by address.  The library records a content tag at registration and compares the bytes
-    behind the pointer with it on the image's FIRST USE: a tensor whose content was replaced in place (= freed and re-allocated at the
+    behind the pointer with it around the image's FIRST USE (asynchronously: round 6): a tensor whose content was replaced in place (= freed and re-allocated at the
     same address) without unregistering gets results from its OWN bytes, the entry is dropped, the stale counter moves; the same after
     a first use is what `verify` is for."""
     from mixq_tensorrt_llm_amd import _lib, mixlib, plugin
@@ -131,7 +131,9 @@ def test_a_weight_replaced_behind_the_same_address_is_not_served_the_old_image(o
     layer.weight.view(torch.int8).copy_(torch.from_numpy(p2["weight"]))     # ... the memory changes hands behind the library's back
     layer.fp_weight.copy_(torch.from_numpy(p2["fp_weight"]).view(torch.float16).reshape(layer.fp_weight.shape))
     layer.weights_scaling_factor.copy_(torch.from_numpy(p2["weights_scaling_factor"]))
-    got = layer(x).cpu().numpy()                                            # first use: tag mismatch -> reads `weight` itself
+    got = layer(x).cpu().numpy()                                            # first use: the check is enqueued, the call reads `weight` itself
+    torch.cuda.synchronize()
+    assert np.array_equal(layer(x).cpu().numpy(), got)                      # the check has completed: tag mismatch -> the entry is dropped
     assert lib.mixq_weight_image_stale_count() == stale0 + 1
     assert_prefill_parity(oracle, got, A, dict(p2, fp_ind=p1["fp_ind"]), "replaced weight, stale image dropped")
     assert not img.verify()                                                 # nothing registered any more

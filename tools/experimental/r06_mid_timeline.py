@@ -15,7 +15,7 @@ import torch  # noqa: E402
 
 from mixq_tensorrt_llm_amd import _lib  # noqa: E402
 
-NAMES = ["entry", "first slices handed over", "half of K multiplied", "last MFMA issued", "halves swapped / outliers staged", "stores issued",
+NAMES = ["entry", "first slices handed over", "(qA loader's wait words)", "last MFMA issued", "halves swapped / outliers staged", "stores issued",
          "stores acknowledged"]
 
 
@@ -69,6 +69,13 @@ def main():
             fn(i & 1)
         lib.mixq_debug_set_stamp_buffer(None)
         torch.cuda.synchronize()
+        raw = stamps[1].cpu().numpy().reshape(-1, 8)
+        raw = raw[raw[:, 0] > 0]
+        for slot, who in ((7, "W loader"), (2, "qA loader")):
+            v = raw[:, slot].astype(np.uint64)
+            w, b = (v >> np.uint64(32)).astype(np.float64) * 0.01, (v & np.uint64(0xffffffff)).astype(np.float64) * 0.01
+            if w.max() < 1e4:
+                print(f"   {who:10s}: us in `s_waitcnt vmcnt` (its copies landing) {w.min():6.2f} {w.mean():6.2f} {w.max():6.2f} | us at the barriers {b.min():6.2f} {b.mean():6.2f} {b.max():6.2f}")
         rec = lambda b: (lambda t: t[t[:, 0] > 0][:, :7] * 0.01)(b.cpu().numpy().reshape(-1, 8).astype(np.float64))
         last, prev = rec(stamps[1]), rec(stamps[0])
         t0 = last[:, 0].min()
