@@ -358,7 +358,8 @@ def int4_points(lib, model, dev, gen, decode_step, batches=(1, 32)):
     per step.  `gemm_only`: mixq_int4_fused_dequantize alone -- ONE launch per linear that streams the packed weight and widens
     it in registers (csrc/int4_gemm_kernels.hip); what a linear costs when the fused RMSNorm in front has already quantised the row
     (mixq_rmsnorm_extract_quant4, the P-flavour's decode route).  `two_launches`: mixq_int4quant + the GEMM.  Against the int8
-    flavour's decode_step at the same batch (bs 1: the W8A16 GEMV on qweight; bs 32: quantise + int8 skinny GEMM)."""
+    flavour's decode_step at the same batch (bs 1: the W8A16 GEMV on qweight; bs 32: quantise + int8 skinny GEMM).  `one_call` (one row):
+    mixq_int4_linear_forward on the fp16 row -- ONE launch per linear, the row quantised inside the weight-streaming kernel."""
     out = {}
     p = lambda x: ctypes.c_void_p(x.data_ptr())  # noqa: E731
     shapes = [(t["weight"].shape[0], ins[0].shape[1]) for (t, ins) in model.keep]
@@ -386,15 +387,21 @@ def int4_points(lib, model, dev, gen, decode_step, batches=(1, 32)):
             assert lib.mixq_int4quant(bs, K, p(acts[K]), p(q4[K]), p(sa[K]), st) == 0
             gemm_only(st)
 
+        def one_call(st):   # mixq_int4_linear_forward: ONE row is quantised INSIDE the weight-streaming launch (round 6; more rows = the two launches)
+            i = turn[0] % len(shapes)
+            turn[0] += 1
+            N, K = shapes[i]
+            assert lib.mixq_int4_linear_forward(p(acts[K]), p(ws4[i]), p(sa[K]), p(q4[K]), p(sws[i]), None, p(outs[N]), bs, N, K // 2, 0, None, st) == 0
+
         pt = {}
-        for name, fn in (("gemm_only", gemm_only), ("two_launches", two_launches)):
+        for name, fn in (("gemm_only", gemm_only), ("two_launches", two_launches)) + ((("one_call", one_call),) if bs == 1 else ()):
             turn[0] = -1
             us = graph_time_us(fn, dev, calls=len(shapes), reps=10) * len(shapes)
             pt[name] = {"us_per_step": us, "weight_GBps": wbytes / us / 1e3, "hbm_frac": wbytes / (us * 1e-6) / 8e12}
         ref = (decode_step or {}).get(f"bs{bs}", {}).get("us_per_step")
         pt["int8_step_us"] = ref
         if ref:
-            pt["speedup_vs_int8_step"] = {k: ref / pt[k]["us_per_step"] for k in ("gemm_only", "two_launches")}
+            pt["speedup_vs_int8_step"] = {k: ref / pt[k]["us_per_step"] for k in ("gemm_only", "two_launches", "one_call") if k in pt}
         pt["kernel"] = lib.mixq_debug_last_gemm_kernel().decode()
         out[f"bs{bs}"] = pt
     out["weight_GB"] = wbytes / 1e9

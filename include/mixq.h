@@ -339,6 +339,17 @@ MIXQ_API int mixq_int4_fused_dequantize(const uint8_t* A, const uint8_t* B, cons
 MIXQ_API int mixq_int4_fused_dequantize_silu(const uint8_t* A, const uint8_t* B, const void* scale_row,
                                              const void* scale_col, const void* y, void* D, int M, int N, int k_packed,
                                              char* workspace, void* stream);
+/* MI355X extension (round 6): the 4-bit flavour's linear on an fp16 activation in ONE call -- FindRowScale(bit = 4) (cult.cu:2515-2567:
+ * x_scale[m] = fp16(amax / 7), q = int4(rn(x / x_scale))) followed by int4FusedDequantize[Silu] above.  x fp16 [M, 2 * k_packed]; x_scale
+ * fp16 [M] is WRITTEN (the P-flavour's cache.x_scale); epilogue 0 = dequant, 1 = dequant + SiLU.  ONE row runs as ONE launch: every
+ * workgroup of the weight-streaming kernel quantises the row for itself and keeps the packed row in LDS (no second launch, no round trip
+ * of the packed row: -5..-12 % against the two launches; q_packed and workspace are not touched and may be NULL).  From two rows on the
+ * in-kernel quantiser measured behind the quantiser launch it replaces (profiles/r06_int4_front_probe.txt) and the call IS the two launches:
+ * q_packed (uint8 [M, k_packed], caller-owned, else MIXQ_E_WORKSPACE) receives the packed rows, workspace as mixq_int4_fused_dequantize.
+ * Same bits either way.  (The decode route that makes the 4-bit step 1.6 x the int8 one quantises in the fused RMSNorm in front:
+ * mixq_rmsnorm_extract_quant4.) */
+MIXQ_API int mixq_int4_linear_forward(const void* x, const uint8_t* B, void* x_scale, uint8_t* q_packed, const void* scale_col,
+                                      const void* y, void* D, int M, int N, int k_packed, int epilogue, char* workspace, void* stream);
 /* MI355X extension: A packed int4 [M, k_packed], B_int8 = the weight widened to int8 [N, 2 * k_packed] once at load time;
  * epilogue 0 = dequant, 1 = dequant + SiLU; workspace >= mixq_int4_fused_workspace_size(M, 0, k_packed) bytes (A only). */
 MIXQ_API int mixq_int4_fused_dequantize_w8(const uint8_t* A, const int8_t* B_int8, const void* scale_row, const void* scale_col,

@@ -102,6 +102,7 @@ SIGNATURES = {
     "mixq_int4_fused_dequantize": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "mixq_int4_fused_dequantize_silu": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "mixq_int4_fused_dequantize_w8": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "mixq_int4_linear_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "mixq_unpack_int4_to_fp16": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "mixq_unpack_int4_to_int8": (_i, [_vp, _vp, ctypes.c_size_t, _vp]),
     "mixq_find_outliers_workspace_size": (ctypes.c_size_t, [_i]),

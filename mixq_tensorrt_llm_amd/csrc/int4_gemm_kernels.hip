@@ -43,15 +43,129 @@ __device__ __forceinline__ void widen_s4x16(const v4i w, v4i& even, v4i& odd)
 // wave-private 4-KiB LDS tile ([row][chunk ^ row], conflict-free both ways, no barrier: one wave's LDS operations execute in
 // order) turns the four registers of a 256-byte group into the group's four 64-byte fragments.  A partial last group (packed row
 // length not a multiple of 256) reads clamped addresses and zeroes the fragments past the row's end.
-template <int MT, int EPI, int KW, bool NTW, bool WROWS = false>
+// QF (round 6): the operator in ONE launch for decode batches of up to 16 rows -- p.A is the fp16 activation [M, 2 K] itself.
+// Every workgroup quantises it for its own use (FindRowScaleKernel4bit, cult.cu:2515-2567: s = fp16(amax / 7), q = int4(rn(x / s))): all 256
+// threads side by side, one pass where the rows fit four vectors per thread (else two), the packed rows go to LDS and the MFMA fragments are
+// read from there; workgroup 0 also writes the row scales out (p.sA: the P-flavour's cache.x_scale).
+// MEASURED (profiles/r06_int4_front_probe.txt, cold weights, us per linear: packed GEMM alone | quantiser launch + GEMM | this): 12288 x 4096 at
+// 1 / 2 / 4 / 8 rows 6.4 | 9.3 | 8.8, 6.5 | 9.4 | 10.0, 6.8 | 9.8 | 17.5, 6.7 | 9.8 | 27.5; 4096 x 11008 at 1 row 7.7 | 12.8 | 11.2.  The loop
+// itself is as fast from LDS as from the packed rows (6.6 with the quantiser body skipped); what costs is N / 16 workgroups each fetching the
+// same M rows at kernel start, cold (the weight stream of the launch before has flushed them from every L2): 2.2 us at one row, and
+// proportional to M.  So the API takes this form at ONE row only (-5..-12 % against two launches) -- the norm-fused producer
+// (mixq_rmsnorm_extract_quant4) stays the route that makes the 4-bit decode step 1.6 x the int8 one; asking for the first weight lines
+// under the front made it slower still (+2 us: the activation rows queue behind cold weight lines; removed).
+template <int MT, int EPI, int KW, bool NTW, bool WROWS = false, bool QF = false>
 __global__ __launch_bounds__(KW * 64) void gemm_skinny_s4_kernel(const GemmParams p)
 {
+    static_assert(!QF || MT == 1, "the fused quantiser serves one 16-row m tile");
     __shared__ v4i part[KW][MT][64]; // [K part][m tile][lane]
+    extern __shared__ __attribute__((aligned(16))) char qsm[]; // QF: packed rows [M][KB], then 16 row maxima, then 16 row scales (fp32)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n0 = blockIdx.x * 16;
     const int lr = lane & 15, lq = lane >> 4;
     const int64_t KB = p.K; // PACKED bytes per row (= in_features / 2)
+    typedef __attribute__((address_space(3))) const v4i lds_cv4i;
+    const unsigned q_lds = (unsigned)(size_t)(MIXQ_LDS_PTR(qsm));
+    if constexpr (QF) {
+        // (explicit LDS address space throughout: through generic pointers hipcc emits FLAT loads / stores / atomics -- the first build's 512
+        //  flat atomic maxima on one word cost ~3 us of the front)
+        typedef __attribute__((address_space(3))) int lds_int;
+        typedef __attribute__((address_space(3))) unsigned lds_u32;
+        lds_int* const rmax = (lds_int*)MIXQ_LDS_PTR(qsm + p.M * KB);
+        lds_u32* const qrows = (lds_u32*)MIXQ_LDS_PTR(qsm);
+        const int tid = threadIdx.x;
+        if (tid < 16) rmax[tid] = -1;
+        const int nvec = (int)(KB >> 2); // 16-byte vectors of 8 fp16 per row (2 KB elements)
+        const int total = p.M * nvec;
+        const uint4* const src = reinterpret_cast<const uint4*>(p.A);
+        auto vec_amax = [](const uint4& x) { // max over |x| bit patterns, NaN dropped like __hmax (-1: every element NaN)
+            const unsigned w[4] = {x.x, x.y, x.z, x.w};
+            int amax = -1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int lo = (int)(w[e] & 0x7fffu), hi = (int)((w[e] >> 16) & 0x7fffu);
+                lo = lo > 0x7c00 ? -1 : lo;
+                hi = hi > 0x7c00 ? -1 : hi;
+                amax = max(amax, max(lo, hi));
+            }
+            return amax;
+        };
+        auto quant_store = [&](const uint4& x, int idx) __attribute__((always_inline)) {
+            const int row = idx / nvec, v = idx - row * nvec;
+            const int am = rmax[row];
+            const uint16_t s_bits = f2h_bits(h2f(am < 0 ? (uint16_t)0x7fffu : (uint16_t)am) / 7.0f); // __hdiv(max, 7.0)
+            const float sc = h2f(s_bits);
+            const float rs = 1.0f / sc;
+            unsigned o = 0u;
+            if (am > 0 && am < 0x7c00 && s_bits != 0) {
+                // every element finite (the maximum is), the scale finite and non-zero: the packed-math quantiser of the int8 path (mixq_device.h
+                // quant_vec8_finite: 8 elements in ~25 VALU operations, bit-identical to quant_one) -- then the low nibble of each int8 is the int4
+                // (both are the low bits of the same __half2int_rn), two nibbles per byte, even element low
+                const uint2 b = quant_vec8_finite(x, sc, rs);
+                const unsigned lo = b.x & 0x0f0f0f0fu, hi = b.y & 0x0f0f0f0fu;
+                const unsigned plo = (lo | (lo >> 4)) & 0x00ff00ffu, phi = (hi | (hi >> 4)) & 0x00ff00ffu; // bytes 0 and 2 hold a packed pair each
+                o = (plo & 0xffu) | ((plo >> 8) & 0xff00u) | ((phi & 0xffu) << 16) | ((phi << 8) & 0xff000000u);
+            } else {
+                const unsigned w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { // int4b_t(int) keeps the low 4 bits of __half2int_rn(__hdiv(x, s)); NaN / inf / zero-scale rows
+                    const unsigned q0 = (unsigned)quant_one(h2f((uint16_t)(w[e] & 0xffffu)), sc) & 0xfu;
+                    const unsigned q1 = (unsigned)quant_one(h2f((uint16_t)(w[e] >> 16)), sc) & 0xfu;
+                    o |= (q0 | (q1 << 4)) << (8 * e);
+                }
+            }
+            qrows[(row * (int)KB >> 2) + v] = o;
+        };
+        __syncthreads();
+        if (total <= 4 * KW * 64) {
+            // the rows fit four vectors per thread: ONE pass, the values stay in registers between the maximum and the quantisation
+            uint4 xr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = tid + i * KW * 64;
+                xr[i] = idx < total ? src[idx] : make_uint4(0u, 0u, 0u, 0u);
+            }
+            const bool wave_one_row = (nvec & 63) == 0; // the 64 vectors of a wave's slot belong to ONE row: reduce in the wave, one LDS atomic
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = tid + i * KW * 64;
+                int am = idx < total ? vec_amax(xr[i]) : -1;
+                if (wave_one_row) {
+#pragma unroll
+                    for (int off = 32; off >= 1; off >>= 1) am = max(am, __shfl_xor(am, off, 64));
+                    if (lane == 0 && idx < total) __hip_atomic_fetch_max(rmax + idx / nvec, am, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else if (idx < total) {
+                    __hip_atomic_fetch_max(rmax + idx / nvec, am, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = tid + i * KW * 64;
+                if (idx < total) quant_store(xr[i], idx);
+            }
+        } else {
+            for (int idx = tid; idx < total; idx += KW * 64)
+                __hip_atomic_fetch_max(rmax + idx / nvec, vec_amax(src[idx]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __syncthreads();
+            for (int idx = tid; idx < total; idx += KW * 64) quant_store(src[idx], idx); // (second pass: from L1 / L2)
+        }
+        if (blockIdx.x == 0 && tid < p.M) {
+            const int am = rmax[tid];
+            const_cast<uint16_t*>(p.sA)[tid] = f2h_bits(h2f(am < 0 ? (uint16_t)0x7fffu : (uint16_t)am) / 7.0f);
+        }
+        __syncthreads();
+    }
+    // activation fragment of m tile t at packed byte offset `off` of its row (+ this lane's 16-byte chunk)
+    auto lda = [&](const int8_t* arow_t, int off) __attribute__((always_inline)) -> v4i {
+        if constexpr (QF) {
+            if (lr >= p.M) return v4i{0, 0, 0, 0};
+            return *(lds_cv4i*)(size_t)(q_lds + (unsigned)lr * (unsigned)KB + (unsigned)(lq * 16 + off));
+        } else {
+            return *reinterpret_cast<const v4i*>(arow_t + off);
+        }
+    };
 
     const int nsteps = (p.K + 63) >> 6; // 64 packed bytes = 128 elements per step
     const int per = (nsteps + KW - 1) / KW;
@@ -72,7 +186,12 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_s4_kernel(const GemmParam
     uint16_t psa = 0;
     uint2 psw = {0u, 0u}, pyb = {0u, 0u};
     if (fin) {
-        psa = p.sA[min(fm, p.M - 1)];
+        if constexpr (QF) {
+            typedef __attribute__((address_space(3))) const int lds_cint;
+            const int am = ((lds_cint*)MIXQ_LDS_PTR(qsm + p.M * KB))[min(fm, p.M - 1)];
+            psa = f2h_bits(h2f(am < 0 ? (uint16_t)0x7fffu : (uint16_t)am) / 7.0f);
+        }
+        if constexpr (!QF) psa = p.sA[min(fm, p.M - 1)];
         psw = *reinterpret_cast<const uint2*>(p.sW + min(fnb, p.N - 4));
         if (p.Y != nullptr) pyb = *reinterpret_cast<const uint2*>(p.Y + (int64_t)min(fm, p.M - 1) * p.N + min(fnb, p.N - 4));
     }
@@ -97,7 +216,7 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_s4_kernel(const GemmParam
             if (NTW) wf[u] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(wrow + off));
             else wf[u] = *reinterpret_cast<const v4i*>(wrow + off);
 #pragma unroll
-            for (int t = 0; t < MT; ++t) af[u][t] = *reinterpret_cast<const v4i*>(arow[t] + off);
+            for (int t = 0; t < MT; ++t) af[u][t] = lda(arow[t], off);
         }
         __builtin_amdgcn_sched_barrier(0); // every load of the batch is issued before the first MFMA
 #pragma unroll
@@ -146,7 +265,7 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_s4_kernel(const GemmParam
                 for (int sp = 0; sp < 4; ++sp) {
                     const int off = min((gg * 4 + sp) * 64 + lq * 16, koff_last) - lq * 16;
 #pragma unroll
-                    for (int t = 0; t < MT; ++t) af[gi * 4 + sp][t] = *reinterpret_cast<const v4i*>(arow[t] + off);
+                    for (int t = 0; t < MT; ++t) af[gi * 4 + sp][t] = lda(arow[t], off);
                 }
             }
             __builtin_amdgcn_sched_barrier(0); // every load of the batch is issued before the first MFMA
@@ -195,7 +314,7 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_s4_kernel(const GemmParam
         const int m = t * 16 + lr;
         const int nb = n0 + 4 * lq;
         if (m < p.M && nb < p.N) {
-            const float sa = h2f(t == wave ? psa : p.sA[m]);
+            const float sa = h2f((QF || t == wave) ? psa : p.sA[m]);
             const uint2 swb = t == wave ? psw : *reinterpret_cast<const uint2*>(p.sW + nb);
             uint2 yb = {0u, 0u};
             if (p.Y != nullptr) yb = t == wave ? pyb : *reinterpret_cast<const uint2*>(p.Y + (int64_t)m * p.N + nb);
@@ -249,6 +368,32 @@ static hipError_t launch_skinny_s4_cfg(const GemmParams& p, hipStream_t st)
 
 // (k_packed < 65536: the accumulators hold 256 x the true sums -- an all -8 row against an all -8 feature reaches exactly 2^31 at K = 131072
 //  elements and wraps; every shorter row is exact.  ADVICE r5.)
+// fused quantiser + stream (QF): M <= 16 rows whose packed image (M x k_packed bytes) fits 40 KiB of LDS next to the static arrays
+bool gemm_skinny_s4q_supported(int M, int N, int k_packed)
+{
+    return M >= 1 && M <= 16 && N % 16 == 0 && k_packed % 16 == 0 && k_packed <= 65520 && (size_t)M * k_packed + 128 <= 40 * 1024;
+}
+template <int EPI, bool NTW>
+static hipError_t launch_skinny_s4q_cfg(const GemmParams& p, hipStream_t st)
+{
+    const dim3 grid((unsigned)((p.N + 15) / 16)), block(4 * 64);
+    const size_t lds = (size_t)p.M * p.K + 128; // (+ 20 KiB of static arrays: below the 64 KiB a launch gets without asking)
+    const int wr = g_s4_wrows.load(std::memory_order_relaxed);
+    if (p.K >= 256 && (wr == 2 || (wr == 1 && p.M > 4 && (int64_t)p.N * p.K >= ((int64_t)16 << 20))))
+        hipLaunchKernelGGL((gemm_skinny_s4_kernel<1, EPI, 4, NTW, true, true>), grid, block, lds, st, p);
+    else hipLaunchKernelGGL((gemm_skinny_s4_kernel<1, EPI, 4, NTW, false, true>), grid, block, lds, st, p);
+    return hipGetLastError();
+}
+// p.A = fp16 activation [M, 2 p.K], p.B packed int4 [N, p.K], p.sA = row scales OUT (fp16 [M]), p.sW, p.Y, p.D as launch_gemm_skinny_s4
+hipError_t launch_gemm_skinny_s4q(const GemmParams& p, int epi, hipStream_t st)
+{
+    if (!gemm_skinny_s4q_supported(p.M, p.N, p.K) || (epi != EPI_DEQUANT && epi != EPI_DEQUANT_SILU)) return hipErrorInvalidValue;
+    const bool ntw = (int64_t)p.N * p.K >= ((int64_t)32 << 20);
+    note_gemm_kernel("gemm_skinny_s4_kernel<QF> (fp16 rows quantised in the launch, packed int4 weight stream)");
+    if (epi == EPI_DEQUANT) return ntw ? launch_skinny_s4q_cfg<EPI_DEQUANT, true>(p, st) : launch_skinny_s4q_cfg<EPI_DEQUANT, false>(p, st);
+    return ntw ? launch_skinny_s4q_cfg<EPI_DEQUANT_SILU, true>(p, st) : launch_skinny_s4q_cfg<EPI_DEQUANT_SILU, false>(p, st);
+}
+
 bool gemm_skinny_s4_supported(int M, int N, int k_packed) { return M >= 1 && M <= 64 && N % 16 == 0 && k_packed % 16 == 0 && k_packed <= 65520; }
 
 // p.A / p.B = PACKED int4 [M, K] / [N, K] with p.K = packed bytes per row; p.Y = fp16 addend or null; p.O unused

@@ -132,9 +132,14 @@ void mixq_debug_set_quant_stamp_buffer(void* device_u64_8_per_block)
 }
 
 static void set_int4_stream(int on);
+static void set_int4_fuse_quant(int on);
 void mixq_debug_set_gemm_variant(int variant)
 {
     if (!debug_knobs_enabled()) return;
+    if (variant >= 875 && variant <= 877) { // mixq_int4_linear_forward: rows quantised inside the stream launch by the measured rule (875, default: one row) / never (876) / whenever the kernel serves the size (877: tests)
+        set_int4_fuse_quant(variant == 875 ? 1 : variant == 876 ? 0 : 2);
+        return;
+    }
     if (variant >= 872 && variant <= 874) { // packed-int4 weight stream, 256-byte runs: 872 by the measured rule (default), 873 off, 874 always
         mixq::set_s4_wrows(variant == 872 ? 1 : variant == 873 ? 0 : 2);
         return;
@@ -156,6 +161,7 @@ void mixq_debug_reset(void)
                   894 /* feature tiles automatic */, 880 /* skinny-GEMM weight image off */, 884 /* row-major weights in 256-byte runs */, 1240 /* mid-M deep form automatic */, 1238, 1410 /* its K walk rotated per tile row */, 1420 /* the deep plan takes it from 129 rows on */, 1290 /* non-temporal weight copies of single-row tile launches: by rule */, 1300 /* quantisers: block-per-row by the measured rules */})
         mixq::set_gemm_variant(v);
     set_int4_stream(1);
+    set_int4_fuse_quant(1);
     mixq::set_s4_wrows(1);
 }
 
@@ -526,6 +532,8 @@ int mixq_int4quant(int rows, int cols, const void* src, uint8_t* dst, void* scal
 static size_t align16_up(size_t v) { return (v + 15) & ~static_cast<size_t>(15); }
 static std::atomic<int> g_int4_stream{1};
 static void set_int4_stream(int on) { g_int4_stream.store(on); }
+static std::atomic<int> g_int4_fuse_quant{1}; // test / measurement knob 875 (default: by rule) / 876 (never) / 877 (always)
+static void set_int4_fuse_quant(int on) { g_int4_fuse_quant.store(on); }
 // ^ test / measurement knob 870 (default: on) / 871: decode batches through the unpack route
 
 size_t mixq_int4_fused_workspace_size(int M, int N, int k_packed)
@@ -570,6 +578,34 @@ static int int4_fused_impl(const uint8_t* A, const uint8_t* B, const void* scale
     }
     if (e != hipSuccess) return hip_rc(e);
     return fused_dequant_impl(a8, b8, scale_row, scale_col, y, D, M, N, 2 * k_packed, epi, stream);
+}
+
+// One call for the 4-bit flavour's linear on an fp16 activation (round 6): FindRowScale(bit = 4) + int4FusedDequantize[Silu]
+// (cult.cu:2515-2567 + 2005-2060 / 2119-2181).  ONE row runs as ONE launch (the row is quantised inside the weight-streaming kernel: -5..-12 %
+// against two launches); from two rows on the in-kernel quantiser loses to the quantiser launch it replaces (int4_gemm_kernels.hip, QF) and
+// the call is the two launches, through `q_packed`.
+int mixq_int4_linear_forward(const void* x, const uint8_t* B, void* x_scale, uint8_t* q_packed, const void* scale_col, const void* y,
+                             void* D, int M, int N, int k_packed, int epilogue, char* workspace, void* stream)
+{
+    if (epilogue != mixq::EPI_DEQUANT && epilogue != mixq::EPI_DEQUANT_SILU) return MIXQ_E_BADARG;
+    if (M < 0 || N < 0 || k_packed <= 0) return MIXQ_E_BADARG;
+    if (M == 0 || N == 0) return MIXQ_OK;
+    if (!x || !B || !x_scale || !scale_col || !D) return MIXQ_E_BADARG;
+    if (k_packed % 16) return MIXQ_E_SHAPE;
+    if (!aligned16(x) || !aligned16(B) || !aligned16(D) || !aligned16(scale_col) || (y && !aligned16(y))) return MIXQ_E_ALIGN;
+    const int fq = g_int4_fuse_quant.load(std::memory_order_relaxed);
+    if (g_int4_stream.load(std::memory_order_relaxed) && (fq == 2 || (fq == 1 && M == 1)) && mixq::gemm_skinny_s4q_supported(M, N, k_packed)) {
+        mixq::GemmParams p{};
+        p.A = static_cast<const int8_t*>(x), p.B = reinterpret_cast<const int8_t*>(B);
+        p.sA = static_cast<const uint16_t*>(x_scale), p.sW = static_cast<const uint16_t*>(scale_col);
+        p.Y = static_cast<const uint16_t*>(y), p.D = D;
+        p.M = M, p.N = N, p.K = k_packed, p.O = 0;
+        return hip_rc(mixq::launch_gemm_skinny_s4q(p, epilogue, static_cast<hipStream_t>(stream)));
+    }
+    if (!q_packed) return MIXQ_E_WORKSPACE;
+    const int rc = mixq_int4quant(M, 2 * k_packed, x, q_packed, x_scale, stream);
+    if (rc != MIXQ_OK) return rc;
+    return int4_fused_impl(q_packed, B, x_scale, scale_col, y, D, M, N, k_packed, workspace, epilogue, stream);
 }
 
 int mixq_int4_fused_dequantize_w8(const uint8_t* A, const int8_t* B_int8, const void* scale_row, const void* scale_col,

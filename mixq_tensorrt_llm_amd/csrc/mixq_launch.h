@@ -186,6 +186,9 @@ hipError_t launch_unpack_s4(const uint8_t* src, int8_t* dst, size_t packed_bytes
 void set_s4_wrows(int mode); // knob 872 by rule (default) / 873 off / 874 always: packed weights read in 256-byte runs (int4_gemm_kernels.hip WROWS)
 bool gemm_skinny_s4_supported(int M, int N, int k_packed);
 hipError_t launch_gemm_skinny_s4(const GemmParams& p, int epi, hipStream_t st);
+// the same with the fp16 rows quantised inside the launch (M <= 16): p.A = fp16 [M, 2 p.K], p.sA = the row scales, WRITTEN (workgroup 0)
+bool gemm_skinny_s4q_supported(int M, int N, int k_packed);
+hipError_t launch_gemm_skinny_s4q(const GemmParams& p, int epi, hipStream_t st);
 hipError_t launch_unpack_s4_columns(const uint8_t* weight, const int32_t* ind, int rows, int cols_packed, int n,
                                     void* out, hipStream_t st);
 hipError_t launch_w8a16(const void* A, const uint8_t* Wq, const void* scale, void* Out, int M, int N, int K,

@@ -253,6 +253,27 @@ def int4FusedDequantizeSilu(A, B, scale_row, scale_col, y, M, N, K, B_int8=None)
 
 
 @_on_tensor_device
+def int4_linear_forward(x, B, scale_col, y, x_scale, silu=False):
+    """MI355X extension (``mixq_int4_linear_forward``): FindRowScale(x, x_scale, M, K, 4) + int4FusedDequantize[Silu] in ONE call; a single
+    row runs as ONE launch (quantised inside the weight-streaming kernel), more rows as the two launches.  x fp16 [M, K], B packed uint8
+    [N, K // 2]; ``x_scale`` is written like the reference's cache.x_scale.  Returns (out fp16 [M, N], q packed uint8 [M, K // 2])."""
+    _dev(*(t for t in (x, B, scale_col, y, x_scale) if t is not None))
+    M, K = x.shape
+    N, kp = B.shape
+    assert K == 2 * kp and x.dtype == torch.float16 and B.dtype == torch.uint8
+    _rows_fit(x_scale, M, "int4_linear_forward")
+    lib = _lib.load()
+    D = torch.empty((M, N), dtype=torch.float16, device=x.device)
+    q = torch.empty((M, kp), dtype=torch.uint8, device=x.device)   # (written unless the call ran as one launch)
+    need = int(lib.mixq_int4_fused_workspace_size(M, N, kp))
+    ws = torch.empty(max(16, need), dtype=torch.uint8, device=x.device) if need else None
+    spare = q
+    _lib.check(lib.mixq_int4_linear_forward(_p(x), _p(B), _p(x_scale), _p(spare), _p(scale_col), _p(y), _p(D), M, N, kp, 1 if silu else 0,
+                                            _p(ws), _st(x)), "int4_linear_forward")
+    return D, q
+
+
+@_on_tensor_device
 def unpack_int4_to_int8(packed):
     """Sign-extending unpack of a packed int4 tensor [rows, cols / 2] -> int8 [rows, cols] (``mixq_unpack_int4_to_int8``)."""
     _dev(packed)

@@ -246,3 +246,67 @@ def test_mixlinear_4bit_decode_batch_and_prefill_agree_with_the_oracle(oracle):
         want = oracle.mixlinear4_forward(qp, sc, ind, wc, x.copy())
         g, w = got.astype(np.float64), want.astype(np.float64)
         assert np.abs(g - w).max() / np.abs(w).max() < 1e-3, M
+
+
+@pytest.mark.parametrize("silu", [False, True])
+@pytest.mark.parametrize("M,N,K", [(1, 512, 4096), (3, 256, 1024), (8, 1024, 4096), (16, 256, 2048), (5, 128, 2080), (2, 512, 11008), (1, 256, 28672),
+                                   (9, 256, 11008), (40, 256, 1024)])
+def test_int4_linear_forward_is_quant_then_gemm_in_one_call(oracle, M, N, K, silu):
+    """mixq_int4_linear_forward: FindRowScale(bit = 4) + int4FusedDequantize[Silu] on the fp16 rows in ONE call -- for up to
+    16 rows whose packed image fits LDS, ONE launch (the rows are quantised inside the weight-streaming kernel).  Bit for bit the two
+    launches it replaces, x_scale included; rows with NaN / zeros / a huge element; against oracle.quant4_rows + the exact integer product."""
+    from mixq_tensorrt_llm_amd import _lib, mixlib
+    lib = _lib.load()
+    rng = np.random.default_rng(M * 131 + K)
+    x = (rng.standard_normal((M, K)) * rng.uniform(0.05, 20)).astype(np.float16)
+    x[0, 5] = np.float16(300.0)
+    if M > 2:
+        x[1] = 0
+        x[2, 9] = np.nan
+    b = rng.integers(-8, 8, (N, K), dtype=np.int8)
+    bp = dev(oracle.pack_i4(b))
+    sb = (rng.random(N) * 1e-2 + 1e-3).astype(np.float16)
+    y = (rng.standard_normal((M, N)) * 0.5).astype(np.float16)
+    xs = torch.zeros((max(M, 64), 1), dtype=torch.float16, device="cuda:0")
+    fits = M <= 16 and M * (K // 2) <= 40 * 1024
+    lib.mixq_debug_set_gemm_variant(877)     # the fused quantiser wherever the kernel serves the size (by default: one row only, the measured rule)
+    try:
+        got, q = mixlib.int4_linear_forward(dev(x), bp, dev(sb.reshape(1, N)), dev(y), xs, silu=silu)
+        torch.cuda.synchronize()
+        assert (b"<QF>" in lib.mixq_debug_last_gemm_kernel()) == fits, lib.mixq_debug_last_gemm_kernel()
+    finally:
+        lib.mixq_debug_set_gemm_variant(875)
+    xs_d = torch.zeros_like(xs)
+    got_d, q_d = mixlib.int4_linear_forward(dev(x), bp, dev(sb.reshape(1, N)), dev(y), xs_d, silu=silu)   # the default rule
+    torch.cuda.synchronize()
+    assert (b"<QF>" in lib.mixq_debug_last_gemm_kernel()) == (fits and M == 1)
+    assert np.array_equal(bits(got_d.cpu().numpy()), bits(got.cpu().numpy())) and np.array_equal(bits(xs_d.cpu().numpy()), bits(xs.cpu().numpy()))
+    # the two launches it replaces
+    xs2 = torch.zeros_like(xs)
+    q2 = mixlib.FindRowScale(dev(x), xs2, M, K, 4)
+    fn = mixlib.int4FusedDequantizeSilu if silu else mixlib.int4FusedDequantize
+    want2 = fn(q2, bp, xs2, dev(sb.reshape(1, N)), dev(y), M, N, K // 2)
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(xs[:M].cpu().numpy()), bits(xs2[:M].cpu().numpy()))
+    assert np.array_equal(bits(got.cpu().numpy()), bits(want2.cpu().numpy()))
+    if not (fits and M == 1):
+        assert torch.equal(q_d, q2)
+    # the same with the fused quantiser switched off: two launches through q_packed, same bits
+    lib.mixq_debug_set_gemm_variant(876)
+    try:
+        got3, _ = mixlib.int4_linear_forward(dev(x), bp, dev(sb.reshape(1, N)), dev(y), torch.zeros_like(xs), silu=silu)
+        torch.cuda.synchronize()
+        assert b"<QF>" not in lib.mixq_debug_last_gemm_kernel()
+    finally:
+        lib.mixq_debug_set_gemm_variant(875)
+    assert np.array_equal(bits(got3.cpu().numpy()), bits(got.cpu().numpy()))
+    # and the oracle
+    qo, so = oracle.quant4_rows(x)
+    assert np.array_equal(bits(xs[:M].cpu().numpy().reshape(-1)), bits(so))
+    want = oracle.dequant_epilogue(oracle.gemm_s8s8s32(oracle.unpack_i4(qo), b), so, sb, C=y, silu=silu)
+    g, w = got.cpu().numpy().astype(np.float64), want.astype(np.float64)
+    if silu:
+        ok = np.isfinite(w)
+        assert np.abs(g[ok] - w[ok]).max() / max(np.abs(w[ok]).max(), 1e-30) < 1e-3
+    else:
+        assert np.array_equal(bits(got.cpu().numpy()), bits(want))
