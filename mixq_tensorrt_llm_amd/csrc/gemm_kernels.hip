@@ -703,7 +703,11 @@ void set_gemm_variant(int v)
         g_deep_mid.store(v == 1420);
         return;
     }
-    if (v >= 1410 && v <= 1412) { // round-6 mid kernel: tile rows start at different K slices: 1410 where K is not split over workgroups (default) / 1411 never / 1412 always
+    if (v == 1430 || v == 1431) { // round-6 mid kernel: tile width by rule (1430, default: 96 where that puts more workgroups on the chip) / 128 always (1431)
+        set_mid_bn(v - 1430);
+        return;
+    }
+    if (v >= 1410 && v <= 1412) { // round-6 mid kernel: tile rows start at different K slices: 1411 never (default) / 1410 where K is not split over workgroups / 1412 always
         set_mid_rot(v == 1410 ? 1 : v == 1411 ? 0 : 2);
         return;
     }
@@ -932,7 +936,7 @@ hipError_t launch_gemm(const GemmParams& p, int epi, hipStream_t st)
         return launch_gemm_skinny(p, epi, st);
     }
     if (variant == 0 && epi != EPI_INT32 && p.a_frag == 0 && gemm_deep_takes(p.M, p.N, p.K, p.splitk_ws != nullptr)) {
-        if (gemm_deep_build(p.M, p.N, p.K) == 3) chose("gemm_w8a8o16_mid_kernel<DEEP> (128x128 tiles, copy-only waves, one barrier per pair of slices, K split over workgroups)");
+        if (gemm_deep_build(p.M, p.N, p.K) == 3) chose("gemm_w8a8o16_mid_kernel<DEEP> (128x128 / 128x96 tiles, copy-only waves, one barrier per pair of slices, K split over workgroups)");
         else chose("gemm_w8a8o16_kernel<DEEP> (128x128 tiles, 4 stages in flight, K split over workgroups)");
         return launch_gemm_deep(p, epi, st);
     }
@@ -992,8 +996,10 @@ void describe_gemm_plan(const GemmParams& p, int epi, char* buf, size_t len)
         return;
     }
     if (variant == 0 && epi != EPI_INT32 && p.a_frag == 0 && gemm_deep_takes(p.M, p.N, p.K, scratch)) {
-        snprintf(buf, len, "deep: 128x128 tiles, %d workgroup(s) per tile along K%s", gemm_deep_factor(p.M, p.N, p.K, scratch),
-                 gemm_deep_build(p.M, p.N, p.K) == 3 ? ", copy-only waves" : "");
+        const int xs = gemm_deep_factor(p.M, p.N, p.K, scratch);
+        const bool midk = gemm_deep_build(p.M, p.N, p.K) == 3;
+        snprintf(buf, len, "deep: 128x%d tiles, %d workgroup(s) per tile along K%s", midk ? gemm_mid_tile_width(p.M, p.N, xs) : 128, xs,
+                 midk ? ", copy-only waves" : "");
         return;
     }
     const int64_t tiles256 = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256);

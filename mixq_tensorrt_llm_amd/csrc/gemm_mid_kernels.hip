@@ -31,106 +31,133 @@
 namespace mixq {
 
 namespace mid {
-constexpr int BM = 128, BN = 128, KS = 128;
-constexpr int XB = BN * KS, YB = BM * KS, STAGE = XB + YB; // 16 + 16 KiB
+constexpr int BM = 128, KS = 128;
+constexpr int YB = BM * KS;      // 16 KiB: the qA rows of a slice
 constexpr int NST = 5;
 constexpr int NCW = 8, NLD = 2, TC = NCW * 64, T = (NCW + NLD) * 64;
-constexpr int PER = 16;          // copy instructions per loader wave per slice (16 x 1 KiB = one operand's 128 rows x 128 B)
 constexpr int OSLICE = 256;      // bytes per LDS row in the outlier phase (128 fp16)
-constexpr int EXCH = 65536;      // exchange region [0, 64 KiB); outlier operands behind it
 constexpr int GROUP_M = 4;
-constexpr size_t LDS = (size_t)NST * STAGE; // 160 KiB
-static_assert(EXCH + (BM + BN) * OSLICE <= LDS, "exchange + outlier tiles must fit the ring's LDS");
+
+// Tile width BN and the layout of a group's four compute waves over the 128 x BN tile (wave tile = TMW x TNW MFMA tiles of 32 x 32):
+//   BN = 128: 2 x 2 waves of 64 x 64;   BN = 96: 4 x 1 waves of 32 x 96 -- more, narrower tiles for shapes whose 128-wide tiles leave a quarter
+//   of the CUs idle (11008 x 4096 at 129..256 rows: 230 workgroups instead of 172; gemm_mid_tile_width below has the measurements).
+template <int BN_>
+struct Layout {
+    static constexpr int BN = BN_;
+    static constexpr int WMW = BN_ == 128 ? 2 : 4, WNW = BN_ == 128 ? 2 : 1; // waves of a group along m / n
+    static constexpr int TMW = BM / WMW / 32, TNW = BN_ / WNW / 32;          // MFMA tiles of a wave tile along m / n
+    static constexpr int WMT = BM / WMW, WNT = BN_ / WNW;                    // wave tile in elements
+    static constexpr int XB = BN_ * KS, STAGE = XB + YB;
+    static constexpr int PERX = BN_ * 8 / 64, PERY = BM * 8 / 64;             // copies per slice of the W / qA loader wave
+    static constexpr int HT = TNW * TMW * 2, KEEP = HT / 2;                   // half tiles (8 accumulator registers) of a wave tile; kept per group
+    static constexpr size_t LDS = (size_t)NST * STAGE;
+    static_assert(HT % 2 == 0 && WMW * WNW == 4, "four waves per group");
+    static_assert(2 * STAGE >= 8 * KEEP * 2048, "the exchange (8 waves x KEEP half tiles x 2 KiB) must fit two stages");
+    static_assert(2 * STAGE >= (BM + BN_) * OSLICE, "the two outlier tiles must fit two adjacent stages");
+};
 } // namespace mid
 
-// ---- what a compute wave does behind the main loop (both schedules): swap halves, K split over workgroups, epilogue ------------
-// `acc`: the wave's 64 x 64 sums over its group's slices; barriers B0, B1 (+ B2, B3 with XSP) are executed by EVERY wave of the
-// workgroup (the copy-only waves run mid_loader_tail next to this).
-// LDS regions (byte offsets, wave-uniform): ex0 / ex1 = 32 KiB each, the exchange slots of waves 0-3 / 4-7; ow / oa = the fpW / fpA tiles
-// (32 KiB each) the copy-only waves staged.
-// What the epilogue reads from global memory, requested by a compute wave at KERNEL START and carried through the loop (10 registers, + 16
-// with an addend; the multiplicand of gate * up is requested in front of the exchange instead: 16 registers more through the loop spill): the first build loaded sA / sW / y inside the store loop -- a dependent L2 round trip per 8-byte store
-// group, 3.8 us of epilogue per tile in its timeline (profiles/r06_mid_v1_timeline.txt).  Clamped addresses: rows / columns past the edge
-// are never stored.
+// What the epilogue reads from global memory, requested by a compute wave at KERNEL START and carried through the loop (per kept half tile:
+// the row scale, two weight-scale quads, two addend quads; the multiplicand of gate * up is requested in front of the exchange instead --
+// 16 registers more through the loop spill): the first build loaded sA / sW / y inside the store loop -- a dependent L2 round trip per
+// 8-byte store group, 3.8 us of epilogue per tile in its timeline (profiles/r06_mid_v1_timeline.txt).  Clamped addresses: rows / columns
+// past the edge are never stored.
+template <int KEEP>
 struct MidEpiPre {
-    float sa[2];
-    uint2 sw[4], y[2][4];
+    float sa[KEEP];
+    uint2 sw[KEEP][2], y[KEEP][2];
 };
-template <int EPI>
-__device__ __forceinline__ void mid_epi_prefetch(MidEpiPre& e, const GemmParams& p, int wave, int lane, int m0, int n0)
+
+// half tile h of a wave tile (order: n tile i, m tile j, half gh): rows m_of(h), first column n_of(h) of this lane's quads g2 = 0, 1 (+ 8 g2)
+template <class L>
+struct HalfTile {
+    int i, j, gh;
+    __device__ __forceinline__ explicit HalfTile(int h) : i(h / (2 * L::TMW)), j((h >> 1) % L::TMW), gh(h & 1) {}
+    __device__ __forceinline__ int m(int m0, int wm, int lr) const { return m0 + wm * L::WMT + j * 32 + lr; }
+    __device__ __forceinline__ int n(int n0, int wn, int lh) const { return n0 + wn * L::WNT + i * 32 + 4 * lh + 16 * gh; }
+};
+
+template <int EPI, class L>
+__device__ __forceinline__ void mid_epi_prefetch(MidEpiPre<L::KEEP>& e, const GemmParams& p, int wave, int lane, int m0, int n0)
 {
-    const int group = wave >> 2, w4 = wave & 3, wm = w4 >> 1, wn = w4 & 1;
+    const int group = wave >> 2, w4 = wave & 3, wm = w4 / L::WNW, wn = w4 % L::WNW;
     const int lr = lane & 31, lh = lane >> 5;
     if (EPI == EPI_INT32) return;
-    const int nb0p = n0 + wn * 64 + group * 32 + 4 * lh;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) e.sw[g] = *reinterpret_cast<const uint2*>(p.sW + min(nb0p + 8 * g, p.N - 4));
+    for (int k = 0; k < L::KEEP; ++k) {
+        const HalfTile<L> t(group * L::KEEP + k);
+        const int mp = min(t.m(m0, wm, lr), p.M - 1);
+        e.sa[k] = h2f(p.sA[mp]);
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-        const int mp = min(m0 + wm * 64 + jj * 32 + lr, p.M - 1);
-        e.sa[jj] = h2f(p.sA[mp]);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int64_t at = (int64_t)mp * p.N + min(nb0p + 8 * g, p.N - 4);
-            e.y[jj][g] = p.Y != nullptr ? *reinterpret_cast<const uint2*>(p.Y + at) : make_uint2(0u, 0u);
+        for (int g2 = 0; g2 < 2; ++g2) {
+            const int nb = min(t.n(n0, wn, lh) + 8 * g2, p.N - 4);
+            e.sw[k][g2] = *reinterpret_cast<const uint2*>(p.sW + nb);
+            e.y[k][g2] = p.Y != nullptr ? *reinterpret_cast<const uint2*>(p.Y + (int64_t)mp * p.N + nb) : make_uint2(0u, 0u);
         }
     }
 }
 
-template <int EPI, bool XSP, int TC>
-__device__ __forceinline__ void mid_finish(const GemmParams& p, char* smem, v16i (&acc)[2][2], int wave, int lane, int tid, int m0, int n0,
-                                           int t_lin, int xrank, int XS, const MidEpiPre& pre, int ex0, int ex1, int ow, int oa)
+// ---- what a compute wave does behind the main loop: swap half tiles, K split over workgroups, epilogue ---------------------------------
+// `acc`: the wave tile's sums over its group's slices; barriers B0, B1 (+ B2, B3 with XSP) are executed by EVERY wave of the workgroup.
+// Group 0 keeps the first KEEP half tiles of every wave tile and adds group 1's sums of them, group 1 the rest (integer adds: same sums).
+// LDS regions (byte offsets, wave-uniform): ex0 / ex1 = the exchange slots of waves 0-3 / 4-7 (KEEP x 2 KiB each); ow / oa = the fpW / fpA
+// tiles the copy-only waves staged.
+template <int EPI, bool XSP, class L>
+__device__ __forceinline__ void mid_finish(const GemmParams& p, char* smem, v16i (&acc)[L::TNW][L::TMW], int wave, int lane, int tid, int m0,
+                                           int n0, int t_lin, int xrank, int XS, const MidEpiPre<L::KEEP>& pre, int ex0, int ex1, int ow, int oa)
 {
     using namespace mid;
-    const int group = wave >> 2, w4 = wave & 3, wm = w4 >> 1, wn = w4 & 1;
+    constexpr int KEEP = L::KEEP, TMW = L::TMW;
+    const int group = wave >> 2, w4 = wave & 3, wm = w4 / L::WNW, wn = w4 % L::WNW;
     const int lr = lane & 31, lh = lane >> 5;
     const bool has_outliers = p.O > 0;
     dbg_stamp(p.dbg, 3); // last MFMA issued (this wave)
-    uint2 mulq[2][4]; // (the multiplicand of gate * up: requested here, in front of the exchange)
+    uint2 mulq[KEEP][2]; // (the multiplicand of gate * up: requested here, in front of the exchange)
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj)
+    for (int k = 0; k < KEEP; ++k) {
+        const HalfTile<L> t(group * KEEP + k);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int64_t at = (int64_t)min(m0 + wm * 64 + jj * 32 + lr, p.M - 1) * p.N + min(n0 + wn * 64 + group * 32 + 4 * lh + 8 * g, p.N - 4);
-            mulq[jj][g] = EPI == EPI_DEQUANT_SILU_MUL ? *reinterpret_cast<const uint2*>(p.Mul + at) : make_uint2(0u, 0u);
+        for (int g2 = 0; g2 < 2; ++g2) {
+            const int64_t at = (int64_t)min(t.m(m0, wm, lr), p.M - 1) * p.N + min(t.n(n0, wn, lh) + 8 * g2, p.N - 4);
+            mulq[k][g2] = EPI == EPI_DEQUANT_SILU_MUL ? *reinterpret_cast<const uint2*>(p.Mul + at) : make_uint2(0u, 0u);
         }
-    // ---- the two groups swap halves: group 0 keeps n half 0 and adds group 1's, group 1 keeps n half 1 ---------------------------
-    __syncthreads(); // B0
-    v16i fin[2];
-    {
-        char* const mine = smem + (wave < 4 ? ex0 : ex1) + (wave & 3) * 8192;
-        // (compile-time half index: a run-time index into acc[][] would put the accumulators into scratch memory)
-        auto park = [&](auto half_tag) __attribute__((always_inline)) {
-            constexpr int hx = decltype(half_tag)::value;
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    *reinterpret_cast<v4i*>(mine + (jj * 4 + q) * 1024 + lane * 16) =
-                        v4i{acc[hx][jj][4 * q], acc[hx][jj][4 * q + 1], acc[hx][jj][4 * q + 2], acc[hx][jj][4 * q + 3]};
-        };
-        if (group == 0) park(std::integral_constant<int, 1>{});
-        else park(std::integral_constant<int, 0>{});
-        __syncthreads(); // B1 (the loader waves' outlier copies have landed by now as well)
-        const char* const theirs = smem + (wave < 4 ? ex1 : ex0) + (wave & 3) * 8192;
-        if (group == 0) {
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) fin[jj] = acc[0][jj];
-        } else {
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) fin[jj] = acc[1][jj];
-        }
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const v4i t4 = *reinterpret_cast<const v4i*>(theirs + (jj * 4 + q) * 1024 + lane * 16);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) fin[jj][4 * q + e] += t4[e];
-            }
     }
-    const int nh = group; // the n half of the wave's 64 columns this wave finishes
-    dbg_stamp(p.dbg, 4); // halves swapped, outlier operands in LDS
+    __syncthreads(); // B0
+    int fin[KEEP][8];
+    {
+        char* const mine = smem + (wave < 4 ? ex0 : ex1) + (wave & 3) * (KEEP * 2048);
+        const char* const theirs = smem + (wave < 4 ? ex1 : ex0) + (wave & 3) * (KEEP * 2048);
+        // (compile-time half-tile indices: a run-time index into acc[][] would put the accumulators into scratch memory)
+        auto swap = [&](auto give0_tag, auto keep0_tag) __attribute__((always_inline)) {
+            constexpr int G0 = decltype(give0_tag)::value, K0 = decltype(keep0_tag)::value;
+#pragma unroll
+            for (int k = 0; k < KEEP; ++k) {
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int h = G0 + k; // given away
+                const int i = h / (2 * TMW), j = (h >> 1) % TMW, gh = h & 1;
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    *reinterpret_cast<v4i*>(mine + (k * 2 + q) * 1024 + lane * 16) =
+                        v4i{acc[i][j][8 * gh + 4 * q], acc[i][j][8 * gh + 4 * q + 1], acc[i][j][8 * gh + 4 * q + 2], acc[i][j][8 * gh + 4 * q + 3]};
+            }
+            __syncthreads(); // B1 (the loader waves' outlier copies have landed by now as well)
+#pragma unroll
+            for (int k = 0; k < KEEP; ++k) {
+                const int h = K0 + k; // kept
+                const int i = h / (2 * TMW), j = (h >> 1) % TMW, gh = h & 1;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const v4i t4 = *reinterpret_cast<const v4i*>(theirs + (k * 2 + q) * 1024 + lane * 16);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) fin[k][4 * q + e] = acc[i][j][8 * gh + 4 * q + e] + t4[e];
+                }
+            }
+        };
+        if (group == 0) swap(std::integral_constant<int, KEEP>{}, std::integral_constant<int, 0>{});
+        else swap(std::integral_constant<int, 0>{}, std::integral_constant<int, KEEP>{});
+    }
+    dbg_stamp(p.dbg, 4); // half tiles swapped, outlier operands in LDS
 
     // ---- K split over workgroups: park, count in, and only the last one to arrive goes on (gemm_kernels.hip, XSP) -------------
     if (XSP) {
@@ -138,17 +165,17 @@ __device__ __forceinline__ void mid_finish(const GemmParams& p, char* smem, v16i
         //  LDS aperture ends at 64 KiB)
         typedef __attribute__((address_space(3))) volatile unsigned lds_vu32;
         lds_vu32& arrived_s = *(lds_vu32*)MIXQ_LDS_PTR(smem + ex0);
-        constexpr int TILE_DW = 2 * 16 * TC; // dwords of one parked tile: [m half][16][512 compute threads]
+        constexpr int TILE_DW = KEEP * 8 * TC; // dwords of one parked tile: [kept half tile][8][512 compute threads]
         unsigned* const counter = static_cast<unsigned*>(p.splitk_ws) + t_lin;
         int* const slots = reinterpret_cast<int*>(static_cast<char*>(p.splitk_ws) + kSplitkWordsBytes) + (size_t)t_lin * XS * TILE_DW;
         int* const my = slots + (size_t)xrank * TILE_DW + tid;
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
+        for (int k = 0; k < KEEP; ++k)
 #pragma unroll
-            for (int e = 0; e < 16; ++e)
-                __hip_atomic_store(my + (jj * 16 + e) * TC, fin[jj][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int e = 0; e < 8; ++e)
+                __hip_atomic_store(my + (k * 8 + e) * TC, fin[k][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every write-through acknowledged
-        __syncthreads(); // B2 (also: everybody has read its partner's half, the first LDS word may be reused)
+        __syncthreads(); // B2 (also: everybody has read its partner's half tiles, the first LDS word may be reused)
         if (tid == 0) arrived_s = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads(); // B3
         if (arrived_s != (unsigned)(XS - 1)) return;
@@ -156,38 +183,44 @@ __device__ __forceinline__ void mid_finish(const GemmParams& p, char* smem, v16i
         for (int o = 1; o < XS; ++o) { // the other parts, in a rotation that depends on nothing but the rank
             const int* const theirs = slots + (size_t)((xrank + o) % XS) * TILE_DW + tid;
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
+            for (int k = 0; k < KEEP; ++k)
 #pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    fin[jj][e] += __hip_atomic_load(theirs + (jj * 16 + e) * TC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int e = 0; e < 8; ++e)
+                    fin[k][e] += __hip_atomic_load(theirs + (k * 8 + e) * TC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 
-    // ---- epilogue: two 32 x 32 tiles per wave (gemm_kernels.hip's arithmetic, statement by statement) ----------------------------
+    // ---- epilogue, one kept half tile (32 rows x 16 columns: two quads per lane) at a time; gemm_kernels.hip's arithmetic -------------------
     const int osteps = has_outliers ? (p.O + 15) / 16 : 0;
+    v16f P;
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-        const int m = m0 + wm * 64 + jj * 32 + lr;
-        const int nb0 = n0 + wn * 64 + nh * 32 + 4 * lh;
+    for (int e = 0; e < 16; ++e) P[e] = 0.f;
+    int ptile = -1; // the MFMA tile whose outlier product P holds
+#pragma unroll
+    for (int k = 0; k < KEEP; ++k) {
+        const HalfTile<L> t(group * KEEP + k);
+        const int m = t.m(m0, wm, lr);
+        const int nb0 = t.n(n0, wn, lh);
         if (EPI == EPI_INT32) {
             if (m < p.M) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int nb = nb0 + 8 * g;
+                for (int g2 = 0; g2 < 2; ++g2) {
+                    const int nb = nb0 + 8 * g2;
                     if (nb < p.N) {
-                        v4i o = {fin[jj][4 * g], fin[jj][4 * g + 1], fin[jj][4 * g + 2], fin[jj][4 * g + 3]};
+                        v4i o = {fin[k][4 * g2], fin[k][4 * g2 + 1], fin[k][4 * g2 + 2], fin[k][4 * g2 + 3]};
                         *reinterpret_cast<v4i*>(static_cast<int32_t*>(p.D) + (int64_t)m * p.N + nb) = o;
                     }
                 }
             }
             continue;
         }
-        v16f P;
+        const int tile = (group * KEEP + k) >> 1;
+        if (has_outliers && tile != ptile) { // (wave-uniform) both halves of a tile share its outlier product
+            ptile = tile;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) P[e] = 0.f;
-        if (has_outliers) {
-            const char* xo = smem + ow + (wn * 64 + nh * 32 + lr) * OSLICE;
-            const char* yo = smem + oa + (wm * 64 + jj * 32 + lr) * OSLICE;
+            for (int e = 0; e < 16; ++e) P[e] = 0.f;
+            const char* xo = smem + ow + (wn * L::WNT + t.i * 32 + lr) * OSLICE;
+            const char* yo = smem + oa + (wm * L::WMT + t.j * 32 + lr) * OSLICE;
             const int sw16 = lr & 15;
             if (osteps == 8) { // O = 128 (every shipped checkpoint): all sixteen fragment reads in flight, then eight MFMAs (same order, same sums)
                 v8h xfo[8], yfo[8];
@@ -209,31 +242,32 @@ __device__ __forceinline__ void mid_finish(const GemmParams& p, char* smem, v16i
             }
         }
         if (m < p.M) {
-            const float sa = pre.sa[jj];
+            const float sa = pre.sa[k];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int nb = nb0 + 8 * g;
+            for (int g2 = 0; g2 < 2; ++g2) {
+                const int nb = nb0 + 8 * g2;
                 if (nb < p.N) {
-                    const uint2 swb = pre.sw[g];
+                    const uint2 swb = pre.sw[k][g2];
                     const uint16_t swh[4] = {(uint16_t)(swb.x & 0xffffu), (uint16_t)(swb.x >> 16), (uint16_t)(swb.y & 0xffffu),
                                              (uint16_t)(swb.y >> 16)};
                     uint16_t yh[4] = {0, 0, 0, 0};
                     if (p.Y != nullptr) {
-                        const uint2 yb = pre.y[jj][g];
+                        const uint2 yb = pre.y[k][g2];
                         yh[0] = (uint16_t)(yb.x & 0xffffu), yh[1] = (uint16_t)(yb.x >> 16);
                         yh[2] = (uint16_t)(yb.y & 0xffffu), yh[3] = (uint16_t)(yb.y >> 16);
                     }
                     uint16_t oh[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        // addend: the fp16-rounded outlier product (cuBLAS writes fp16) or the caller's y
-                        const float c = has_outliers ? h2f(f2h_bits_of_f32_result(P[4 * g + e])) : h2f(yh[e]);
-                        float v = __builtin_fmaf((float)fin[jj][4 * g + e], h2f(swh[e]) * sa, c);
+                        // addend: the fp16-rounded outlier product (cuBLAS writes fp16) or the caller's y.  P element of (half gh, quad g2, e): 8 gh + 4 g2 + e
+                        const float pe = t.gh ? P[8 + 4 * g2 + e] : P[4 * g2 + e];
+                        const float c = has_outliers ? h2f(f2h_bits_of_f32_result(pe)) : h2f(yh[e]);
+                        float v = __builtin_fmaf((float)fin[k][4 * g2 + e], h2f(swh[e]) * sa, c);
                         if (epi_has_silu(EPI)) v = silu_f32(v);
                         oh[e] = f2h_bits_of_f32_result(v);
                     }
                     if (EPI == EPI_DEQUANT_SILU_MUL) { // gate * up: one fp16 multiply of the rounded result
-                        const uint2 mb = mulq[jj][g];
+                        const uint2 mb = mulq[k][g2];
                         const uint16_t mh[4] = {(uint16_t)(mb.x & 0xffffu), (uint16_t)(mb.x >> 16), (uint16_t)(mb.y & 0xffffu),
                                                 (uint16_t)(mb.y >> 16)};
 #pragma unroll
@@ -254,15 +288,15 @@ __device__ __forceinline__ void mid_finish(const GemmParams& p, char* smem, v16i
     }
 }
 
-// ---- copy-only waves: the outlier operands -> LDS (wave lw = 0: the fpW tile, 1: the fpA tile; 32 copies of 1 KiB, not waited for here) -----
-__device__ __forceinline__ void mid_stage_outliers(const GemmParams& p, unsigned lds_dst, int lw, int lane, int m0, int n0)
+// ---- copy-only waves: an outlier operand tile -> LDS (`rows` rows of 256 B: rows / 4 copies of 1 KiB, not waited for here) -----------------
+__device__ __forceinline__ void mid_stage_outliers(const GemmParams& p, unsigned lds_dst, int lw, int lane, int m0, int n0, int rows)
 {
     using namespace mid;
     const int rows_total = lw == 0 ? p.N : p.M, r0 = lw == 0 ? n0 : m0;
     const int obytes = p.O * 2;
     const char* const ob = lw == 0 ? reinterpret_cast<const char*>(p.fpW) : reinterpret_cast<const char*>(p.fpA);
 #pragma unroll 8
-    for (int q = 0; q < 32; ++q) { // 256-B rows, slot = chunk ^ (row & 15); chunks past O come from the zero page
+    for (int q = 0; q < rows / 4; ++q) { // 256-B rows, slot = chunk ^ (row & 15); chunks past O come from the zero page
         const int row = q * 4 + (lane >> 4);
         const int c = ((lane & 15) ^ (row & 15)) << 4;
         const int grow = min(r0 + row, rows_total - 1);
@@ -272,10 +306,12 @@ __device__ __forceinline__ void mid_stage_outliers(const GemmParams& p, unsigned
     }
 }
 
-template <int EPI, bool XSP>
+template <int EPI, bool XSP, int BN>
 __global__ __launch_bounds__(mid::T) void gemm_w8a8o16_mid_kernel(const GemmParams p)
 {
     using namespace mid;
+    using L = Layout<BN>;
+    constexpr int XB = L::XB, STAGE = L::STAGE, TMW = L::TMW, TNW = L::TNW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int XS = XSP ? p.xsplit : 1;
     const int tid = threadIdx.x;
@@ -308,14 +344,21 @@ __global__ __launch_bounds__(mid::T) void gemm_w8a8o16_mid_kernel(const GemmPara
     const int npair = (nk + 1) >> 1;
     const bool has_outliers = p.O > 0;
     const unsigned lds0 = (unsigned)(size_t)(MIXQ_LDS_PTR(smem));
+    // (pair P = npair - 1 is the last: its slices 2P, 2P + 1 sit in stages 2P % 5, (2P + 1) % 5 -> the exchange, behind B0.  The other three
+    //  stages -- a = (2P + 2) % 5, a + 1, a + 2 (mod 5) -- are free once the last loop barrier is passed; two of them are adjacent in memory
+    //  (a, a + 1 unless a = 4: then 0, 1) -> the fpA tile (32 KiB) followed by the fpW tile (BN x 256 B), which may straddle the stage border)
+    const int st_ex0 = ((2 * npair - 2) % NST) * STAGE, st_ex1 = ((2 * npair - 1) % NST) * STAGE;
+    const int st_a = (2 * npair) % NST;
+    const int st_oa = (st_a <= 3 ? st_a : 0) * STAGE, st_ow = st_oa + BM * OSLICE;
 
     if (wave >= NCW) {
         // =================================== loader wave: copies and barriers, nothing else ===================================
         const int lw = wave - NCW; // 0: W rows -> region X, 1: qA rows -> region Y
+        const int per = lw == 0 ? L::PERX : L::PERY; // (wave-uniform)
         const int rows_total = lw == 0 ? p.N : p.M, r0 = lw == 0 ? n0 : m0;
-        unsigned voff[PER];
+        unsigned voff[L::PERY];
 #pragma unroll
-        for (int i = 0; i < PER; ++i) { // LDS row = i * 8 + lane / 8, 16-B slot lane % 8 holds source chunk slot ^ ((row >> 1) & 7)
+        for (int i = 0; i < L::PERY; ++i) { // LDS row = i * 8 + lane / 8, 16-B slot lane % 8 holds source chunk slot ^ ((row >> 1) & 7)
             const int row = i * 8 + (lane >> 3);
             const int rr = min(r0 + row, rows_total - 1) - r0; // clamp: rows past the edge are copied but never stored
             voff[i] = (unsigned)rr * (unsigned)p.K + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
@@ -323,11 +366,8 @@ __global__ __launch_bounds__(mid::T) void gemm_w8a8o16_mid_kernel(const GemmPara
         const char* const base = (lw == 0 ? reinterpret_cast<const char*>(p.B) : reinterpret_cast<const char*>(p.A)) +
                                  (int64_t)r0 * K + (int64_t)kbeg * KS;
         const bool nt = lw == 0 && (p.flags & 2) != 0;
-        // Tiles that share a W panel (the tile rows of one tile column) run at the same time on neighbouring CUs.  Walking K from the same
-        // slice they ask for the same cold lines at the same moment: one is the miss, the others wait on it, and every one of them has a queue
-        // slot tied up for the whole HBM round trip (a CU keeps ~32 KiB of requests outstanding, R6.5).  Each tile row therefore STARTS at a
-        // different slice of its K range (integer sums commute: same bits): a line is then fetched from HBM by one CU and found in L2 / the
-        // Infinity Cache by the others a few microseconds later.  (p.flags bit 2 off: measurement knob 1411.)
+        // (measurement option, off by default -- launch_mid_epi: tiles that share a W panel start at DIFFERENT slices of their K range, so that a
+        //  cold line is fetched from HBM by one CU and found in L2 / the Infinity Cache by the others later; integer sums commute: same bits)
         const int rot = (p.flags & 4) ? (int)(((int64_t)tile_m * nk) / tiles_m + ((tile_n * 5) % 7)) % nk : 0;
         auto issue = [&](int s) __attribute__((always_inline)) {
             const unsigned dst = lds0 + (unsigned)(s % NST) * STAGE + lw * XB;
@@ -336,10 +376,13 @@ __global__ __launch_bounds__(mid::T) void gemm_w8a8o16_mid_kernel(const GemmPara
             const char* b = base + (int64_t)sr * KS; // wave-uniform
             if (nt) {
 #pragma unroll
-                for (int i = 0; i < PER; ++i) glds16_sbase_nt(b, voff[i], dst + i * 1024);
+                for (int i = 0; i < L::PERX; ++i) glds16_sbase_nt(b, voff[i], dst + i * 1024);
+            } else if (lw == 0) {
+#pragma unroll
+                for (int i = 0; i < L::PERX; ++i) glds16_sbase(b, voff[i], dst + i * 1024);
             } else {
 #pragma unroll
-                for (int i = 0; i < PER; ++i) glds16_sbase(b, voff[i], dst + i * 1024);
+                for (int i = 0; i < L::PERY; ++i) glds16_sbase(b, voff[i], dst + i * 1024);
             }
         };
 #pragma unroll
@@ -349,18 +392,19 @@ __global__ __launch_bounds__(mid::T) void gemm_w8a8o16_mid_kernel(const GemmPara
         for (int j = 0; j < npair; ++j) {
             // issued so far: slices .. 2j + 2; the pair 2j, 2j + 1 must have landed (copies complete in order)
             const unsigned long long ta = p.dbg ? wall_clock64() : 0;
-            if (2 * j + 2 < nk) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (2 * j + 2 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (lw == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::PERX) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::PERY) : "memory");
             const unsigned long long tb = p.dbg ? wall_clock64() : 0;
             __syncthreads(); // pair j handed over; the compute waves are done with pair j - 1
             if (p.dbg) t_wait += tb - ta, t_bar += wall_clock64() - tb;
             if (2 * j + 3 < nk) issue(2 * j + 3);
             if (2 * j + 4 < nk) issue(2 * j + 4);
         }
+        (void)per;
         // the outlier operands go into the two stages the LAST BUT ONE pair has just handed back (nothing is issued into them any more), so
         // that they land under the last pair's MFMAs and the exchange instead of behind it; the exchange takes the last pair's own stages
-        const bool has_o = EPI != EPI_INT32 && has_outliers;
-        if (has_o) mid_stage_outliers(p, lds0 + (unsigned)((2 * npair + 1 + lw) % NST) * STAGE, lw, lane, m0, n0);
+        if (EPI != EPI_INT32 && has_outliers) mid_stage_outliers(p, lds0 + (unsigned)(lw == 0 ? st_ow : st_oa), lw, lane, m0, n0, lw == 0 ? BN : BM);
         if (p.dbg != nullptr && lane == 0) // slot 7: the W loader, slot 2: the qA loader; (ticks waiting for copies) << 32 | ticks at the barrier
             static_cast<unsigned long long*>(p.dbg)[(size_t)blockIdx.x * 8 + (lw == 0 ? 7 : 2)] = (t_wait << 32) | (t_bar & 0xffffffffull);
         __syncthreads(); // B0
@@ -376,22 +420,22 @@ __global__ __launch_bounds__(mid::T) void gemm_w8a8o16_mid_kernel(const GemmPara
     // ======================================== compute wave ========================================
     const int group = wave >> 2;          // slices group, group + 2, ...
     const int w4 = wave & 3;
-    const int wm = w4 >> 1, wn = w4 & 1;  // 2 x 2 waves of 64 x 64 inside the group
+    const int wm = w4 / L::WNW, wn = w4 % L::WNW;
     const int lr = lane & 31, lh = lane >> 5;
     const int sw = (lr >> 1) & 7;
     int koff[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) koff[ks] = ((ks * 2 + lh) ^ sw) << 4;
-    const int xrow = (wn * 64 + lr) * KS;
-    const int yrow = XB + (wm * 64 + lr) * KS;
+    const int xrow = (wn * L::WNT + lr) * KS;
+    const int yrow = XB + (wm * L::WMT + lr) * KS;
 
-    MidEpiPre pre;
-    mid_epi_prefetch<EPI>(pre, p, wave, lane, m0, n0);
-    v16i acc[2][2]; // [n half][m half]
+    MidEpiPre<L::KEEP> pre;
+    mid_epi_prefetch<EPI, L>(pre, p, wave, lane, m0, n0);
+    v16i acc[TNW][TMW]; // [n tile][m tile]
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TNW; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TMW; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
 
@@ -402,39 +446,69 @@ __global__ __launch_bounds__(mid::T) void gemm_w8a8o16_mid_kernel(const GemmPara
         const int kt = 2 * j + group;
         if (kt < nk) {
             const char* base = smem + (kt % NST) * STAGE;
-            v4i xf[2][2], yf[2][2]; // [buffer][half]: fragments of k-step ks + 1 are requested before the MFMAs of k-step ks
+            v4i xf[2][TNW], yf[2][TMW]; // [buffer][tile]: fragments of k-step ks + 1 are requested before the MFMAs of k-step ks
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                xf[0][h] = *reinterpret_cast<const v4i*>(base + xrow + h * 32 * KS + koff[0]);
-                yf[0][h] = *reinterpret_cast<const v4i*>(base + yrow + h * 32 * KS + koff[0]);
-            }
+            for (int h = 0; h < TNW; ++h) xf[0][h] = *reinterpret_cast<const v4i*>(base + xrow + h * 32 * KS + koff[0]);
+#pragma unroll
+            for (int h = 0; h < TMW; ++h) yf[0][h] = *reinterpret_cast<const v4i*>(base + yrow + h * 32 * KS + koff[0]);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int cur = ks & 1, nxt = cur ^ 1;
                 if (ks + 1 < 4) {
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        xf[nxt][h] = *reinterpret_cast<const v4i*>(base + xrow + h * 32 * KS + koff[ks + 1]);
-                        yf[nxt][h] = *reinterpret_cast<const v4i*>(base + yrow + h * 32 * KS + koff[ks + 1]);
-                    }
+                    for (int h = 0; h < TNW; ++h) xf[nxt][h] = *reinterpret_cast<const v4i*>(base + xrow + h * 32 * KS + koff[ks + 1]);
+#pragma unroll
+                    for (int h = 0; h < TMW; ++h) yf[nxt][h] = *reinterpret_cast<const v4i*>(base + yrow + h * 32 * KS + koff[ks + 1]);
                 }
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < TNW; ++i)
 #pragma unroll
-                    for (int jj = 0; jj < 2; ++jj)
+                    for (int jj = 0; jj < TMW; ++jj)
                         acc[i][jj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xf[cur][i], yf[cur][jj], acc[i][jj], 0, 0, 0);
             }
         }
     }
-
-    // (pair P = npair - 1 is the last: its slices 2P, 2P + 1 sit in stages 2P % 5, (2P + 1) % 5 -> the exchange; the pair before it in
-    //  (2P + 3) % 5, (2P + 4) % 5 -> the outlier tiles)
-    mid_finish<EPI, XSP, TC>(p, smem, acc, wave, lane, tid, m0, n0, t_lin, xrank, XS, pre, ((2 * npair - 2) % NST) * STAGE, ((2 * npair - 1) % NST) * STAGE,
-                             ((2 * npair + 1) % NST) * STAGE, ((2 * npair + 2) % NST) * STAGE);
+    mid_finish<EPI, XSP, L>(p, smem, acc, wave, lane, tid, m0, n0, t_lin, xrank, XS, pre, st_ex0, st_ex1, st_ow, st_oa);
 }
 
-static std::atomic<int> g_mid_rot{1}; // measurement knob 1410 (default: where the tiles are not split along K) / 1411 (never) / 1412 (always): tile rows start at different K slices
+static std::atomic<int> g_mid_rot{0}; // measurement knob 1411 (default: never) / 1410 (where the tiles are not split along K) / 1412 (always): tile rows start at different K slices
 void set_mid_rot(int mode) { g_mid_rot.store(mode); }
+static std::atomic<int> g_mid_bn{0};  // measurement knob 1430 (default: by rule) / 1431 (always 128) / 1432 (96 wherever it leaves at most one workgroup per CU)
+void set_mid_bn(int mode) { g_mid_bn.store(mode); }
+
+// 96-wide tiles where they put MORE workgroups on the chip than 128-wide ones and still leave a sixteenth of the CUs free (tiles alone, no K
+// split).  Cold, us per GEMM, 128-wide -> 96-wide (profiles/r06_mid_bn96_cold.txt): 11008 x 4096 at 160 / 192 / 256 rows (172 -> 230 workgroups)
+// 25.1 / 25.0 / 25.5 -> 24.0 / 24.3 / 25.0, 4608 x 3584 at 512 rows (144 -> 192) 20.7 -> 19.8; but 12288 x 4096 at 256 rows (192 -> 256 = EVERY CU)
+// 26.8 -> 29.6: a launch that needs every CU at once runs at the pace of the chip's slowest one (notebook R4.13 saw the same on the 256 x 256
+// K split), hence the margin.  The gain where it applies is 2-4 %: the cold weight stream does not go faster with more CUs asking (R6.7).
+int gemm_mid_tile_width(int M, int N, int xsplit)
+{
+    const int mode = g_mid_bn.load();
+    const int tm = (M + mid::BM - 1) / mid::BM;
+    const int t128 = tm * ((N + 127) / 128), t96 = tm * ((N + 95) / 96);
+    const bool fits96 = xsplit <= 1 && 16 * t96 <= 15 * num_cus() && t96 > t128;
+    if (mode == 1) return 128;
+    return fits96 ? 96 : 128;
+}
+
+template <int EPI, int BN>
+static hipError_t launch_mid_cfg(const GemmParams& q, hipStream_t st)
+{
+    using L = mid::Layout<BN>;
+    const int tiles = ((q.M + mid::BM - 1) / mid::BM) * ((q.N + BN - 1) / BN);
+    if (q.xsplit > 1) {
+        auto kern = gemm_w8a8o16_mid_kernel<EPI, true, BN>;
+        static DeviceOnce once;
+        if (hipError_t e = ensure_dynamic_lds(kern, L::LDS, once); e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * q.xsplit)), dim3(mid::T), L::LDS, st, q);
+    } else {
+        auto kern = gemm_w8a8o16_mid_kernel<EPI, false, BN>;
+        static DeviceOnce once;
+        if (hipError_t e = ensure_dynamic_lds(kern, L::LDS, once); e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(mid::T), L::LDS, st, q);
+    }
+    return hipGetLastError();
+}
 
 template <int EPI>
 static hipError_t launch_mid_epi(const GemmParams& p, hipStream_t st)
@@ -443,25 +517,14 @@ static hipError_t launch_mid_epi(const GemmParams& p, hipStream_t st)
     // one tile row: every weight line is read by exactly one workgroup -> non-temporal copies for weights of 32 MiB and more
     // (the rule of gemm_kernels.hip's launch_cfg)
     if (p.M <= mid::BM && (int64_t)p.N * p.K >= ((int64_t)32 << 20)) q.flags |= 2;
-    // (the walk is rotated where the tiles alone fill the chip: cold, h vs j in profiles/r06_mid_final_sweep_cold.txt, ahead in every such cell, by up
-    //  to 16 %.  With K split over workgroups the parts of a tile already start at different slices, and rotating them as well is BIMODAL --
-    //  4096 x 11008 at 256 rows with four parts ran 29.5 us in one process and 35 us in the next, at 512 rows with two parts 39.7 / 47.9 -- and
-    //  tripped the selection gate (+16.8 % behind the round-5 build): not rotated.  Knob 1412 rotates always, for measurements.)
+    // (rotated K walk -- every tile row starting at its own slice, p.flags bit 2 -- is OFF by default: over three cold sweeps on different boxes it
+    //  was ahead by 2-7 % in about half of the unsplit cells and behind by as much in the others (profiles/r06_mid_final_sweep_cold.txt,
+    //  r06_mid_bn96_cold.txt: h1 vs j1), 4-8 % behind warm, and bimodal with K split over workgroups (4096 x 11008 at 256 rows, four parts:
+    //  29.5 us in one process, 35 in the next -- it tripped the selection gate).  Knobs 1410 / 1412 switch it on for unsplit tiles / always.)
     const int rotm = g_mid_rot.load();
     if (rotm == 2 || (rotm == 1 && p.xsplit <= 1)) q.flags |= 4;
-    const int tiles = ((p.M + mid::BM - 1) / mid::BM) * ((p.N + mid::BN - 1) / mid::BN);
-    if (p.xsplit > 1) {
-        auto kern = gemm_w8a8o16_mid_kernel<EPI, true>;
-        static DeviceOnce once;
-        if (hipError_t e = ensure_dynamic_lds(kern, mid::LDS, once); e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * p.xsplit)), dim3(mid::T), mid::LDS, st, q);
-    } else {
-        auto kern = gemm_w8a8o16_mid_kernel<EPI, false>;
-        static DeviceOnce once;
-        if (hipError_t e = ensure_dynamic_lds(kern, mid::LDS, once); e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(mid::T), mid::LDS, st, q);
-    }
-    return hipGetLastError();
+    if (gemm_mid_tile_width(p.M, p.N, p.xsplit) == 96) return launch_mid_cfg<EPI, 96>(q, st);
+    return launch_mid_cfg<EPI, 128>(q, st);
 }
 
 // p.xsplit = workgroups per tile along K (1: the tiles alone); K % 128 == 0

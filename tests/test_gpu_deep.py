@@ -31,7 +31,7 @@ SHAPES = [(300, 528, 2064),     # ragged M and N, partial last K slice, 3 x 5 ti
           (200, 784, 4352)]
 
 
-@pytest.mark.parametrize("build", [0, 10, 20, 30, 31])   # 4 waves x 64 x 64 | 8 waves x 64 x 32 | 8 waves, 5 stages | round 6: copy-only waves, one barrier per pair of slices (gemm_mid_kernels.hip; 30: every tile row starting at its own K slice, 31: all from slice 0; K % 128 != 0 falls back to build 10)
+@pytest.mark.parametrize("build", [0, 10, 20, 30, 31, 32])   # 4 waves x 64 x 64 | 8 waves x 64 x 32 | 8 waves, 5 stages | round 6: copy-only waves, one barrier per pair of slices (gemm_mid_kernels.hip; 30: every tile row starting at its own K slice -- a measurement option --, 31: all from slice 0 = the default, 32: 128-wide tiles always -- by rule the unsplit cases here take 96-wide ones; K % 128 != 0 falls back to build 10)
 @pytest.mark.parametrize("xs", [1, 2, 4, 8])
 @pytest.mark.parametrize("M,N,K", SHAPES)
 @pytest.mark.parametrize("O", [128, 0, 40, 256])   # 256: side GEMM first, then the addend form (C = D = Out)
@@ -39,7 +39,7 @@ def test_deep_form_gives_the_bits_of_the_one_workgroup_form(lib, build, xs, M, N
     if build == 0 and O in (40, 256) or build == 20 and O != 128:
         pytest.skip("a subset for the builds the table does not select")
     if build >= 30:
-        lib.mixq_debug_set_gemm_variant(1412 - (build - 30))
+        lib.mixq_debug_set_gemm_variant(1431 if build == 32 else 1412 - (build - 30))
         build = 30
     if xs == 8:
         K = 2 * K + 16          # 8 ways need >= 32 K slices
