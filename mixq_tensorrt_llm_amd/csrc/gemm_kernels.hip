@@ -707,8 +707,8 @@ void set_gemm_variant(int v)
         set_mid_bn(v - 1430);
         return;
     }
-    if (v >= 1410 && v <= 1412) { // round-6 mid kernel: tile rows start at different K slices: 1411 never (default) / 1410 where K is not split over workgroups / 1412 always
-        set_mid_rot(v == 1410 ? 1 : v == 1411 ? 0 : 2);
+    if (v >= 1410 && v <= 1413) { // round-6 mid kernel: tile rows start at different K slices: 1413 by the measured rule (default: 4..7 tile rows, K not split) / 1411 never / 1410 where K is not split over workgroups / 1412 always
+        set_mid_rot(v == 1410 ? 1 : v == 1411 ? 0 : v == 1412 ? 2 : 3);
         return;
     }
     if (v >= 1240 && v <= 1279) { // mid-M deep form: 1240 automatic, 1241 off, 1241 + xs (1242 / 1243 / 1245 / 1249) forced, + 10 the 8-wave build, + 30 the round-6 schedule

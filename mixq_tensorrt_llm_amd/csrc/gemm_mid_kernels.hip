@@ -471,7 +471,7 @@ __global__ __launch_bounds__(mid::T) void gemm_w8a8o16_mid_kernel(const GemmPara
     mid_finish<EPI, XSP, L>(p, smem, acc, wave, lane, tid, m0, n0, t_lin, xrank, XS, pre, st_ex0, st_ex1, st_ow, st_oa);
 }
 
-static std::atomic<int> g_mid_rot{0}; // measurement knob 1411 (default: never) / 1410 (where the tiles are not split along K) / 1412 (always): tile rows start at different K slices
+static std::atomic<int> g_mid_rot{3}; // measurement knob 1413 (default: by rule) / 1411 (never) / 1410 (where the tiles are not split along K) / 1412 (always): tile rows start at different K slices
 void set_mid_rot(int mode) { g_mid_rot.store(mode); }
 static std::atomic<int> g_mid_bn{0};  // measurement knob 1430 (default: by rule) / 1431 (always 128) / 1432 (96 wherever it leaves at most one workgroup per CU)
 void set_mid_bn(int mode) { g_mid_bn.store(mode); }
@@ -517,12 +517,16 @@ static hipError_t launch_mid_epi(const GemmParams& p, hipStream_t st)
     // one tile row: every weight line is read by exactly one workgroup -> non-temporal copies for weights of 32 MiB and more
     // (the rule of gemm_kernels.hip's launch_cfg)
     if (p.M <= mid::BM && (int64_t)p.N * p.K >= ((int64_t)32 << 20)) q.flags |= 2;
-    // (rotated K walk -- every tile row starting at its own slice, p.flags bit 2 -- is OFF by default: over three cold sweeps on different boxes it
-    //  was ahead by 2-7 % in about half of the unsplit cells and behind by as much in the others (profiles/r06_mid_final_sweep_cold.txt,
-    //  r06_mid_bn96_cold.txt: h1 vs j1), 4-8 % behind warm, and bimodal with K split over workgroups (4096 x 11008 at 256 rows, four parts:
-    //  29.5 us in one process, 35 in the next -- it tripped the selection gate).  Knobs 1410 / 1412 switch it on for unsplit tiles / always.)
+    // Rotated K walk (every tile row starts at its own slice, p.flags bit 2; integer sums commute: same bits): the tile rows of a column panel
+    // then miss on DIFFERENT weight lines at any moment instead of all waiting for the same ones.  Taken where it measured ahead on three of
+    // three boxes, cold: 4..7 tile rows, tiles not split along K (4608 x 3584 at 512 / 768 rows 24.2 / 24.5 -> 20.6 / 22.7, 22.1 / 25.0 -> 19.8 / 23.7,
+    // 22.1 / 25.5 -> 20.8 / 24.6 us; 4096 x 4096 at 768 rows 26.0 -> 22.9, 26.0 -> 24.3, 26.3 -> 25.1; warm: level) -- profiles/r06_mid_final_sweep_cold.txt,
+    // r06_mid_bn96_cold.txt, r06_mid_rot_rows_cold.txt.  Not with two tile rows (12288 / 11008 x 4096 at 256 rows: ahead on one box, behind on two, 8 %
+    // behind warm), not at 8 rows (+2 %), and not with K split over workgroups: bimodal there (4096 x 11008 at 256 rows, four parts: 29.5 us in one
+    // process, 35 in the next -- it tripped the selection gate).  Knobs 1411 / 1410 / 1412: never / every unsplit launch / always.
     const int rotm = g_mid_rot.load();
-    if (rotm == 2 || (rotm == 1 && p.xsplit <= 1)) q.flags |= 4;
+    const int tile_rows = (p.M + mid::BM - 1) / mid::BM;
+    if (rotm == 2 || (rotm == 1 && p.xsplit <= 1) || (rotm == 3 && p.xsplit <= 1 && tile_rows >= 4 && tile_rows <= 7)) q.flags |= 4;
     if (gemm_mid_tile_width(p.M, p.N, p.xsplit) == 96) return launch_mid_cfg<EPI, 96>(q, st);
     return launch_mid_cfg<EPI, 128>(q, st);
 }

@@ -125,7 +125,7 @@ void set_deep_force(int v);
 hipError_t launch_gemm_deep(const GemmParams& p, int epi, hipStream_t st);
 // round-6 schedule of the same tiles (gemm_mid_kernels.hip): 2 copy-only waves + 8 compute waves, one barrier per pair of slices; p.xsplit workgroups per tile
 hipError_t launch_gemm_mid(const GemmParams& p, int epi, hipStream_t st);
-void set_mid_rot(int mode);  // measurement knob 1410 (default: 1 = by rule) / 1411 (0 = never) / 1412 (2 = always)
+void set_mid_rot(int mode);  // measurement knob 1413 (default: 3 = by rule) / 1411 (0 = never) / 1410 (1 = unsplit tiles) / 1412 (2 = always)
 void set_mid_bn(int mode);   // measurement knob 1430 (default: 0 = by rule) / 1431 (1 = 128-wide tiles always)
 int gemm_mid_tile_width(int M, int N, int xsplit); // 128 | 96: the tile width launch_gemm_mid takes
 bool gemm_skinny_supported(const GemmParams& p);
