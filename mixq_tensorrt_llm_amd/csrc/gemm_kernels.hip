@@ -703,7 +703,7 @@ void set_gemm_variant(int v)
         g_deep_mid.store(v == 1420);
         return;
     }
-    if (v == 1430 || v == 1431) { // round-6 mid kernel: tile width by rule (1430, default: 96 where that puts more workgroups on the chip) / 128 always (1431)
+    if (v == 1430 || v == 1431 || v == 1432) { // round-6 mid kernel: tile width by rule (1430, default: 96 where that puts more workgroups on the chip) / 128 always (1431)
         set_mid_bn(v - 1430);
         return;
     }

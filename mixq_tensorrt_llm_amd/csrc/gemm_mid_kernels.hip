@@ -473,21 +473,23 @@ __global__ __launch_bounds__(mid::T) void gemm_w8a8o16_mid_kernel(const GemmPara
 
 static std::atomic<int> g_mid_rot{3}; // measurement knob 1413 (default: by rule) / 1411 (never) / 1410 (where the tiles are not split along K) / 1412 (always): tile rows start at different K slices
 void set_mid_rot(int mode) { g_mid_rot.store(mode); }
-static std::atomic<int> g_mid_bn{0};  // measurement knob 1430 (default: by rule) / 1431 (always 128) / 1432 (96 wherever it leaves at most one workgroup per CU)
+static std::atomic<int> g_mid_bn{0};  // measurement knob 1430 (default: by rule) / 1431 (always 128) / 1432 (96-wide only where a sixteenth of the CUs stays free)
 void set_mid_bn(int mode) { g_mid_bn.store(mode); }
 
-// 96-wide tiles where they put MORE workgroups on the chip than 128-wide ones and still leave a sixteenth of the CUs free (tiles alone, no K
-// split).  Cold, us per GEMM, 128-wide -> 96-wide (profiles/r06_mid_bn96_cold.txt): 11008 x 4096 at 160 / 192 / 256 rows (172 -> 230 workgroups)
-// 25.1 / 25.0 / 25.5 -> 24.0 / 24.3 / 25.0, 4608 x 3584 at 512 rows (144 -> 192) 20.7 -> 19.8; but 12288 x 4096 at 256 rows (192 -> 256 = EVERY CU)
-// 26.8 -> 29.6: a launch that needs every CU at once runs at the pace of the chip's slowest one (notebook R4.13 saw the same on the 256 x 256
-// K split), hence the margin.  The gain where it applies is 2-4 %: the cold weight stream does not go faster with more CUs asking (R6.7).
+// 96-wide tiles where they put MORE workgroups on the chip than 128-wide ones, up to one per CU (tiles alone, no K split): the cold weight stream
+// of a launch is paced by CUs x what one CU pulls (15-18 GB/s, R6.7 / R6.14), so more CUs asking IS more stream.  Cold, us per GEMM, 128-wide -> 96-wide:
+// 12288 x 4096 at 160 / 192 / 224 / 256 rows (192 -> 256 workgroups = every CU) 24.7 / 25.4 / 26.3 / 27.5 -> 23.3 / 24.4 / 24.9 / 25.4 (profiles/r06_mid_bn96_all_cus.txt),
+// 11008 x 4096 at 160 / 192 / 256 rows (172 -> 230) 25.1 / 25.0 / 25.5 -> 24.0 / 24.3 / 25.0, 4608 x 3584 at 512 rows (144 -> 192) 20.7 -> 19.8
+// (profiles/r06_mid_bn96_cold.txt); warm: level.  (A first measurement of the 256-workgroup case -- 26.8 -> 29.6 -- had the rotated K walk switched on as well,
+// which is what loses with two tile rows (R6.15); knob 1432 keeps the sixteenth of the CUs free that it led to, for A/B.)
 int gemm_mid_tile_width(int M, int N, int xsplit)
 {
     const int mode = g_mid_bn.load();
     const int tm = (M + mid::BM - 1) / mid::BM;
     const int t128 = tm * ((N + 127) / 128), t96 = tm * ((N + 95) / 96);
-    const bool fits96 = xsplit <= 1 && 16 * t96 <= 15 * num_cus() && t96 > t128;
+    const bool fits96 = xsplit <= 1 && t96 <= num_cus() && t96 > t128;
     if (mode == 1) return 128;
+    if (mode == 2) return fits96 && 16 * t96 <= 15 * num_cus() ? 96 : 128; // (measurement: a sixteenth of the CUs left free)
     return fits96 ? 96 : 128;
 }
 
