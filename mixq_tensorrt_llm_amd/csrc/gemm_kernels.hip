@@ -594,7 +594,11 @@ bool gemm_deep_takes(int M, int N, int K, bool have_scratch)
 size_t gemm_deep_workspace_size(int M, int N, int K)
 {
     const DeepPlan pl = deep_plan(M, N, K);
-    return pl.xs > 1 ? kSplitkWordsBytes + (size_t)pl.tiles * pl.xs * (size_t)(128 * 128 * 4) : 0;
+    if (pl.xs <= 1) return 0;
+    // a parked tile is 128 x 128 or -- the mid kernel's 96-wide tiles, gemm_mid_tile_width -- 128 x 96 int32: room for whichever count x size is larger
+    const size_t t96 = (size_t)((M + 127) / 128) * ((N + 95) / 96);
+    const size_t b128 = (size_t)pl.tiles * (128 * 128 * 4), b96 = t96 * (128 * 96 * 4);
+    return kSplitkWordsBytes + (b128 > b96 ? b128 : b96) * pl.xs;
 }
 void set_deep_force(int v) { g_deep_force.store(v); }
 
@@ -703,7 +707,7 @@ void set_gemm_variant(int v)
         g_deep_mid.store(v == 1420);
         return;
     }
-    if (v == 1430 || v == 1431 || v == 1432) { // round-6 mid kernel: tile width by rule (1430, default: 96 where that puts more workgroups on the chip) / 128 always (1431)
+    if (v >= 1430 && v <= 1433) { // round-6 mid kernel: tile width by rule (1430, default: 96 where that puts more workgroups on the chip) / 128 always (1431)
         set_mid_bn(v - 1430);
         return;
     }

@@ -473,23 +473,26 @@ __global__ __launch_bounds__(mid::T) void gemm_w8a8o16_mid_kernel(const GemmPara
 
 static std::atomic<int> g_mid_rot{3}; // measurement knob 1413 (default: by rule) / 1411 (never) / 1410 (where the tiles are not split along K) / 1412 (always): tile rows start at different K slices
 void set_mid_rot(int mode) { g_mid_rot.store(mode); }
-static std::atomic<int> g_mid_bn{0};  // measurement knob 1430 (default: by rule) / 1431 (always 128) / 1432 (96-wide only where a sixteenth of the CUs stays free)
+static std::atomic<int> g_mid_bn{0};  // measurement knob 1430 (default: by rule) / 1431 (always 128) / 1432 (96-wide only where a sixteenth of the CUs stays free) / 1433 (96-wide only without K split)
 void set_mid_bn(int mode) { g_mid_bn.store(mode); }
 
-// 96-wide tiles where they put MORE workgroups on the chip than 128-wide ones, up to one per CU (tiles alone, no K split): the cold weight stream
+// 96-wide tiles where they put MORE workgroups on the chip than 128-wide ones, up to one per CU (workgroups = tiles x parts along K): the cold weight stream
 // of a launch is paced by CUs x what one CU pulls (15-18 GB/s, R6.7 / R6.14), so more CUs asking IS more stream.  Cold, us per GEMM, 128-wide -> 96-wide:
 // 12288 x 4096 at 160 / 192 / 224 / 256 rows (192 -> 256 workgroups = every CU) 24.7 / 25.4 / 26.3 / 27.5 -> 23.3 / 24.4 / 24.9 / 25.4 (profiles/r06_mid_bn96_all_cus.txt),
 // 11008 x 4096 at 160 / 192 / 256 rows (172 -> 230) 25.1 / 25.0 / 25.5 -> 24.0 / 24.3 / 25.0, 4608 x 3584 at 512 rows (144 -> 192) 20.7 -> 19.8
-// (profiles/r06_mid_bn96_cold.txt); warm: level.  (A first measurement of the 256-workgroup case -- 26.8 -> 29.6 -- had the rotated K walk switched on as well,
+// (profiles/r06_mid_bn96_cold.txt); with K split over workgroups (R6.23, profiles/r06_mid_bn96_xsplit.txt): 3584 x 8192 at 320 / 384 rows, two parts (168 -> 228 workgroups)
+// 27.7 / 29.4 -> 26.6 / 27.3, 1280 x 8192 at 512 rows, four parts (160 -> 224) 22.5 -> 21.4, at 1024 rows, two parts 29.1 -> 27.2; warm: level.  (A first measurement of the 256-workgroup case -- 26.8 -> 29.6 -- had the rotated K walk switched on as well,
 // which is what loses with two tile rows (R6.15); knob 1432 keeps the sixteenth of the CUs free that it led to, for A/B.)
 int gemm_mid_tile_width(int M, int N, int xsplit)
 {
     const int mode = g_mid_bn.load();
     const int tm = (M + mid::BM - 1) / mid::BM;
     const int t128 = tm * ((N + 127) / 128), t96 = tm * ((N + 95) / 96);
-    const bool fits96 = xsplit <= 1 && t96 <= num_cus() && t96 > t128;
+    const int xs = xsplit > 1 ? xsplit : 1;
+    const bool fits96 = t96 * xs <= num_cus() && t96 > t128;
     if (mode == 1) return 128;
-    if (mode == 2) return fits96 && 16 * t96 <= 15 * num_cus() ? 96 : 128; // (measurement: a sixteenth of the CUs left free)
+    if (mode == 3) return fits96 && xs == 1 ? 96 : 128;                          // (measurement: not with K split over workgroups)
+    if (mode == 2) return fits96 && 16 * t96 * xs <= 15 * num_cus() ? 96 : 128;  // (measurement: a sixteenth of the CUs left free)
     return fits96 ? 96 : 128;
 }
 

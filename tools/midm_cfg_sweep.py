@@ -33,7 +33,7 @@ def main():
     scr = torch.zeros(int(lib.mixq_gemm_scratch_bound()) + (1 << 20), dtype=torch.uint8, device=dev)
     variants = [("auto", [0, 79, 69])] + [(f"c{i}", [70, 60, 10 + i]) for i in range(24)] + \
                [("pp128", [70, 60, 5]), ("pp256", [70, 60, 2]), ("s2", [0, 72]), ("s4", [0, 74]), ("s8", [0, 78])] + \
-               [(f"d{x}", [0, 1241 + x]) for x in (1, 2, 4, 8)] + [(f"e{x}", [0, 1251 + x]) for x in (1, 2, 4, 8)] + [(f"f{x}", [0, 1261 + x]) for x in (1, 2, 4, 8)] + [(f"g{x}", [0, 1251 + x, 1239]) for x in (1, 2, 4, 8)] + [(f"h{x}", [0, 1271 + x, 1412]) for x in (1, 2, 4, 8)] + [(f"j{x}", [0, 1271 + x, 1411]) for x in (1, 2, 4, 8)] + [("w1", [0, 1272, 1412, 1431])] + [("n1", [0, 1272, 1411, 1431]), ("m1", [0, 1272, 1411, 1432])]   # n1 / m1: not rotated, 128-wide always / 96-wide only where a sixteenth of the CUs stays free (the rule before R6.22)   # w1 = h1 on 128-wide tiles always   # round-6 schedule (gemm_mid_kernels.hip): K walk rotated per tile row (measurement option) / not (the default)   # j / k = h / i with every tile walking K from slice 0   # g = e with every wave issuing its copies before its MFMAs   # mid-M deep form (128 x 128, 4 stages in flight): 4- / 8-wave builds, x workgroups per tile
+               [(f"d{x}", [0, 1241 + x]) for x in (1, 2, 4, 8)] + [(f"e{x}", [0, 1251 + x]) for x in (1, 2, 4, 8)] + [(f"f{x}", [0, 1261 + x]) for x in (1, 2, 4, 8)] + [(f"g{x}", [0, 1251 + x, 1239]) for x in (1, 2, 4, 8)] + [(f"h{x}", [0, 1271 + x, 1412]) for x in (1, 2, 4, 8)] + [(f"j{x}", [0, 1271 + x, 1411]) for x in (1, 2, 4, 8)] + [("w1", [0, 1272, 1412, 1431])] + [(f"x{x}", [0, 1271 + x, 1411, 1433]) for x in (2, 4)]   # x = j with 96-wide tiles only where K is not split (the rule before R6.23) + [("n1", [0, 1272, 1411, 1431]), ("m1", [0, 1272, 1411, 1432])]   # n1 / m1: not rotated, 128-wide always / 96-wide only where a sixteenth of the CUs stays free (the rule before R6.22)   # w1 = h1 on 128-wide tiles always   # round-6 schedule (gemm_mid_kernels.hip): K walk rotated per tile row (measurement option) / not (the default)   # j / k = h / i with every tile walking K from slice 0   # g = e with every wave issuing its copies before its MFMAs   # mid-M deep form (128 x 128, 4 stages in flight): 4- / 8-wave builds, x workgroups per tile
     variants += [(f"xs{x}", [1, 70, 1241, 60 + (6 if x == 16 else x)]) for x in (2, 4, 8, 16)]   # two-barrier small tiles, K split over x workgroups
     if a.only:
         variants = [v for v in variants + [("plain", [0, 70]), ("nodeep", [0, 1241]), ("r5deep", [0, 1421])] if v[0] in a.only.split(",")]   # nodeep = automatic with the mid-M deep form off   # plain = automatic with the 256 x 256 K split off
@@ -59,7 +59,7 @@ def main():
                     continue
                 if name.startswith("xs") and nscr == 0:
                     continue
-                if name[0] in "defghjw" and name[1:].isdigit() and (nscr > scr.numel() or (nscr == 0 and name[1:] != "1")):
+                if name[0] in "defghjwx" and name[1:].isdigit() and (nscr > scr.numel() or (nscr == 0 and name[1:] != "1")):
                     continue
                 def fn():
                     w = Ws[turn[0] % len(Ws)]
